@@ -1,0 +1,648 @@
+"""oracle/oracle.py — TEST INFRASTRUCTURE ONLY (see oracle/quaff_oracle.c header).
+
+Python glue over oracle/liboracle.so (the plain-C CPU restatement) plus the
+host-side pieces of the reference that are easier to restate in Python:
+quaff's JSON formats read with gason's number parser, the null-model fit, the
+per-read align / count task logic and the Stockholm / SAM writers.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Each function cites the reference file:line it follows (/root/reference/...).
+"""
+import ctypes as C
+import gzip
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+NQUAL = 94
+NQ1 = 95
+NEG_INF = float("-inf")
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build():
+    """Compile the C restatement (gcc, no FMA contraction)."""
+    src = os.path.join(HERE, "quaff_oracle.c")
+    out = os.path.join(HERE, "liboracle.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, src, "-lm"])
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.qo_gason_number.restype = C.c_double
+        L.qo_gason_number.argtypes = [C.c_char_p]
+        L.qo_lse.restype = C.c_double
+        L.qo_lse.argtypes = [C.c_double, C.c_double]
+        L.qo_lse_table.restype = C.POINTER(C.c_double)
+        L.qo_log_negbinom.restype = C.c_double
+        L.qo_log_negbinom.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.qo_null_loglike.restype = C.c_double
+        L.qo_envelope_cells.restype = C.c_uint64
+        L.qo_viterbi.restype = C.c_double
+        L.qo_forward_backward.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+# ---------------------------------------------------------------- sequences
+def tokens(seq):
+    """FastSeq::tokens, src/fastseq.cpp:71-83 (raises on non-ACGT)."""
+    b = seq.encode() if isinstance(seq, str) else seq
+    out = np.empty(len(b), np.uint8)
+    rc = lib().qo_tokenize(b, len(b), out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("Unknown symbol %r at %d" % (chr(b[-rc - 1]), -rc - 1))
+    return out
+
+
+def quals(qual):
+    """FastSeq::qualScores, src/fastseq.cpp:101-109."""
+    b = qual.encode() if isinstance(qual, str) else qual
+    out = np.empty(len(b), np.uint8)
+    lib().qo_quals(b, len(b), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def kmers(tok, k):
+    """FastSeq::kmers, src/fastseq.cpp:85-99."""
+    out = np.empty(len(tok), np.uint32)
+    lib().qo_kmers(tok.ctypes.data_as(C.c_void_p), len(tok), int(k), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "a": "T", "c": "G", "g": "C", "t": "A"}
+
+
+def revcomp_str(s):
+    """revcomp(), src/fastseq.cpp:209-216 (dnaComplementChar upper-cases ACGT, keeps others)."""
+    return "".join(_COMP.get(c, c) for c in reversed(s))
+
+
+class FastSeq:
+    """name/comment/seq/qual (+ source coords), src/fastseq.h:41-72."""
+
+    def __init__(self, name, seq, qual="", comment="", source=None):
+        self.name, self.seq, self.qual, self.comment = name, seq, qual, comment
+        self.source = source  # (name, start, end, rev) or None
+
+    def has_qual(self):
+        return len(self.qual) == len(self.seq)
+
+    def revcomp(self):
+        """FastSeq::revcomp, src/fastseq.cpp:218-230 (+ compose :51-65)."""
+        src = compose(("" + self.name, 1, len(self.seq), True), self.source)
+        return FastSeq("revcomp(" + self.name + ")", revcomp_str(self.seq), self.qual[::-1], self.comment, src)
+
+
+def compose(c, src):
+    """SeqIntervalCoords::compose, src/fastseq.cpp:51-65."""
+    if src is None:
+        return c
+    name, start, end, rev = c
+    sname, sstart, send, srev = src
+    if srev:
+        return (sname, send - end + 1, send - start + 1, rev != srev)
+    return (sname, start + sstart - 1, end + sstart - 1, rev != srev)
+
+
+def read_fastx(path):
+    """readFastSeqs via kseq, src/fastseq.cpp:143-171: FASTA/FASTQ, optionally gzipped;
+    quality kept only if as long as the sequence (initFastSeq :133-141)."""
+    op = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    with op(path, "rt") as f:
+        lines = [l.rstrip("\n").rstrip("\r") for l in f]
+    seqs, i = [], 0
+    while i < len(lines):
+        if not lines[i] or lines[i][0] not in ">@":
+            i += 1
+            continue
+        hdr = lines[i][1:]
+        name, _, comment = hdr.partition(" ")
+        i += 1
+        seq = ""
+        while i < len(lines) and lines[i][:1] not in (">", "@", "+"):
+            seq += lines[i].strip()
+            i += 1
+        qual = ""
+        if i < len(lines) and lines[i][:1] == "+":
+            i += 1
+            while i < len(lines) and len(qual) < len(seq):
+                qual += lines[i]
+                i += 1
+            if len(qual) != len(seq):
+                qual = ""
+        seqs.append(FastSeq(name, seq, qual, comment))
+    return seqs
+
+
+# ------------------------------------------------------------------- JSON
+def gason_number(s):
+    """string2double, src/gason.cpp:73-117 — python floats are IEEE doubles, so the same
+    operation sequence gives the same bits as the C restatement qo_gason_number."""
+    return lib().qo_gason_number(s.encode())
+
+
+def gason_loads(text):
+    return json.loads(text, parse_float=gason_number, parse_int=gason_number)
+
+
+def kmer_string(km, k):
+    """kmerToString, src/fastseq.cpp:44-49."""
+    s = ""
+    for _ in range(k):
+        s = "ACGT"[km % 4] + s
+        km //= 4
+    return s
+
+
+class Params:
+    """QuaffParams, src/qmodel.h:147-163; JSON reader src/qmodel.cpp:230-271."""
+
+    def __init__(self, match_len=1, gap_len=0):
+        self.match_len, self.gap_len = match_len, gap_len
+        self.Km, self.Kg = 4 ** match_len, 4 ** gap_len
+        self.refBase = [0.25] * 4
+        self.beginInsert = [0.5] * self.Kg
+        self.beginDelete = [0.5] * self.Kg
+        self.extendInsert = self.extendDelete = 0.5
+        self.insert = np.zeros((4, 3))
+        self.match = np.zeros((4, self.Km, 3))
+
+    @staticmethod
+    def from_json(text):
+        jm = gason_loads(text) if isinstance(text, str) else text
+        ml = int(jm.get("matchOrder", 1))  # readJsonKmerLen, src/qmodel.cpp:122-128
+        gl = int(jm.get("gapOrder", 0))
+        p = Params(ml, gl)
+        # NB: refBase is written but never read back (src/qmodel.cpp:236-271) -> stays 0.25
+        for g in range(p.Kg):
+            ks = kmer_string(g, gl)
+            p.beginInsert[g] = jm["beginInsert"][ks]
+            p.beginDelete[g] = jm["beginDelete"][ks]
+        p.extendInsert, p.extendDelete = jm["extendInsert"], jm["extendDelete"]
+        for i in range(4):
+            d = jm["insert"]["ACGT"[i]]
+            p.insert[i] = (d["p"], d["q"], d["r"])
+        for jp in range(0, p.Km, 4):
+            pref = kmer_string(jp, ml)[: ml - 1]
+            for i in range(4):
+                for js in range(4):
+                    d = jm["match"][pref]["ACGT"[i]]["ACGT"[js]]
+                    p.match[i, jp + js] = (d["p"], d["q"], d["r"])
+        return p
+
+
+class Scores:
+    """QuaffScores, src/qmodel.cpp:296-325, flattened: ins[4][95], mat[4][Km][95], trans[4Kg+4]."""
+
+    def __init__(self, p):
+        self.Km, self.Kg, self.match_len, self.gap_len = p.Km, p.Kg, p.match_len, p.gap_len
+        self.ins = np.zeros((4, NQ1))
+        self.mat = np.zeros((4, p.Km, NQ1))
+        self.trans = np.zeros(4 * p.Kg + 4)
+        lib().qo_build_scores(
+            p.Km, p.Kg,
+            np.ascontiguousarray(p.insert).ctypes.data_as(C.c_void_p),
+            np.ascontiguousarray(p.match).ctypes.data_as(C.c_void_p),
+            (C.c_double * p.Kg)(*p.beginInsert), (C.c_double * p.Kg)(*p.beginDelete),
+            C.c_double(p.extendInsert), C.c_double(p.extendDelete),
+            self.ins.ctypes.data_as(C.c_void_p), self.mat.ctypes.data_as(C.c_void_p),
+            self.trans.ctypes.data_as(C.c_void_p))
+
+
+class NullParams:
+    """QuaffNullParams, src/qmodel.cpp:1806-1907."""
+
+    def __init__(self):
+        self.nullEmit = 0.5
+        self.null = np.tile(np.array([0.25, 0.5, 47.0]), (4, 1))
+
+    @staticmethod
+    def from_json(text):
+        jm = gason_loads(text) if isinstance(text, str) else text
+        n = NullParams()
+        n.nullEmit = jm["nullEmit"]
+        for i in range(4):
+            d = jm["null"]["ACGT"[i]]
+            n.null[i] = (d["p"], d["q"], d["r"])
+        return n
+
+    @staticmethod
+    def fit(seqs, pseudocount=1.0):
+        """QuaffNullParams(seqs), src/qmodel.cpp:1811-1843."""
+        cnt = np.full((4, NQUAL), pseudocount / NQUAL)
+        yes = no = pseudocount
+        sym = np.full(4, float(pseudocount))
+        for s in seqs:
+            no += 1
+            yes += len(s.seq)
+            t = tokens(s.seq)
+            for b in range(4):
+                sym[b] += np.count_nonzero(t == b)
+            if s.has_qual():
+                q = quals(s.qual)
+                np.add.at(cnt, (t, q), 1.0)
+        n = NullParams()
+        n.nullEmit = 1 / (1 + no / yes)
+        tot = sym.sum()
+        for b in range(4):
+            p, r = fit_negbinom(cnt[b])
+            n.null[b] = (sym[b] / tot, p, r)
+        return n
+
+    def loglike(self, fs):
+        """QuaffNullParams::logLikelihood, src/qmodel.cpp:1875-1890."""
+        t = tokens(fs.seq)
+        q = quals(fs.qual) if fs.has_qual() else None
+        return lib().qo_null_loglike(
+            C.c_double(self.nullEmit), np.ascontiguousarray(self.null).ctypes.data_as(C.c_void_p),
+            t.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p) if q is not None else None, len(t))
+
+    def to_json(self):
+        """writeJson, src/qmodel.cpp:1892-1901 (+ SymQualDist::writeJson :58-66)."""
+        parts = []
+        for i in range(4):
+            p, q, r = self.null[i]
+            parts.append(' "%s": %s' % ("ACGT"[i], sqd_json(p, q, r)))
+        return '{\n  "nullEmit": %s,\n  "null": {%s } }' % (fmt(self.nullEmit), ",".join(parts))
+
+
+def fmt(x):
+    """default ostream<<double (precision 6, %g)."""
+    s = "%g" % x
+    return s
+
+
+def sqd_json(p, q, r):
+    m = r * (1 - q) / q
+    sd = math.sqrt(r * (1 - q) / (q * q))
+    return '{ "p": %s, "q": %s, "r": %s, "m": %s, "sd": %s }' % (fmt(p), fmt(q), fmt(r), fmt(m), fmt(sd))
+
+
+# ------------------------------------------------ negative-binomial ML fit
+def _psi(x):
+    from scipy.special import digamma
+    return float(digamma(x))
+
+
+def _psi1(x):
+    from scipy.special import polygamma
+    return float(polygamma(1, x))
+
+
+def fit_negbinom(kfreq):
+    """fitNegativeBinomial, src/negbinom.cpp:112-129: moments -> bracketed root of
+    dLL/dr (Brent in the reference; GSL is absent so a bisection/secant bracket to the
+    same 1e-3 interval test) -> Newton polish (relative 1e-4).  Returns (p, r)."""
+    k = np.arange(len(kfreq), dtype=float)
+    cnt = kfreq.sum()
+    if cnt <= 0:
+        return float("nan"), float("nan")
+    mean = (kfreq * k).sum() / cnt
+    var = (kfreq * k * k).sum() / cnt - mean * mean
+    nz = kfreq > 0
+
+    def d1(r):  # logNegativeBinomialSingleDeriv1, :45-58
+        fs = kfreq[nz].sum()
+        ks = (kfreq[nz] * k[nz]).sum()
+        kd = sum(f * _psi(r + kk) for f, kk in zip(kfreq[nz], k[nz]))
+        return -fs * math.log(1. + ks / (fs * r)) - fs * _psi(r) + kd
+
+    def d2(r):  # :60-71
+        fs = kfreq[nz].sum()
+        kt = sum(f * _psi1(r + kk) for f, kk in zip(kfreq[nz], k[nz]))
+        return -fs * _psi1(r) + kt
+
+    def popt(r):  # optimalNegativeBinomialSuccessProb, :78-86
+        return 1. / (1 + (kfreq * k).sum() / (kfreq.sum() * r))
+
+    def ll(r):
+        p = popt(r)
+        return sum(f * lib().qo_log_negbinom(int(kk), p, r) for f, kk in zip(kfreq, k))
+
+    lo, hi = 1., max(1., len(kfreq) - 1.)
+    if var > 0 and var > mean:  # momentFit :142-162
+        p0 = mean / var
+        r0 = mean * p0 / (1 - p0)
+        lo, hi = max(1., r0 / 2), min(len(kfreq) - 1., r0 * 2)
+    flo, fhi = d1(lo), d1(hi)
+    if (flo > 0) == (fhi > 0):  # :190-203: same sign -> better endpoint
+        r = lo if ll(lo) > ll(hi) else hi
+    else:
+        a, b, fa = lo, hi, flo
+        for _ in range(100):
+            mid = 0.5 * (a + b)
+            fm = d1(mid)
+            if (fm > 0) == (fa > 0):
+                a, fa = mid, fm
+            else:
+                b = mid
+            if abs(b - a) < 1e-3 + 1e-3 * min(abs(a), abs(b)):
+                break
+        r = 0.5 * (a + b)
+    for _ in range(100):  # gradientFit :262-322
+        rn = r - d1(r) / d2(r)
+        done = abs(rn - r) < 1e-4 * abs(rn)
+        r = rn
+        if done or r > len(kfreq):
+            break
+    return popt(r), r
+
+
+# ------------------------------------------------------------ DP wrappers
+class DPConfig:
+    """QuaffDPConfig defaults, src/qmodel.h:303-335 (kmerThreshold 20 for align/train: t/quaff.cpp:128)."""
+
+    def __init__(self, local=True, sparse=True, kmer_len=6, kmer_threshold=20, band=64, max_size=0):
+        self.local, self.sparse, self.kmer_len = local, sparse, kmer_len
+        self.kmer_threshold, self.band, self.max_size = kmer_threshold, band, max_size
+
+
+def envelope(xtok, ytok, cfg, cell_size=24):
+    """QuaffDPConfig::makeEnvelope, src/qmodel.cpp:1049-1056 -> sorted diagonal list."""
+    diags = np.empty(len(xtok) + len(ytok) - 1, np.int32)
+    n = lib().qo_envelope(
+        xtok.ctypes.data_as(C.c_void_p), len(xtok), ytok.ctypes.data_as(C.c_void_p), len(ytok),
+        int(cfg.sparse), cfg.kmer_len, cfg.band, cfg.kmer_threshold,
+        C.c_uint64(cell_size), C.c_uint64(cfg.max_size), diags.ctypes.data_as(C.c_void_p))
+    return diags[:n].copy()
+
+
+def diag_histogram(xtok, ytok, k):
+    h = np.empty(len(xtok) + len(ytok) - 1, np.uint32)
+    lib().qo_diag_histogram(xtok.ctypes.data_as(C.c_void_p), len(xtok), ytok.ctypes.data_as(C.c_void_p), len(ytok), k,
+                            h.ctypes.data_as(C.c_void_p))
+    return h
+
+
+def envelope_cells(diags, xlen, ylen):
+    return int(lib().qo_envelope_cells(diags.ctypes.data_as(C.c_void_p), len(diags), xlen, ylen))
+
+
+class ReadCtx:
+    """Per-read arrays of QuaffDPMatrix, src/qmodel.cpp:1308-1324."""
+
+    def __init__(self, fs, sc):
+        self.fs = fs
+        self.tok = tokens(fs.seq)
+        self.qual = quals(fs.qual) if (fs.has_qual() and len(fs.qual)) else None
+        self.mk = kmers(self.tok, sc.match_len)
+        self.gk = kmers(self.tok, sc.gap_len)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def viterbi(xtok, rc, sc, diags, local=True, want_tb=True, dump=False):
+    """QuaffViterbiMatrix (+alignment), src/qmodel.cpp:1512-1646.
+    Returns dict(result, xStart, xEnd, ops) ; ops is a str of M/I/D or None."""
+    xlen, ylen = len(xtok), len(rc.tok)
+    ops = C.create_string_buffer(xlen + ylen + 2)
+    xs, xe, nops = C.c_int(0), C.c_int(0), C.c_int(-1)
+    mdump = np.empty((len(diags), ylen + 1, 3)) if dump else None
+    res = lib().qo_viterbi(
+        xlen, ylen, sc.Km, sc.Kg, int(local), _vp(xtok), _vp(rc.tok), _vp(rc.qual), _vp(rc.mk), _vp(rc.gk),
+        _vp(sc.ins), _vp(sc.mat), _vp(sc.trans), _vp(diags), len(diags),
+        int(want_tb), C.byref(xs), C.byref(xe), ops, xlen + ylen + 2, C.byref(nops), _vp(mdump))
+    out = {"result": res, "xStart": None, "xEnd": None, "ops": None}
+    if nops.value >= 0:
+        out.update(xStart=xs.value, xEnd=xe.value, ops=ops.raw[: nops.value].decode())
+    elif nops.value < -1:
+        raise RuntimeError("oracle traceback failed (%d)" % nops.value)
+    if dump:
+        out["matrix"] = mdump
+    return out
+
+
+def counts_size(Km, Kg):
+    return (4 + 4 * Km) * NQUAL + 4 * Kg + 4
+
+
+def forward_backward(xtok, rc, sc, diags, local=True, want_back=True):
+    """QuaffForwardMatrix / QuaffBackwardMatrix, src/qmodel.cpp:1343-1510.
+    Returns (forward result, backward result or None, flattened QuaffCounts or None)."""
+    xlen, ylen = len(xtok), len(rc.tok)
+    cnt = np.zeros(counts_size(sc.Km, sc.Kg)) if want_back else None
+    bres = C.c_double(float("nan"))
+    f = lib().qo_forward_backward(
+        xlen, ylen, sc.Km, sc.Kg, int(local), _vp(xtok), _vp(rc.tok), _vp(rc.qual), _vp(rc.mk), _vp(rc.gk),
+        _vp(sc.ins), _vp(sc.mat), _vp(sc.trans), _vp(diags), len(diags),
+        int(want_back), _vp(cnt), C.byref(bres))
+    return f, (bres.value if want_back else None), cnt
+
+
+def lse(a, b):
+    return lib().qo_lse(a, b)
+
+
+# ------------------------------------------------------- per-read tasks
+def cigar(ops):
+    """Alignment::cigarString, src/qmodel.cpp:625-653: letter BEFORE count."""
+    out, last, n = "", None, 0
+    for c in ops:
+        if c == last:
+            n += 1
+        else:
+            if n:
+                out += last + str(n)
+            last, n = c, 1
+    if n:
+        out += last + str(n)
+    return out
+
+
+def align_read(refs, read, sc, null, cfg, print_all=False):
+    """QuaffAlignmentTask::run, src/qmodel.cpp:2764-2778.  refs: list of FastSeq (originals
+    then revcomps).  Returns the kept alignments, best first: dicts with ref index, raw and
+    adjusted score, xStart/xEnd, ops."""
+    rc = ReadCtx(read, sc)
+    nll = null.loglike(read)
+    kept = []
+    for nx, x in enumerate(refs):
+        xt = tokens(x.seq)
+        d = envelope(xt, rc.tok, cfg, 24)
+        v = viterbi(xt, rc, sc, d, cfg.local)
+        if v["result"] > NEG_INF:
+            v.update(ref=nx, raw=v["result"], score=v["result"] - nll, ndiag=len(d),
+                     cells=envelope_cells(d, len(xt), len(rc.tok)))
+            # multiset insert at upper bound of equal scores, then keep first (:2773-2775)
+            pos = len(kept)
+            for a, k in enumerate(kept):
+                if v["score"] > k["score"]:
+                    pos = a
+                    break
+            kept.insert(pos, v)
+            if not print_all:
+                kept = kept[:1]
+    return kept
+
+
+def gapped_rows(x, read, al):
+    """Gapped rows built by the traceback, src/qmodel.cpp:1577-1645."""
+    xr, yr, qr = [], [], []
+    i, j = al["xStart"] - 1, 0
+    for c in al["ops"]:
+        if c == "M":
+            xr.append(x.seq[i]); yr.append(read.seq[j]); qr.append(read.qual[j] if read.has_qual() else "")
+            i += 1; j += 1
+        elif c == "I":
+            xr.append("-"); yr.append(read.seq[j]); qr.append(read.qual[j] if read.has_qual() else "")
+            j += 1
+        else:
+            xr.append(x.seq[i]); yr.append("-"); qr.append("~" if read.has_qual() else "")
+            i += 1
+    return "".join(xr), "".join(yr), "".join(qr)
+
+
+def stockholm(x, read, al, local=True):
+    """Alignment::writeStockholm, src/qmodel.cpp:553-606 for the 2-row Ref/Read alignment."""
+    xrow, yrow, qrow = gapped_rows(x, read, al)
+    names = ["Ref", "Read"]
+    data = [xrow, yrow]
+    cons = "".join("-" if (a in "-." or b in "-.") else (a.upper() if a.upper() == b.upper() else ":")
+                   for a, b in zip(xrow, yrow))
+    names.insert(1, "#=GC id")
+    data.insert(1, cons)
+    if read.has_qual():
+        names.append("#=GR Read QS")
+        data.append(qrow)
+    nw = max(len(n) for n in names)
+    dw = max(nw, 79 - nw)
+    out = ["# STOCKHOLM 1.0", "#=GF Score " + fmt(al["score"])]
+    xc = ("substr(%s,%d..%d)" % (x.name, al["xStart"], al["xEnd"])) if local else x.name
+    out.append("#=GS CC Ref " + xc)
+    out.append("#=GS CC Read " + read.name)
+    ncol = len(xrow)
+    for col in range(0, ncol, dw):
+        if col > 0:
+            out.append("")
+        for n, d in zip(names, data):
+            out.append(n.ljust(nw) + " " + d[col: col + dw])
+    out.append("//")
+    return "\n".join(out) + "\n"
+
+
+def sam_line(x, read, al):
+    """Alignment::writeSam, src/qmodel.cpp:608-616 with the revcomp path (:655-660,
+    fastseq.cpp:218-230): a reverse-strand ref (x.source.rev) prints the reverse-complemented
+    alignment, whose POS is computed from the GAPPED row length."""
+    ops = al["ops"]
+    xsrc = compose((x.name, al["xStart"], al["xEnd"], False), x.source)
+    ysrc = compose((read.name, 1, len(read.seq), False), read.source)
+    if xsrc[3]:
+        ncol = len(ops)
+        # FastSeq::revcomp on the gapped row: source (name,1,ncol,rev) composed with the row's own source
+        xsrc = compose((None, 1, ncol, True), xsrc)
+        ysrc = compose((None, 1, ncol, True), ysrc)
+        ops = ops[::-1]
+    flag = 16 if ysrc[3] else 0
+    return "%s\t%d\t%s\t%d\t0\t%s\t*\t0\t0\t*\t*\tAS:i:%d\n" % (
+        ysrc[0], flag, xsrc[0], xsrc[1], cigar(ops), int(round_half_away(al["score"])))
+
+
+def round_half_away(x):
+    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+
+def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True):
+    """QuaffCountingTask::run, src/qmodel.cpp:2238-2271.  Returns (yCounts as flattened
+    QuaffParamCounts-style QuaffCounts sum, yLogLike, new sort order).  The returned counts are
+    still in QuaffCounts layout (m2m,m2i,m2d,m2e,...); param_counts() converts."""
+    rc = ReadCtx(read, sc)
+    ynull = null.loglike(read) if use_null else NEG_INF
+    ylog = ynull
+    order = list(range(len(refs))) if sort_order is None else list(sort_order)
+    xyll = [NEG_INF] * len(refs)
+    xyc = [None] * len(refs)
+    for nx in order:
+        xt = tokens(refs[nx].seq)
+        d = envelope(xt, rc.tok, cfg, 48)
+        f, _, _ = forward_backward(xt, rc, sc, d, cfg.local, want_back=False)
+        xyll[nx] = f
+        if f >= ylog - 20:
+            _, _, cnt = forward_backward(xt, rc, sc, d, cfg.local, want_back=True)
+            xyc[nx] = cnt
+        ylog = lse(ylog, f)
+    tot = np.zeros(counts_size(sc.Km, sc.Kg))
+    for nx in range(len(refs)):
+        w = math.exp(xyll[nx] - ylog) if xyll[nx] > NEG_INF else 0.0
+        if xyc[nx] is not None:
+            tot += w * param_counts(xyc[nx], sc.Km, sc.Kg)
+    asc = sorted(range(len(refs)), key=lambda a: xyll[a])
+    new_order = []
+    for nx in reversed(asc):
+        if xyll[nx] < ylog - 20:
+            break
+        new_order.append(nx)
+    return tot, ylog, new_order
+
+
+def param_counts(cnt, Km, Kg):
+    """QuaffParamCounts(const QuaffCounts&), src/qmodel.cpp:407-417, flattened as
+    ins[4][94] | mat[4][Km][94] | beginInsertNo[Kg] beginInsertYes[Kg] beginDeleteNo[Kg] beginDeleteYes[Kg]
+    | extendInsertNo extendInsertYes extendDeleteNo extendDeleteYes."""
+    ne = (4 + 4 * Km) * NQUAL
+    out = np.zeros_like(cnt)
+    out[:ne] = cnt[:ne]
+    m2m, m2i, m2d, m2e = (cnt[ne + a * Kg: ne + (a + 1) * Kg] for a in range(4))
+    d2d, d2m, i2i, i2m = cnt[ne + 4 * Kg: ne + 4 * Kg + 4]
+    out[ne: ne + Kg] = m2m + m2d
+    out[ne + Kg: ne + 2 * Kg] = m2i + m2e
+    out[ne + 2 * Kg: ne + 3 * Kg] = m2m
+    out[ne + 3 * Kg: ne + 4 * Kg] = m2d
+    out[ne + 4 * Kg: ne + 4 * Kg + 4] = (i2m, i2i, d2m, d2d)
+    return out
+
+
+def join6(v):
+    return ", ".join(fmt(x) for x in v)
+
+
+def param_counts_json(pc, match_len, gap_len):
+    """QuaffParamCounts::writeJson, src/qmodel.cpp:458-470 (+ QuaffEmitCounts::writeJson :341-362)."""
+    Km, Kg = 4 ** match_len, 4 ** gap_len
+    ne = (4 + 4 * Km) * NQUAL
+    ins = pc[: 4 * NQUAL].reshape(4, NQUAL)
+    mat = pc[4 * NQUAL: ne].reshape(4, Km, NQUAL)
+    o = "{\n"
+    if match_len != 1:
+        o += '  "matchOrder": %d,\n' % match_len
+    if gap_len != 0:
+        o += '  "gapOrder": %d,\n' % gap_len
+    o += '  "insert": {\n'
+    for i in range(4):
+        o += '    "%s": [ %s ]%s\n' % ("ACGT"[i], join6(ins[i]), " }," if i == 3 else ",")
+    o += '  "match": {\n'
+    for jp in range(0, Km, 4):
+        o += '   "%s": {\n' % kmer_string(jp, match_len)[: match_len - 1]
+        for i in range(4):
+            o += '    "%s": {\n' % "ACGT"[i]
+            for js in range(4):
+                o += '      "%s": [ %s ]%s' % ("ACGT"[js], join6(mat[i, jp + js]), " }" if js == 3 else ",\n")
+            o += " }" if i == 3 else ",\n"
+        o += (" }" if jp == Km - 4 else ",") + "\n"
+    o += ",\n"
+
+    def kmers_obj(name, v):
+        return '  "%s": {%s }' % (name, ",".join(' "%s": %s' % (kmer_string(g, gap_len), fmt(v[g])) for g in range(Kg)))
+    tr = pc[ne:]
+    o += kmers_obj("beginInsertNo", tr[0:Kg]) + ",\n"
+    o += kmers_obj("beginInsertYes", tr[Kg:2 * Kg]) + ",\n"
+    o += kmers_obj("beginDeleteNo", tr[2 * Kg:3 * Kg]) + ",\n"
+    o += kmers_obj("beginDeleteYes", tr[3 * Kg:4 * Kg]) + ",\n"
+    e = tr[4 * Kg:]
+    o += '  "extendInsertNo": %s,\n  "extendInsertYes": %s,\n  "extendDeleteNo": %s,\n  "extendDeleteYes": %s }' % tuple(fmt(x) for x in e)
+    return o
