@@ -35,7 +35,7 @@ def test_self_counts_golden(c8f30, golden):
     reads, sc, null, cfg = c8f30
     tot, ylog, order = O.count_read(reads, reads[0], sc, null, cfg)
     assert order == [0]
-    assert O.param_counts_json(tot, 1, 0) + "\n" == open(os.path.join(golden, "c8f30-self-counts.json")).read()
+    assert O.param_counts_json(tot, 1, 0) == open(os.path.join(golden, "c8f30-self-counts.json")).read()
 
 
 def test_default_threshold_seeding_anchor(c8f30):
