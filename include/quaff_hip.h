@@ -1,0 +1,165 @@
+/*
+ * quaff_hip.h — C ABI of libquaffhip: the MI355X (gfx950) implementation of quaff's
+ * k-mer-seeded banded pair-HMM DP hot path.
+ *
+ * The reference (ihh/quaff) has no FFI seam: the hot path is reached through C++
+ * constructors called from three per-task drivers.  This header is the seam a quaff
+ * maintainer would bind instead, at the Task level and batched:
+ *
+ *   reference (file:line under /root/reference)              replaced by
+ *   -------------------------------------------------------  ---------------------------
+ *   QuaffParams::readJson            src/qmodel.cpp:230-271   qf_set_params_json
+ *   defaultQuaffParams               src/defaultparams.cpp:4  qf_set_params_json(ctx, NULL)
+ *   QuaffScores::QuaffScores         src/qmodel.cpp:296-325   (built inside qf_set_params_json)
+ *   QuaffNullParams::readJson        src/qmodel.cpp:1856-1866 qf_set_null_json
+ *   QuaffNullParams::logLikelihood   src/qmodel.cpp:1875-1890 qf_align_result.null_loglike
+ *   FastSeq::tokens/kmers/qualScores src/fastseq.cpp:71-109   (device prep kernel)
+ *   KmerIndex::KmerIndex             src/fastseq.cpp:240-256  qf_set_refs (device k-mer index)
+ *   QuaffDPConfig::makeEnvelope      src/qmodel.cpp:1049-1056 \
+ *   DiagonalEnvelope::initSparse     src/diagenv.cpp:20-106    > qf_align_batch (seed kernel)
+ *   DiagonalEnvelope::initFull       src/diagenv.cpp:11-18    /
+ *   QuaffViterbiMatrix ctor          src/qmodel.cpp:1512-1560 qf_align_batch (fill kernel)
+ *   QuaffViterbiMatrix::alignment    src/qmodel.cpp:1562-1646 qf_align_batch (traceback kernel)
+ *   QuaffAlignmentTask::run          src/qmodel.cpp:2764-2778 qf_align_batch (best ref per read)
+ *   Alignment::cigarString           src/qmodel.cpp:625-653   qf_cigar_string
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * negative qf_status otherwise (message via qf_last_error); nothing throws or exits across
+ * the boundary (the reference prints and exit(1)s: src/util.cpp:80-98).  A context is
+ * single-threaded; use one context per GPU / host thread.  Result views point into
+ * context-owned memory and stay valid until the next *_batch call on that context.
+ * There is no CPU fallback: without a usable HIP device qf_ctx_create fails.
+ */
+#ifndef QUAFF_HIP_H
+#define QUAFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qf_ctx qf_ctx;
+
+enum qf_status {
+  QF_OK = 0,
+  QF_ERR_DEVICE = -1,      /* no HIP device / HIP runtime error */
+  QF_ERR_ARG = -2,         /* bad argument */
+  QF_ERR_PARSE = -3,       /* JSON parse / missing parameter */
+  QF_ERR_SYMBOL = -4,      /* non-ACGT symbol (reference: "Unknown symbol", src/fastseq.cpp:76-79) */
+  QF_ERR_UNSUPPORTED = -5, /* valid for the reference, not built yet (documented in DESIGN.md) */
+  QF_ERR_MEMORY = -6,
+  QF_ERR_STATE = -7        /* call order (e.g. no params / refs set) */
+};
+
+/* QuaffDPConfig, src/qmodel.h:280-335: the DP-relevant fields only. */
+typedef struct qf_dp_config {
+  int32_t local;           /* 1 = local in the reference sequence (default); 0 = -global */
+  int32_t sparse;          /* 1 = k-mer seeded envelope (default); 0 = -kmatchoff (full DP) */
+  int32_t kmer_len;        /* -kmatch, default 6 */
+  int32_t kmer_threshold;  /* -kmatchn; default 20 (align/train) or 14 (overlap); < 0 = memory mode */
+  int32_t band_size;       /* -kmatchband, default 64 */
+  int32_t reserved;
+  uint64_t max_size;       /* memory mode: effectiveMaxSize() in bytes (-kmatchmb M => M<<20) */
+} qf_dp_config;
+
+#define QF_MAX_FILL_CLASSES 16
+
+/* flags for qf_align_batch */
+#define QF_ALIGN_BEST 0u      /* traceback only the best reference per read (default; QuaffAlignmentTask) */
+#define QF_ALIGN_ALL 1u       /* -printall: traceback every pair with a finite Viterbi score */
+#define QF_ALIGN_NO_TRACEBACK 2u /* scores only */
+
+typedef struct qf_alignment {
+  uint32_t read;           /* index into the batch */
+  uint32_t ref;            /* index into the reference set */
+  double viterbi;          /* raw Viterbi log-likelihood (QuaffViterbiMatrix::result) */
+  double score;            /* viterbi - null log-likelihood of the read (scoreAdjustedAlignment) */
+  uint32_t x_start, x_end; /* 1-based closed interval of the reference covered */
+  uint32_t n_columns;      /* alignment columns */
+  uint32_t n_runs;         /* CIGAR runs */
+  uint64_t run_offset;     /* first run in qf_align_result.cigar_runs */
+} qf_alignment;
+
+typedef struct qf_align_result {
+  uint32_t n_reads, n_refs;
+  const double *viterbi;        /* [n_reads * n_refs], -inf where no path exists */
+  const uint64_t *cells;        /* [n_reads * n_refs] DP cells visited (SURVEY 8d definition) */
+  const uint32_t *n_diagonals;  /* [n_reads * n_refs] envelope diagonals */
+  const double *null_loglike;   /* [n_reads] (0 when no null model is set) */
+  uint64_t total_cells;
+  uint32_t n_alignments;
+  const qf_alignment *alignments;  /* ordered by read, then (QF_ALIGN_ALL) by descending score */
+  const uint32_t *cigar_runs;      /* run = (length << 2) | op, op 0=M 1=I 2=D, alignment order */
+  /* device-side timings of the last call, milliseconds (HIP events on the context's stream) */
+  float ms_prep, ms_seed, ms_fill, ms_traceback, ms_total;
+  uint64_t n_units;             /* independent diagonal bands filled */
+  uint64_t traceback_bytes;     /* packed traceback bytes written */
+  /* per fill-kernel class (qf_fill_class_name): launch duration, cells and bands it processed */
+  float ms_fill_class[QF_MAX_FILL_CLASSES];
+  uint64_t cells_class[QF_MAX_FILL_CLASSES];
+  uint32_t units_class[QF_MAX_FILL_CLASSES];
+  uint32_t n_fill_classes;
+} qf_align_result;
+
+/* ---- context ---------------------------------------------------------------------- */
+int qf_ctx_create(int device_id, qf_ctx **ctx);
+void qf_ctx_destroy(qf_ctx *ctx);
+const char *qf_last_error(const qf_ctx *ctx);   /* ctx may be NULL: last creation error */
+int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
+
+/* ---- model ------------------------------------------------------------------------ */
+/* Parse a quaff params JSON document (numbers go through the same non-correctly-rounded
+ * decimal algorithm as the reference's gason, src/gason.cpp:73-117), build the log-space
+ * score tables and upload them.  text == NULL selects the built-in defaults. */
+int qf_set_params_json(qf_ctx *ctx, const char *text);
+/* Score tables as built (for inspection / parity tests).  Any pointer may be NULL.
+ *   ins[4][95], mat[4][Km][95] (index 94 = quality-marginalised), trans[4*Kg+4] =
+ *   m2m[Kg] m2i[Kg] m2d[Kg] m2e[Kg] d2d d2m i2i i2m. */
+int qf_get_scores(const qf_ctx *ctx, int *match_len, int *gap_len, double *ins, double *mat, double *trans);
+/* Host-only variant of the two calls above (no context, no device): parse + build the tables. */
+int qf_scores_from_json(const char *text, int *match_len, int *gap_len, double *ins, double *mat, double *trans,
+                        char *err, size_t err_cap);
+/* Kernel name of a fill class, e.g. "k_viterbi_fill<16,5>"; NULL past the last class. */
+const char *qf_fill_class_name(uint32_t cls);
+/* Null model: JSON as written by quaff -savenull; text == NULL clears it (null_loglike = 0). */
+int qf_set_null_json(qf_ctx *ctx, const char *text);
+/* The 100001-entry log(1+exp(-x)) table of src/logsumexp.cpp:20-28 as built on the host. */
+int qf_get_lse_table(const qf_ctx *ctx, const double **table, int *n);
+
+/* ---- sequences -------------------------------------------------------------------- */
+/* Reference set (already including reverse complements if wanted, as SeqList::loadSequences
+ * does, t/quaff.cpp:610-636).  seq = concatenated characters, offsets[n_refs+1]. */
+int qf_set_refs(qf_ctx *ctx, const char *seq, const uint64_t *offsets, uint32_t n_refs);
+
+/* Reads resident in HBM.  qual == NULL => no quality scores (-noquals). */
+int qf_upload_reads(qf_ctx *ctx, const char *seq, const char *qual, const uint64_t *offsets, uint32_t n_reads);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* Viterbi-align every uploaded read against every reference. */
+int qf_align_resident(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t flags, qf_align_result *out);
+/* Convenience: qf_upload_reads + qf_align_resident. */
+int qf_align_batch(qf_ctx *ctx, const qf_dp_config *cfg, const char *seq, const char *qual,
+                   const uint64_t *offsets, uint32_t n_reads, uint32_t flags, qf_align_result *out);
+
+/* Envelope only (DiagonalEnvelope::diagonals for pair (read, ref)); returns the number of
+ * diagonals, writes at most cap of them.  For tests and debugging. */
+int64_t qf_envelope(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t read, uint32_t ref, int32_t *diags, uint64_t cap);
+
+/* Alignment::cigarString (letter BEFORE count, src/qmodel.cpp:625-653); returns length needed. */
+size_t qf_cigar_string(const uint32_t *runs, uint32_t n_runs, char *buf, size_t cap);
+
+/* ---- synthetic workloads (SURVEY 8d generator; deterministic, host side) ----------- */
+/* i.i.d. uniform ACGT reference of ref_len bases (xoshiro256**, seed). */
+int qf_synth_ref(uint64_t seed, uint64_t ref_len, char *seq);
+/* n_reads reads of read_len SOURCE bases sampled from ref, odd reads reverse-complemented,
+ * 3% del / 3% ins / 5% sub, Phred 5..25.  seq/qual need capacity n_reads*(2*read_len);
+ * offsets[n_reads+1]. */
+int qf_synth_reads(uint64_t seed, const char *ref, uint64_t ref_len, uint32_t n_reads, uint32_t read_len,
+                   char *seq, char *qual, uint64_t *offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUAFF_HIP_H */

@@ -1,0 +1,250 @@
+"""ctypes binding of include/quaff_hip.h (one function per C entry point, same names minus qf_)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+_LIB = None
+
+
+class QuaffHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libquaffhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(HERE, "libquaffhip.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(args)
+    return library_path()
+
+
+class DPConfig(C.Structure):
+    """qf_dp_config; defaults are `quaff align`'s (t/quaff.cpp:128, src/qmodel.h:303-335)."""
+    _fields_ = [("local", C.c_int32), ("sparse", C.c_int32), ("kmer_len", C.c_int32), ("kmer_threshold", C.c_int32),
+                ("band_size", C.c_int32), ("reserved", C.c_int32), ("max_size", C.c_uint64)]
+
+    def __init__(self, local=True, sparse=True, kmer_len=6, kmer_threshold=20, band_size=64, max_size=0):
+        super().__init__(int(local), int(sparse), kmer_len, kmer_threshold, band_size, 0, max_size)
+
+
+class _Alignment(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("ref", C.c_uint32), ("viterbi", C.c_double), ("score", C.c_double),
+                ("x_start", C.c_uint32), ("x_end", C.c_uint32), ("n_columns", C.c_uint32), ("n_runs", C.c_uint32),
+                ("run_offset", C.c_uint64)]
+
+
+class _AlignResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_refs", C.c_uint32), ("viterbi", C.POINTER(C.c_double)),
+                ("cells", C.POINTER(C.c_uint64)), ("n_diagonals", C.POINTER(C.c_uint32)),
+                ("null_loglike", C.POINTER(C.c_double)), ("total_cells", C.c_uint64), ("n_alignments", C.c_uint32),
+                ("alignments", C.POINTER(_Alignment)), ("cigar_runs", C.POINTER(C.c_uint32)),
+                ("ms_prep", C.c_float), ("ms_seed", C.c_float), ("ms_fill", C.c_float), ("ms_traceback", C.c_float),
+                ("ms_total", C.c_float), ("n_units", C.c_uint64), ("traceback_bytes", C.c_uint64),
+                ("ms_fill_class", C.c_float * 16), ("cells_class", C.c_uint64 * 16), ("units_class", C.c_uint32 * 16),
+                ("n_fill_classes", C.c_uint32)]
+
+
+EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
+           "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
+           "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
+           "qf_fill_class_name"]
+
+
+def load_library():
+    """dlopen libquaffhip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise QuaffHipError(-1, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        L = C.CDLL(path)
+        L.qf_last_error.restype = C.c_char_p
+        L.qf_last_error.argtypes = [C.c_void_p]
+        L.qf_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.qf_ctx_destroy.argtypes = [C.c_void_p]
+        L.qf_ctx_destroy.restype = None
+        L.qf_set_params_json.argtypes = [C.c_void_p, C.c_char_p]
+        L.qf_set_null_json.argtypes = [C.c_void_p, C.c_char_p]
+        L.qf_get_scores.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qf_get_lse_table.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]
+        L.qf_set_refs.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]
+        L.qf_upload_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32]
+        L.qf_align_resident.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_uint32, C.POINTER(_AlignResult)]
+        L.qf_align_batch.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32,
+                                     C.c_uint32, C.POINTER(_AlignResult)]
+        L.qf_envelope.restype = C.c_int64
+        L.qf_envelope.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
+        L.qf_cigar_string.restype = C.c_size_t
+        L.qf_cigar_string.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+        L.qf_synth_ref.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p]
+        L.qf_synth_reads.argtypes = [C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p,
+                                     C.c_void_p]
+        L.qf_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.qf_scores_from_json.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_char_p, C.c_size_t]
+        L.qf_fill_class_name.restype = C.c_char_p
+        L.qf_fill_class_name.argtypes = [C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+ALIGN_BEST, ALIGN_ALL, ALIGN_NO_TRACEBACK = 0, 1, 2
+
+
+def scores_from_json(text=None):
+    """Host-only: (match_len, gap_len, ins[4][95], mat[4][Km][95], trans[4Kg+4]) for a params JSON (None = defaults)."""
+    L = load_library()
+    ml, gl = C.c_int(), C.c_int()
+    err = C.create_string_buffer(256)
+    t = text.encode() if text is not None else None
+    rc = L.qf_scores_from_json(t, C.byref(ml), C.byref(gl), None, None, None, err, 256)
+    if rc:
+        raise QuaffHipError(rc, err.value.decode())
+    Km, Kg = 4 ** ml.value, 4 ** gl.value
+    ins, mat, trans = np.zeros((4, 95)), np.zeros((4, Km, 95)), np.zeros(4 * Kg + 4)
+    rc = L.qf_scores_from_json(t, None, None, ins.ctypes.data, mat.ctypes.data, trans.ctypes.data, err, 256)
+    if rc:
+        raise QuaffHipError(rc, err.value.decode())
+    return ml.value, gl.value, ins, mat, trans
+
+
+def synth_ref(seed, length):
+    buf = C.create_string_buffer(length)
+    load_library().qf_synth_ref(seed, length, buf)
+    return buf.raw
+
+
+def synth_reads(seed, ref, n_reads, read_len):
+    """Returns (seq bytes, qual bytes, offsets uint64[n_reads+1])."""
+    cap = n_reads * 2 * read_len + 16
+    seq, qual = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    off = np.zeros(n_reads + 1, np.uint64)
+    rc = load_library().qf_synth_reads(seed, ref, len(ref), n_reads, read_len, seq, qual, off.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise QuaffHipError(rc, "qf_synth_reads")
+    tot = int(off[-1])
+    return seq.raw[:tot], qual.raw[:tot], off
+
+
+def pack(seqs):
+    """list of str/bytes -> (concatenated bytes, offsets)."""
+    bs = [s.encode() if isinstance(s, str) else s for s in seqs]
+    off = np.zeros(len(bs) + 1, np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    return b"".join(bs), off
+
+
+class Context:
+    """qf_ctx: one per GPU.  Mirrors the call order of a quaff run: params -> null -> refs -> reads -> align."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.qf_ctx_create(device, C.byref(h))
+        if rc:
+            raise QuaffHipError(rc, self.L.qf_last_error(None).decode())
+        self.h = h
+        self.n_reads = self.n_refs = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qf_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise QuaffHipError(rc, self.L.qf_last_error(self.h).decode())
+
+    def device_name(self):
+        b = C.create_string_buffer(256)
+        self._chk(self.L.qf_device_name(self.h, b, 256))
+        return b.value.decode()
+
+    def set_params_json(self, text=None):
+        self._chk(self.L.qf_set_params_json(self.h, text.encode() if text is not None else None))
+
+    def set_null_json(self, text=None):
+        self._chk(self.L.qf_set_null_json(self.h, text.encode() if text is not None else None))
+
+    def get_scores(self):
+        ml, gl = C.c_int(), C.c_int()
+        self._chk(self.L.qf_get_scores(self.h, C.byref(ml), C.byref(gl), None, None, None))
+        Km, Kg = 4 ** ml.value, 4 ** gl.value
+        ins, mat, trans = np.zeros((4, 95)), np.zeros((4, Km, 95)), np.zeros(4 * Kg + 4)
+        self._chk(self.L.qf_get_scores(self.h, None, None, ins.ctypes.data, mat.ctypes.data, trans.ctypes.data))
+        return ml.value, gl.value, ins, mat, trans
+
+    def lse_table(self):
+        p, n = C.POINTER(C.c_double)(), C.c_int()
+        self._chk(self.L.qf_get_lse_table(self.h, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(p, (n.value,)).copy()
+
+    def set_refs(self, seqs):
+        data, off = pack(seqs)
+        self._chk(self.L.qf_set_refs(self.h, data, off.ctypes.data, len(seqs)))
+        self.n_refs = len(seqs)
+
+    def upload_reads_packed(self, seq, qual, off):
+        self._chk(self.L.qf_upload_reads(self.h, seq, qual, off.ctypes.data, len(off) - 1))
+        self.n_reads = len(off) - 1
+
+    def upload_reads(self, seqs, quals=None):
+        data, off = pack(seqs)
+        q = pack(quals)[0] if quals is not None else None
+        self.upload_reads_packed(data, q, off)
+
+    def align_resident(self, cfg=None, flags=ALIGN_BEST, raw=False):
+        cfg = cfg or DPConfig()
+        res = _AlignResult()
+        self._chk(self.L.qf_align_resident(self.h, C.byref(cfg), flags, C.byref(res)))
+        return res if raw else self._unpack(res)
+
+    def _unpack(self, res):
+        n = res.n_reads * res.n_refs
+        shape = (res.n_reads, res.n_refs)
+        out = {
+            "viterbi": np.ctypeslib.as_array(res.viterbi, (n,)).reshape(shape).copy() if n else np.zeros(shape),
+            "cells": np.ctypeslib.as_array(res.cells, (n,)).reshape(shape).copy() if n else np.zeros(shape, np.uint64),
+            "n_diagonals": np.ctypeslib.as_array(res.n_diagonals, (n,)).reshape(shape).copy() if n else np.zeros(shape, np.uint32),
+            "null_loglike": np.ctypeslib.as_array(res.null_loglike, (res.n_reads,)).copy() if res.n_reads else np.zeros(0),
+            "total_cells": int(res.total_cells), "n_units": int(res.n_units), "traceback_bytes": int(res.traceback_bytes),
+            "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "fill", "traceback", "total")},
+            "alignments": [],
+            "classes": [{"name": self.L.qf_fill_class_name(k).decode(), "ms": res.ms_fill_class[k],
+                         "cells": int(res.cells_class[k]), "units": int(res.units_class[k])}
+                        for k in range(res.n_fill_classes) if res.units_class[k]],
+        }
+        for a in range(res.n_alignments):
+            al = res.alignments[a]
+            runs = np.ctypeslib.as_array(C.cast(C.addressof(res.cigar_runs.contents) + 4 * al.run_offset,
+                                                C.POINTER(C.c_uint32)), (al.n_runs,)).copy() if al.n_runs else np.zeros(0, np.uint32)
+            out["alignments"].append({
+                "read": al.read, "ref": al.ref, "viterbi": al.viterbi, "score": al.score, "xStart": al.x_start,
+                "xEnd": al.x_end, "n_columns": al.n_columns, "runs": runs,
+                "cigar": "".join("MID"[int(r) & 3] + str(int(r) >> 2) for r in runs),
+                "ops": "".join("MID"[int(r) & 3] * (int(r) >> 2) for r in runs)})
+        return out
+
+    def envelope(self, read, ref, cfg=None):
+        cfg = cfg or DPConfig()
+        n = self.L.qf_envelope(self.h, C.byref(cfg), read, ref, None, 0)
+        if n < 0:
+            self._chk(int(n))
+        d = np.zeros(max(int(n), 1), np.int32)
+        n = self.L.qf_envelope(self.h, C.byref(cfg), read, ref, d.ctypes.data, len(d))
+        if n < 0:
+            self._chk(int(n))
+        return d[:n]

@@ -1,0 +1,665 @@
+// qf_api.hip — the C ABI of include/quaff_hip.h: context, device memory, batch orchestration.
+// No kernels here (qf_kernels.hip) and no model arithmetic (qf_model.cpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/quaff_hip.h"
+#include "qf_kernels.hpp"
+#include "qf_model.hpp"
+
+using namespace qf;
+
+namespace {
+std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  template <class T> T* as() const { return (T*)p; }
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {  // retry exact
+      want = bytes;
+      e = hipMalloc(&p, want);
+    }
+    if (e == hipSuccess) cap = want; else p = nullptr;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+}  // namespace
+
+struct qf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  hipEvent_t cls_ev[kNumClasses + 1] = {};
+  std::string err, devname;
+  // model
+  Params params;
+  Scores scores;
+  bool have_params = false;
+  NullParams null;
+  bool have_null = false;
+  DevBuf d_ematch, d_eins, d_trans, d_nullq;
+  // references
+  uint32_t n_refs = 0;
+  std::vector<uint64_t> ref_off, ref_woff;
+  uint64_t ref_total = 0, ref_maxlen = 0;
+  DevBuf d_ref_seq, d_ref_tok, d_ref_off, d_ref_woff, d_ref_packed, d_bucket, d_cursor, d_pos;
+  int index_k = 0;
+  // reads
+  uint32_t n_reads = 0;
+  std::vector<uint64_t> read_off;
+  uint64_t read_total = 0, read_maxlen = 0;
+  bool reads_have_qual = false;
+  DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll;
+  // batch state
+  DevBuf d_units, d_cls_list, d_pair_head, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
+      d_recs, d_runs_tmp, d_runs_out, d_cover;
+  // host results
+  std::vector<double> h_viterbi, h_nll;
+  std::vector<uint64_t> h_cells;
+  std::vector<uint32_t> h_ndiag, h_runs;
+  std::vector<qf_alignment> h_align;
+  std::vector<AlignRec> h_recs;
+};
+
+#define HIPCHK(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipError_t _e = (call);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                           \
+      return QF_ERR_DEVICE;                                                                     \
+    }                                                                                           \
+  } while (0)
+
+static int fail(qf_ctx* c, int code, const std::string& msg) {
+  c->err = msg;
+  return code;
+}
+
+extern "C" {
+
+int qf_ctx_create(int device_id, qf_ctx** out) {
+  if (!out) return QF_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = "no HIP device available (libquaffhip has no CPU fallback)";
+    return QF_ERR_DEVICE;
+  }
+  if (device_id < 0 || device_id >= n) {
+    g_create_error = "device id out of range";
+    return QF_ERR_ARG;
+  }
+  if ((e = hipSetDevice(device_id)) != hipSuccess) {
+    g_create_error = hipGetErrorString(e);
+    return QF_ERR_DEVICE;
+  }
+  qf_ctx* c = new qf_ctx();
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+  if ((e = hipStreamCreate(&c->stream)) != hipSuccess) {
+    g_create_error = hipGetErrorString(e);
+    delete c;
+    return QF_ERR_DEVICE;
+  }
+  for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+  for (auto& ev : c->cls_ev) (void)hipEventCreate(&ev);
+  *out = c;
+  return QF_OK;
+}
+
+void qf_ctx_destroy(qf_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
+                    &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_units, &c->d_cls_list,
+                    &c->d_pair_head, &c->d_pair_ndiag, &c->d_pair_cells, &c->d_pair_score, &c->d_pair_end_unit,
+                    &c->d_bc, &c->d_tb, &c->d_recs, &c->d_runs_tmp, &c->d_runs_out, &c->d_cover})
+    b->release();
+  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->cls_ev) if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* qf_last_error(const qf_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int qf_device_name(const qf_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || !cap) return QF_ERR_ARG;
+  snprintf(buf, cap, "%s", c->devname.c_str());
+  return QF_OK;
+}
+
+// ---------------------------------------------------------------------------------- model
+int qf_set_params_json(qf_ctx* c, const char* text) {
+  if (!c) return QF_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  Json j;
+  std::string err;
+  if (!parse_json(text ? text : kDefaultParamsJson, j, err)) return fail(c, QF_ERR_PARSE, err);
+  Params p;
+  if (!p.read_json(j, err)) return fail(c, QF_ERR_PARSE, err);
+  c->params = p;
+  c->scores.build(p);
+  const Scores& s = c->scores;
+  // device layout of the match table: [(kmer*95 + q)*4 + refTok] so the four reference-token variants
+  // of one read column are adjacent
+  std::vector<double> em((size_t)s.Km * kNQ1 * 4);
+  for (uint32_t t = 0; t < 4; ++t)
+    for (uint32_t k = 0; k < s.Km; ++k)
+      for (int q = 0; q < kNQ1; ++q) em[((size_t)k * kNQ1 + q) * 4 + t] = s.mat[((size_t)t * s.Km + k) * kNQ1 + q];
+  HIPCHK(c, c->d_ematch.reserve(em.size() * 8));
+  HIPCHK(c, c->d_eins.reserve(s.ins.size() * 8));
+  HIPCHK(c, c->d_trans.reserve(s.trans.size() * 8));
+  HIPCHK(c, hipMemcpy(c->d_ematch.p, em.data(), em.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_eins.p, s.ins.data(), s.ins.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_trans.p, s.trans.data(), s.trans.size() * 8, hipMemcpyHostToDevice));
+  c->have_params = true;
+  return QF_OK;
+}
+
+int qf_get_scores(const qf_ctx* c, int* match_len, int* gap_len, double* ins, double* mat, double* trans) {
+  if (!c || !c->have_params) return QF_ERR_STATE;
+  const Scores& s = c->scores;
+  if (match_len) *match_len = (int)s.match_len;
+  if (gap_len) *gap_len = (int)s.gap_len;
+  if (ins) memcpy(ins, s.ins.data(), s.ins.size() * 8);
+  if (mat) memcpy(mat, s.mat.data(), s.mat.size() * 8);
+  if (trans) memcpy(trans, s.trans.data(), s.trans.size() * 8);
+  return QF_OK;
+}
+
+int qf_scores_from_json(const char* text, int* match_len, int* gap_len, double* ins, double* mat, double* trans,
+                        char* errbuf, size_t err_cap) {
+  Json j;
+  std::string err;
+  Params p;
+  if (!parse_json(text ? text : kDefaultParamsJson, j, err) || !p.read_json(j, err)) {
+    if (errbuf && err_cap) snprintf(errbuf, err_cap, "%s", err.c_str());
+    return QF_ERR_PARSE;
+  }
+  Scores s;
+  s.build(p);
+  if (match_len) *match_len = (int)s.match_len;
+  if (gap_len) *gap_len = (int)s.gap_len;
+  if (ins) memcpy(ins, s.ins.data(), s.ins.size() * 8);
+  if (mat) memcpy(mat, s.mat.data(), s.mat.size() * 8);
+  if (trans) memcpy(trans, s.trans.data(), s.trans.size() * 8);
+  return QF_OK;
+}
+
+const char* qf_fill_class_name(uint32_t cls) {
+  static std::string names[kNumClasses];
+  if (cls >= (uint32_t)kNumClasses) return nullptr;
+  if (names[cls].empty())
+    names[cls] = cls == 0 ? std::string("k_viterbi_single")
+                          : "k_viterbi_fill<" + std::to_string(fill_class((int)cls).G) + "," + std::to_string(fill_class((int)cls).B) + ">";
+  return names[cls].c_str();
+}
+
+int qf_set_null_json(qf_ctx* c, const char* text) {
+  if (!c) return QF_ERR_ARG;
+  if (!text) {
+    c->have_null = false;
+    return QF_OK;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  Json j;
+  std::string err;
+  if (!parse_json(text, j, err)) return fail(c, QF_ERR_PARSE, err);
+  NullParams n;
+  if (!n.read_json(j, err)) return fail(c, QF_ERR_PARSE, err);
+  c->null = n;
+  double le, l1, ls[4];
+  std::vector<double> lq(4 * kNQual);
+  n.tables(le, l1, ls, lq.data());
+  HIPCHK(c, c->d_nullq.reserve(lq.size() * 8));
+  HIPCHK(c, hipMemcpy(c->d_nullq.p, lq.data(), lq.size() * 8, hipMemcpyHostToDevice));
+  c->have_null = true;
+  return QF_OK;
+}
+
+int qf_get_lse_table(const qf_ctx*, const double** table, int* n) {
+  const std::vector<double>& t = lse_table();
+  if (table) *table = t.data();
+  if (n) *n = kLseEntries;
+  return QF_OK;
+}
+
+// ------------------------------------------------------------------------------ sequences
+static int read_counters(qf_ctx* c, BatchCounters& bc) {
+  HIPCHK(c, hipMemcpyAsync(&bc, c->d_bc.p, sizeof bc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return QF_OK;
+}
+
+int qf_set_refs(qf_ctx* c, const char* seq, const uint64_t* offsets, uint32_t n_refs) {
+  if (!c || !seq || !offsets || !n_refs) return QF_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->n_refs = 0;
+  c->index_k = 0;
+  c->ref_off.assign(offsets, offsets + n_refs + 1);
+  c->ref_total = offsets[n_refs] - offsets[0];
+  if (offsets[0] != 0) return fail(c, QF_ERR_ARG, "offsets[0] must be 0");
+  c->ref_maxlen = 0;
+  c->ref_woff.assign(n_refs + 1, 0);
+  for (uint32_t x = 0; x < n_refs; ++x) {
+    if (offsets[x + 1] <= offsets[x]) return fail(c, QF_ERR_ARG, "empty reference sequence");
+    const uint64_t len = offsets[x + 1] - offsets[x];
+    if (len > 0x7FFFFFF0ull) return fail(c, QF_ERR_ARG, "reference longer than 2^31");
+    c->ref_maxlen = std::max(c->ref_maxlen, len);
+    c->ref_woff[x + 1] = c->ref_woff[x] + (len + 15) / 16 + 2;
+  }
+  HIPCHK(c, c->d_ref_seq.reserve(c->ref_total));
+  HIPCHK(c, c->d_ref_tok.reserve(c->ref_total));
+  HIPCHK(c, c->d_ref_off.reserve((n_refs + 1) * 8));
+  HIPCHK(c, c->d_ref_woff.reserve((n_refs + 1) * 8));
+  HIPCHK(c, c->d_ref_packed.reserve(c->ref_woff[n_refs] * 4));
+  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
+  HIPCHK(c, hipMemcpyAsync(c->d_ref_seq.p, seq, c->ref_total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ref_off.p, c->ref_off.data(), (n_refs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ref_woff.p, c->ref_woff.data(), (n_refs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
+  launch_prep_ref(c->d_ref_seq.as<char>(), c->ref_total, c->d_ref_tok.as<uint8_t>(), c->d_bc.as<BatchCounters>(), c->stream);
+  launch_pack_ref(c->d_ref_tok.as<uint8_t>(), c->d_ref_off.as<uint64_t>(), c->d_ref_woff.as<uint64_t>(), n_refs,
+                  c->ref_maxlen, c->d_ref_packed.as<uint32_t>(), c->stream);
+  HIPCHK(c, hipGetLastError());
+  BatchCounters bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  if (bc.error & 4u) {
+    char m[96];
+    snprintf(m, sizeof m, "Unknown symbol %c in reference sequence (offset %u)", seq[bc.error_detail], bc.error_detail);
+    return fail(c, QF_ERR_SYMBOL, m);
+  }
+  c->n_refs = n_refs;
+  return QF_OK;
+}
+
+static int ensure_ref_index(qf_ctx* c, int k) {
+  if (c->index_k == k) return QF_OK;
+  if (k < 1 || k > kMaxRefK)
+    return fail(c, QF_ERR_UNSUPPORTED, "-kmatch " + std::to_string(k) + ": device k-mer index is built for k <= " + std::to_string(kMaxRefK));
+  const uint32_t nb = 1u << (2 * k);
+  const size_t bytes = (size_t)c->n_refs * (nb + 1) * 4;
+  HIPCHK(c, c->d_bucket.reserve(bytes));
+  HIPCHK(c, c->d_cursor.reserve(bytes));
+  HIPCHK(c, c->d_pos.reserve(c->ref_total * 4));
+  HIPCHK(c, hipMemsetAsync(c->d_bucket.p, 0, bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_cursor.p, 0, bytes, c->stream));
+  launch_ref_index(c->d_ref_tok.as<uint8_t>(), c->d_ref_off.as<uint64_t>(), c->n_refs, c->ref_maxlen, (uint32_t)k, nb,
+                   c->d_bucket.as<uint32_t>(), c->d_cursor.as<uint32_t>(), c->d_pos.as<uint32_t>(), c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->index_k = k;
+  return QF_OK;
+}
+
+int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t* offsets, uint32_t n_reads) {
+  if (!c || !seq || !offsets) return QF_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->n_reads = 0;
+  if (n_reads && offsets[0] != 0) return fail(c, QF_ERR_ARG, "offsets[0] must be 0");
+  c->read_off.assign(offsets, offsets + n_reads + 1);
+  c->read_total = n_reads ? offsets[n_reads] : 0;
+  c->read_maxlen = 0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    if (offsets[r + 1] <= offsets[r]) return fail(c, QF_ERR_ARG, "empty read (the reference drops zero-length sequences on load)");
+    c->read_maxlen = std::max(c->read_maxlen, offsets[r + 1] - offsets[r]);
+  }
+  if (c->read_maxlen > 0xFFFFu * 16ull) return fail(c, QF_ERR_UNSUPPORTED, "read longer than 1M bases");
+  const uint64_t tot = c->read_total;
+  HIPCHK(c, c->d_seq.reserve(tot + 16));
+  if (qual) HIPCHK(c, c->d_qual.reserve(tot + 16));
+  HIPCHK(c, c->d_roff.reserve((n_reads + 1) * 8));
+  HIPCHK(c, c->d_tok.reserve(tot + 16));
+  HIPCHK(c, c->d_ctx.reserve((tot + 2 * kCtxPad) * 4));
+  HIPCHK(c, c->d_skmer.reserve((tot + 16) * 4));
+  HIPCHK(c, c->d_nll.reserve((n_reads + 1) * 8));
+  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
+  HIPCHK(c, hipMemcpyAsync(c->d_seq.p, seq, tot, hipMemcpyHostToDevice, c->stream));
+  if (qual) HIPCHK(c, hipMemcpyAsync(c->d_qual.p, qual, tot, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_roff.p, c->read_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_ctx.p, 0, (tot + 2 * kCtxPad) * 4, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->reads_have_qual = qual != nullptr;
+  c->n_reads = n_reads;
+  return QF_OK;
+}
+
+// tokens / context words / seeding k-mers / null log-likelihoods for the resident reads
+static int prep_reads(qf_ctx* c, int seed_k) {
+  PrepArgs a{};
+  a.seq = c->d_seq.as<char>();
+  a.qual = c->reads_have_qual ? c->d_qual.as<char>() : nullptr;
+  a.off = c->d_roff.as<uint64_t>();
+  a.match_len = c->scores.match_len;
+  a.gap_len = c->scores.gap_len;
+  a.seed_k = (uint32_t)seed_k;
+  a.tok = c->d_tok.as<uint8_t>();
+  a.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+  a.skmer = c->d_skmer.as<uint32_t>();
+  a.nll = c->d_nll.as<double>();
+  a.has_null = c->have_null;
+  if (c->have_null) {
+    std::vector<double> lq(4 * kNQual);
+    c->null.tables(a.null_logEmit, a.null_log1mEmit, a.null_logSym, lq.data());
+    a.null_logQual = c->d_nullq.as<double>();
+  }
+  a.bc = c->d_bc.as<BatchCounters>();
+  launch_prep_reads(a, c->n_reads, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return QF_OK;
+}
+
+static int check_cfg(qf_ctx* c, const qf_dp_config* cfg) {
+  if (!c) return QF_ERR_ARG;
+  if (!cfg) return fail(c, QF_ERR_ARG, "null config");
+  if (!c->have_params) return fail(c, QF_ERR_STATE, "no parameters set (qf_set_params_json)");
+  if (!c->n_refs) return fail(c, QF_ERR_STATE, "no references set (qf_set_refs)");
+  if (cfg->band_size < 0) return fail(c, QF_ERR_ARG, "negative band size");
+  if (cfg->sparse && (cfg->kmer_len < 1 || cfg->kmer_len > 32)) return fail(c, QF_ERR_ARG, "kmer_len out of range");
+  return QF_OK;
+}
+
+static void fill_seed_args(qf_ctx* c, const qf_dp_config* cfg, SeedArgs& s, uint32_t max_units, int max_nd) {
+  s = SeedArgs{};
+  s.n_refs = c->n_refs;
+  s.ref_off = c->d_ref_off.as<uint64_t>();
+  s.read_off = c->d_roff.as<uint64_t>();
+  s.skmer = c->d_skmer.as<uint32_t>();
+  s.ref_bucket = c->d_bucket.as<uint32_t>();
+  s.ref_pos = c->d_pos.as<uint32_t>();
+  s.nbuckets = cfg->sparse ? 1u << (2 * cfg->kmer_len) : 0;
+  s.sparse = cfg->sparse;
+  s.kmer_len = cfg->kmer_len;
+  s.threshold = cfg->kmer_threshold;
+  s.band = cfg->band_size;
+  s.cell_size = 24;  // QuaffDPMatrixContainer::cellSize(), src/qmodel.h:384 (align / overlap)
+  s.max_size = cfg->max_size;
+  s.max_nd = max_nd;
+  s.units = c->d_units.as<Unit>();
+  s.max_units = max_units;
+  s.cls_list = c->d_cls_list.as<uint32_t>();
+  s.pair_head = c->d_pair_head.as<uint32_t>();
+  s.pair_ndiag = c->d_pair_ndiag.as<uint32_t>();
+  s.pair_cells = c->d_pair_cells.as<unsigned long long>();
+  s.bc = c->d_bc.as<BatchCounters>();
+}
+
+static int reserve_pair_buffers(qf_ctx* c, uint64_t n_pairs, uint32_t max_units) {
+  HIPCHK(c, c->d_units.reserve((size_t)max_units * sizeof(Unit)));
+  HIPCHK(c, c->d_cls_list.reserve((size_t)kNumClasses * max_units * 4));
+  HIPCHK(c, c->d_pair_head.reserve(n_pairs * 4));
+  HIPCHK(c, c->d_pair_ndiag.reserve(n_pairs * 4));
+  HIPCHK(c, c->d_pair_cells.reserve(n_pairs * 8));
+  HIPCHK(c, c->d_pair_score.reserve(n_pairs * 8));
+  HIPCHK(c, c->d_pair_end_unit.reserve(n_pairs * 4));
+  HIPCHK(c, hipMemsetAsync(c->d_pair_head.p, 0xFF, n_pairs * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_pair_ndiag.p, 0, n_pairs * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_pair_cells.p, 0, n_pairs * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
+  return QF_OK;
+}
+
+int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_align_result* out) {
+  if (int rc = check_cfg(c, cfg)) return rc;
+  if (!out) return fail(c, QF_ERR_ARG, "null result");
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
+  const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
+  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
+  const uint32_t n_pairs = (uint32_t)n_pairs64;
+  out->n_reads = n_reads;
+  out->n_refs = n_refs;
+  if (!n_pairs) return QF_OK;
+  const bool sparse = cfg->sparse != 0;
+  const bool mem = sparse && cfg->kmer_threshold < 0;
+  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
+
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const uint32_t max_units = n_pairs * 4 + 1024;
+  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+  // ---- seeding
+  const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
+  SeedArgs sa;
+  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
+    return fail(c, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
+                                           " exceeds the LDS diagonal histogram (global-memory histogram not built yet)");
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  BatchCounters bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  if (bc.error & 2u)
+    return fail(c, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels (" +
+                                           std::to_string(kMaxBandDiagSpace) + "); the row-space full-DP kernel is not built yet");
+  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
+
+  // ---- fill
+  const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
+  if (tb_bytes > (200ull << 30)) return fail(c, QF_ERR_MEMORY, "traceback needs " + std::to_string(tb_bytes >> 30) + " GiB; split the batch");
+  HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
+  FillArgs fa{};
+  fa.n_refs = n_refs;
+  fa.units = c->d_units.as<Unit>();
+  fa.ref_off = c->d_ref_off.as<uint64_t>();
+  fa.ref_woff = c->d_ref_woff.as<uint64_t>();
+  fa.ref_tok = c->d_ref_tok.as<uint8_t>();
+  fa.ref_packed = c->d_ref_packed.as<uint32_t>();
+  fa.read_off = c->d_roff.as<uint64_t>();
+  fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+  fa.tb = c->d_tb.as<uint32_t>();
+  const Scores& sc = c->scores;
+  fa.dp.ematch = c->d_ematch.as<double>();
+  fa.dp.eins = c->d_eins.as<double>();
+  fa.dp.trans = c->d_trans.as<double>();
+  fa.dp.d2d = sc.trans[4 * sc.Kg + 0];
+  fa.dp.d2m = sc.trans[4 * sc.Kg + 1];
+  fa.dp.i2i = sc.trans[4 * sc.Kg + 2];
+  fa.dp.i2m = sc.trans[4 * sc.Kg + 3];
+  fa.dp.Kg = sc.Kg;
+  fa.dp.local = cfg->local;
+  // widest classes first: they run longest
+  for (int cls = kNumClasses - 1; cls >= 0; --cls) {
+    HIPCHK(c, hipEventRecord(c->cls_ev[cls + 1], c->stream));
+    fa.n_cls_units = bc.cls_count[cls];
+    fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+    launch_viterbi_fill(cls, fa, sc.Kg > 1, c->stream);
+  }
+  HIPCHK(c, hipEventRecord(c->cls_ev[0], c->stream));
+  const BatchCounters seed_bc = bc;
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+
+  // ---- pair results, selection, traceback
+  FinalArgs fin{};
+  fin.n_pairs = n_pairs;
+  fin.n_reads = n_reads;
+  fin.n_refs = n_refs;
+  fin.all = (flags & QF_ALIGN_ALL) != 0;
+  fin.units = c->d_units.as<Unit>();
+  fin.pair_head = c->d_pair_head.as<uint32_t>();
+  fin.pair_score = c->d_pair_score.as<double>();
+  fin.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
+  fin.nll = c->d_nll.as<double>();
+  fin.read_off = c->d_roff.as<uint64_t>();
+  fin.tb = c->d_tb.as<uint32_t>();
+  fin.bc = c->d_bc.as<BatchCounters>();
+  launch_finalize(fin, c->stream);
+  uint32_t n_recs = 0;
+  uint64_t total_runs = 0;
+  if (!(flags & QF_ALIGN_NO_TRACEBACK)) {
+    const size_t max_recs = fin.all ? n_pairs : n_reads;
+    HIPCHK(c, c->d_recs.reserve(max_recs * sizeof(AlignRec)));
+    fin.recs = c->d_recs.as<AlignRec>();
+    launch_select(fin, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (int rc = read_counters(c, bc)) return rc;
+    n_recs = bc.n_align;
+    HIPCHK(c, c->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
+    HIPCHK(c, c->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
+    fin.n_recs = n_recs;
+    fin.runs_tmp = c->d_runs_tmp.as<uint32_t>();
+    fin.runs_out = c->d_runs_out.as<uint32_t>();
+    launch_traceback(fin, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (int rc = read_counters(c, bc)) return rc;
+    total_runs = bc.total_runs_out;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+
+  // ---- results to the host
+  c->h_viterbi.resize(n_pairs);
+  c->h_cells.resize(n_pairs);
+  c->h_ndiag.resize(n_pairs);
+  c->h_nll.resize(n_reads);
+  c->h_recs.resize(n_recs);
+  c->h_runs.resize(total_runs);
+  HIPCHK(c, hipMemcpyAsync(c->h_viterbi.data(), c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_cells.data(), c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data(), c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_nll.data(), c->d_nll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
+  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data(), c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data(), c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+
+  // order: by read; within a read by descending score, earlier reference first on ties (multiset order,
+  // src/qmodel.cpp:2773-2775)
+  std::vector<uint32_t> order(n_recs);
+  for (uint32_t a = 0; a < n_recs; ++a) order[a] = a;
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    const AlignRec &p = c->h_recs[x], &q = c->h_recs[y];
+    if (p.read != q.read) return p.read < q.read;
+    if (p.score != q.score) return p.score > q.score;
+    return p.ref < q.ref;
+  });
+  c->h_align.resize(n_recs);
+  for (uint32_t a = 0; a < n_recs; ++a) {
+    const AlignRec& r = c->h_recs[order[a]];
+    if (!r.ok) return fail(c, QF_ERR_DEVICE, "traceback did not reach the start state (read " + std::to_string(r.read) + ")");
+    qf_alignment& o = c->h_align[a];
+    o.read = r.read;
+    o.ref = r.ref;
+    o.viterbi = r.viterbi;
+    o.score = r.score;
+    o.x_start = r.x_start;
+    o.x_end = r.x_end;
+    o.n_columns = r.n_columns;
+    o.n_runs = r.n_runs;
+    o.run_offset = r.run_off;
+  }
+  out->viterbi = c->h_viterbi.data();
+  out->cells = c->h_cells.data();
+  out->n_diagonals = c->h_ndiag.data();
+  out->null_loglike = c->h_nll.data();
+  out->total_cells = bc.total_cells;
+  out->n_alignments = n_recs;
+  out->alignments = c->h_align.data();
+  out->cigar_runs = c->h_runs.data();
+  out->n_units = bc.n_units;
+  out->traceback_bytes = tb_bytes;
+  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&out->ms_seed, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&out->ms_fill, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&out->ms_traceback, c->ev[3], c->ev[4]);
+  (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
+  out->n_fill_classes = kNumClasses;
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    // class cls ran between cls_ev[cls+1] and the next lower class's start (cls_ev[cls]); cls 0 ends at cls_ev[0]
+    out->ms_fill_class[cls] = 0;
+    if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&out->ms_fill_class[cls], c->cls_ev[cls + 1], c->cls_ev[cls]);
+    out->cells_class[cls] = seed_bc.cls_cells[cls];
+    out->units_class[cls] = seed_bc.cls_count[cls];
+  }
+  return QF_OK;
+}
+
+int qf_align_batch(qf_ctx* c, const qf_dp_config* cfg, const char* seq, const char* qual, const uint64_t* offsets,
+                   uint32_t n_reads, uint32_t flags, qf_align_result* out) {
+  if (int rc = qf_upload_reads(c, seq, qual, offsets, n_reads)) return rc;
+  return qf_align_resident(c, cfg, flags, out);
+}
+
+int64_t qf_envelope(qf_ctx* c, const qf_dp_config* cfg, uint32_t read, uint32_t ref, int32_t* diags, uint64_t cap) {
+  if (int rc = check_cfg(c, cfg)) return rc;
+  if (read >= c->n_reads || ref >= c->n_refs) return fail(c, QF_ERR_ARG, "pair out of range");
+  if (hipSetDevice(c->device) != hipSuccess) return QF_ERR_DEVICE;
+  const bool sparse = cfg->sparse != 0;
+  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
+  const uint64_t n_pairs = (uint64_t)c->n_reads * c->n_refs;
+  const uint32_t max_units = 4096;
+  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  const int xLen = (int)(c->ref_off[ref + 1] - c->ref_off[ref]), yLen = (int)(c->read_off[read + 1] - c->read_off[read]);
+  const int nd = xLen + yLen - 1;
+  if (c->d_cover.reserve((size_t)nd + 16) != hipSuccess) return fail(c, QF_ERR_MEMORY, "out of device memory");
+  SeedArgs sa;
+  fill_seed_args(c, cfg, sa, max_units, sparse ? (int)(c->ref_maxlen + c->read_maxlen - 1) : 2);
+  sa.pair_base = read * c->n_refs + ref;
+  sa.dump_cover = c->d_cover.as<uint8_t>();
+  if (launch_seed(sa, 1, sparse && cfg->kmer_threshold < 0, c->stream) != 0) return fail(c, QF_ERR_UNSUPPORTED, "sequence too long for the LDS histogram");
+  std::vector<uint8_t> cover(nd);
+  if (hipMemcpyAsync(cover.data(), c->d_cover.p, nd, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess)
+    return fail(c, QF_ERR_DEVICE, "copy failed");
+  int64_t n = 0;
+  for (int b = 0; b < nd; ++b)
+    if (cover[b]) {
+      if ((uint64_t)n < cap && diags) diags[n] = b + (1 - yLen);
+      ++n;
+    }
+  return n;
+}
+
+size_t qf_cigar_string(const uint32_t* runs, uint32_t n_runs, char* buf, size_t cap) {
+  std::string s;
+  for (uint32_t a = 0; a < n_runs; ++a) {
+    s += "MID"[runs[a] & 3u];
+    s += std::to_string(runs[a] >> 2);
+  }
+  if (buf && cap) snprintf(buf, cap, "%s", s.c_str());
+  return s.size();
+}
+
+int qf_synth_ref(uint64_t seed, uint64_t ref_len, char* seq) {
+  if (!seq) return QF_ERR_ARG;
+  synth_ref(seed, ref_len, seq);
+  return QF_OK;
+}
+
+int qf_synth_reads(uint64_t seed, const char* ref, uint64_t ref_len, uint32_t n_reads, uint32_t read_len, char* seq,
+                   char* qual, uint64_t* offsets) {
+  if (!ref || !seq || !qual || !offsets || !ref_len || !read_len) return QF_ERR_ARG;
+  synth_reads(seed, ref, ref_len, n_reads, read_len, seq, qual, offsets);
+  return QF_OK;
+}
+
+}  // extern "C"

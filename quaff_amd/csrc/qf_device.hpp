@@ -1,0 +1,79 @@
+// qf_device.hpp — device-side data layout shared by the HIP kernels and the C-ABI host code.
+// gfx950 only: 64-wide wavefronts, fp64 VALU, LDS histograms; no MFMA (the recurrence is
+// max-plus / log-sum-exp, not a contraction).
+#pragma once
+#include <cstdint>
+
+namespace qf {
+
+constexpr int kMaxRefK = 8;        // direct-addressed k-mer index up to 4^8 buckets per sequence
+constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
+constexpr int kCtxPad = 128;       // junk words before/after the per-column context array
+
+// Packed per-column read context word (one per read base), built by the prep kernel:
+//   bits  0..14  erow   = matchKmer*95 + q      row of the match-emission table (q = 94 without quals)
+//   bits 15..23  insrow = token*95 + q          row of the insert-emission table
+//   bits 24..31  gk     = indel-context k-mer of the context ending at this base
+__host__ __device__ inline uint32_t ctx_pack(uint32_t erow, uint32_t insrow, uint32_t gk) {
+  return erow | (insrow << 15) | (gk << 24);
+}
+
+// One contiguous run of envelope diagonals of one (read, ref) pair.  Runs separated by a
+// missing diagonal never exchange probability mass (every transition moves to the same or an
+// adjacent diagonal), so each is an independent DP problem.
+struct Unit {
+  uint32_t pair;      // read * n_refs + ref
+  int32_t dlo, dhi;   // diagonals i - j, inclusive
+  uint32_t next;      // next unit of the same pair (kNoUnit terminates)
+  uint64_t tb_off;    // first traceback word
+  double end_val;     // max over the last read column of mat + m2e  (-inf if none)
+  uint32_t end_i;     // its 1-based reference row (largest row on ties)
+  uint32_t cls;       // fill-kernel class
+};
+
+// Fill-kernel classes: class 0 = single diagonal (one lane per unit); class c>0 = G lanes x B
+// diagonals per lane.  Kept in one table so host and device agree.
+struct FillClass { int G, B; };
+constexpr int kNumClasses = 13;
+__host__ __device__ constexpr FillClass fill_class(int c) {
+  constexpr FillClass t[kNumClasses] = {{1, 1},  {16, 2}, {16, 3}, {16, 4}, {16, 5},  {16, 6},  {16, 8},
+                                        {64, 3}, {64, 4}, {64, 6}, {64, 8}, {64, 12}, {64, 16}};
+  return t[c];
+}
+constexpr int kMaxBandDiagSpace = 64 * 16;  // widest band the diagonal-space kernels take
+__host__ __device__ inline int classify_width(int W) {
+  if (W <= 1) return 0;
+  for (int c = 1; c < kNumClasses; ++c)
+    if (fill_class(c).G * fill_class(c).B >= W) return c;
+  return -1;  // needs the row-space kernel
+}
+// traceback words a unit occupies
+__host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
+  if (cls == 0) return (yLen + 7) / 8;
+  const FillClass fc = fill_class(cls);
+  return (uint64_t)(yLen + fc.G - 1) * fc.G * (fc.B > 8 ? 2 : 1);
+}
+
+struct BatchCounters {
+  uint32_t n_units;
+  uint32_t cls_count[kNumClasses];
+  uint32_t error;          // bit 0: unit overflow, bit 1: band too wide, bit 2: bad symbol
+  uint32_t error_detail;
+  unsigned long long tb_words;
+  unsigned long long total_cells;
+  unsigned long long cls_cells[kNumClasses];
+  uint32_t n_align;
+  unsigned long long n_runs;          // scratch run capacity reserved by the select kernel
+  unsigned long long total_runs_out;  // compacted CIGAR runs written by the traceback kernel
+};
+
+struct DpParams {  // kernel argument block for the fills
+  const double* ematch;   // [(matchKmer*95 + q)*4 + refTok]
+  const double* eins;     // [tok*95 + q]
+  const double* trans;    // m2m[Kg] m2i[Kg] m2d[Kg] m2e[Kg]
+  double d2d, d2m, i2i, i2m;
+  uint32_t Kg;
+  int32_t local;
+};
+
+}  // namespace qf

@@ -1,0 +1,785 @@
+// qf_kernels.hip — hand-written HIP kernels for gfx950 (MI355X): read/ref preparation, k-mer index,
+// diagonal seeding, banded Viterbi fill (anti-diagonal-skewed wavefront), end-cell reduction and
+// traceback.  fp64 throughout; compiled with -ffp-contract=off so every add/mul rounds exactly as the
+// reference's scalar code does.  See DESIGN.md for the layout and the roofline of each kernel.
+#include <hip/hip_runtime.h>
+
+#include "qf_kernels.hpp"
+
+namespace qf {
+
+#define QF_NEG_INF (-__builtin_huge_val())
+
+// ------------------------------------------------------------------------------------------------
+// Sequence preparation
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tokenize_char(int c) {  // tokenize(), src/fastseq.cpp:11-16
+  c &= ~0x20;  // toupper for letters
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+
+// One thread per reference base: token bytes; one thread per 16 bases: 2-bit packed words.
+__global__ void k_prep_ref(const char* __restrict__ seq, uint64_t total, uint8_t* __restrict__ tok,
+                           BatchCounters* bc) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int t = tokenize_char((unsigned char)seq[i]);
+  if (t < 0) {
+    atomicOr(&bc->error, 4u);
+    bc->error_detail = (uint32_t)i;
+    t = 0;
+  }
+  tok[i] = (uint8_t)t;
+}
+
+__global__ void k_pack_ref(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off,
+                           const uint64_t* __restrict__ woff, uint32_t n_refs, uint32_t* __restrict__ packed) {
+  const uint32_t x = blockIdx.y;
+  const uint64_t b = off[x], len = off[x + 1] - b;
+  const uint64_t nw = (len + 15) / 16 + 2;  // two zero words of slack
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nw) return;
+  uint32_t v = 0;
+  for (int a = 0; a < 16; ++a) {
+    const uint64_t p = w * 16 + a;
+    if (p < len) v |= (uint32_t)tok[b + p] << (2 * a);
+  }
+  packed[woff[x] + w] = v;
+}
+
+// k-mer index of each reference: counting sort of positions by k-mer value (KmerIndex, src/fastseq.cpp:240-256,
+// built on the reference side once instead of on every read: the (i,j) match set is symmetric).
+__global__ void k_ref_kmer_count(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k,
+                                 uint32_t nbuckets, uint32_t* __restrict__ counts) {
+  const uint32_t x = blockIdx.y;
+  const uint64_t b = off[x], len = off[x + 1] - b;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (len < k || i > len - k) return;
+  uint32_t km = 0;
+  for (uint32_t a = 0; a < k; ++a) km = km * 4 + tok[b + i + a];
+  atomicAdd(&counts[(uint64_t)x * (nbuckets + 1) + km], 1u);
+}
+
+// exclusive scan of each reference's bucket counts (one block per reference)
+__global__ __launch_bounds__(1024) void k_bucket_scan(uint32_t* __restrict__ counts, uint32_t nbuckets) {
+  __shared__ uint32_t part[1024];
+  uint32_t* c = counts + (uint64_t)blockIdx.x * (nbuckets + 1);
+  const uint32_t tid = threadIdx.x, per = (nbuckets + 1 + 1023) / 1024;
+  const uint32_t lo = tid * per, hi = min(lo + per, nbuckets + 1);
+  uint32_t s = 0;
+  for (uint32_t a = lo; a < hi; ++a) s += c[a];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? part[tid - 1] : 0;
+  for (uint32_t a = lo; a < hi; ++a) {
+    const uint32_t v = c[a];
+    c[a] = run;
+    run += v;
+  }
+}
+
+__global__ void k_ref_kmer_scatter(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k,
+                                   uint32_t nbuckets, const uint32_t* __restrict__ starts,
+                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ pos) {
+  const uint32_t x = blockIdx.y;
+  const uint64_t b = off[x], len = off[x + 1] - b;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (len < k || i > len - k) return;
+  uint32_t km = 0;
+  for (uint32_t a = 0; a < k; ++a) km = km * 4 + tok[b + i + a];
+  const uint64_t bi = (uint64_t)x * (nbuckets + 1) + km;
+  const uint32_t slot = starts[bi] + atomicAdd(&cursor[bi], 1u);
+  pos[b + slot] = (uint32_t)i;
+}
+
+// One wavefront per read: tokens, packed per-column context words, seeding k-mers and the null-model
+// log-likelihood (FastSeq::tokens/kmers/qualScores src/fastseq.cpp:71-109; QuaffDPMatrix ctor
+// src/qmodel.cpp:1308-1324; QuaffNullParams::logLikelihood :1875-1890).
+__global__ __launch_bounds__(64) void k_prep_reads(PrepArgs a) {
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
+  const uint64_t b = a.off[r];
+  const uint32_t L = (uint32_t)(a.off[r + 1] - b);
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  for (uint32_t i = lane; i < L; i += 64) {
+    int t = tokenize_char((unsigned char)a.seq[b + i]);
+    if (t < 0) {
+      atomicOr(&a.bc->error, 4u);
+      a.bc->error_detail = r;
+      t = 0;
+    }
+    a.tok[b + i] = (uint8_t)t;
+    cnt0 += t == 0; cnt1 += t == 1; cnt2 += t == 2; cnt3 += t == 3;
+  }
+  for (int o = 32; o; o >>= 1) {
+    cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
+    cnt2 += __shfl_xor(cnt2, o); cnt3 += __shfl_xor(cnt3, o);
+  }
+  // most frequent token, first maximum on ties (max_element, src/fastseq.cpp:92)
+  uint32_t padTok = 0, best = cnt0;
+  if (cnt1 > best) { best = cnt1; padTok = 1; }
+  if (cnt2 > best) { best = cnt2; padTok = 2; }
+  if (cnt3 > best) { best = cnt3; padTok = 3; }
+  auto tokAt = [&](int64_t p) -> uint32_t {
+    if (p < 0) return padTok;
+    int t = tokenize_char((unsigned char)a.seq[b + p]);
+    return t < 0 ? 0u : (uint32_t)t;
+  };
+  for (uint32_t i = lane; i < L; i += 64) {
+    uint32_t mk = 0, gk = 0;
+    for (uint32_t c = 0; c < a.match_len; ++c) mk = mk * 4 + tokAt((int64_t)i - (a.match_len - 1) + c);
+    for (uint32_t c = 0; c < a.gap_len; ++c) gk = gk * 4 + tokAt((int64_t)i - (a.gap_len - 1) + c);
+    uint32_t q = kNQualDev;  // slot 94: no quality scores
+    if (a.qual) {
+      int v = (int)(signed char)a.qual[b + i] - '!';
+      q = (uint32_t)max(0, min(kNQualDev - 1, v));
+    }
+    const uint32_t t = tokAt(i);
+    a.ctx[b + i] = ctx_pack(mk * (kNQualDev + 1) + q, t * (kNQualDev + 1) + q, gk);
+    if (a.seed_k && i + a.seed_k <= L) {
+      uint32_t sk = 0;
+      for (uint32_t c = 0; c < a.seed_k; ++c) sk = sk * 4 + tokAt(i + c);
+      a.skmer[b + i] = sk;
+    }
+  }
+  if (lane == 0) {
+    double ll = 0;
+    if (a.has_null) {
+      ll = (double)L * a.null_logEmit + a.null_log1mEmit;
+      for (uint32_t i = 0; i < L; ++i) {
+        const uint32_t t = tokAt(i);
+        ll += a.null_logSym[t];
+        if (a.qual) {
+          int v = (int)(signed char)a.qual[b + i] - '!';
+          ll += a.null_logQual[t * kNQualDev + max(0, min(kNQualDev - 1, v))];
+        }
+      }
+    }
+    a.nll[r] = ll;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Seeding: DiagonalEnvelope::initSparse / initFull, src/diagenv.cpp:11-106
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long band_cells(int dlo, int dhi, int xLen, int yLen) {
+  unsigned long long c = 0;  // sum_d #{j in [1,yLen] : 1 <= d+j <= xLen}, diagenv.h:75-85
+  for (int d = dlo; d <= dhi; ++d) {
+    const int jlo = max(1, 1 - d), jhi = min(yLen, xLen - d);
+    if (jhi >= jlo) c += (unsigned)(jhi - jlo + 1);
+  }
+  return c;
+}
+
+__device__ int emit_unit(const SeedArgs& a, uint32_t pair, int dlo, int dhi, int xLen, int yLen) {
+  const int cls = classify_width(dhi - dlo + 1);
+  if (cls < 0) {
+    atomicOr(&a.bc->error, 2u);
+    a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
+    return -1;
+  }
+  const uint32_t uid = atomicAdd(&a.bc->n_units, 1u);
+  if (uid >= a.max_units) {
+    atomicOr(&a.bc->error, 1u);
+    return -1;
+  }
+  const uint32_t slot = atomicAdd(&a.bc->cls_count[cls], 1u);
+  a.cls_list[(uint64_t)cls * a.max_units + slot] = uid;
+  Unit u;
+  u.pair = pair;
+  u.dlo = dlo;
+  u.dhi = dhi;
+  u.tb_off = atomicAdd(&a.bc->tb_words, (unsigned long long)unit_tb_words(cls, (uint32_t)yLen));
+  u.end_val = QF_NEG_INF;
+  u.end_i = 0;
+  u.cls = (uint32_t)cls;
+  u.next = atomicExch(&a.pair_head[pair], uid);
+  a.units[uid] = u;
+  return cls;
+}
+
+// One 256-thread workgroup per (read, ref) pair.  LDS: a dense histogram of k-mer matches per diagonal
+// (two 16-bit counters per dword) and a per-diagonal membership array.
+template <bool MEM>
+__global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t pair = a.pair_base + blockIdx.x, tid = threadIdx.x;
+  const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
+  const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
+  const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
+  const int minD = 1 - yLen, maxD = xLen - 1, nd = xLen + yLen - 1;
+  const int k = a.kmer_len;
+
+  bool full = !a.sparse;
+  if (!full && a.threshold >= 0) {  // diagenv.cpp:23-29
+    const uint32_t minLen = 2u * (uint32_t)(k + a.threshold);
+    if ((uint32_t)xLen < minLen || (uint32_t)yLen < minLen) full = true;
+  }
+  if (full) {  // initFull, diagenv.cpp:11-18
+    if (tid == 0) {
+      const int cls = emit_unit(a, pair, minD, maxD, xLen, yLen);
+      const unsigned long long cells = (unsigned long long)xLen * (unsigned long long)yLen;
+      a.pair_ndiag[pair] = (uint32_t)nd;
+      a.pair_cells[pair] = cells;
+      atomicAdd(&a.bc->total_cells, cells);
+      if (cls >= 0) atomicAdd(&a.bc->cls_cells[cls], cells);
+    }
+    if (a.dump_cover)
+      for (int b = tid; b < nd; b += 256) a.dump_cover[b] = 1;
+    return;
+  }
+
+  const int histWords = (a.max_nd + 1) / 2;
+  uint32_t* hist = lds;
+  // threshold mode: cover = u8[nd]; memory mode: cover = u16[nd] level stamps, st = u16[nd+2] storage stamps
+  uint8_t* cover8 = (uint8_t*)(lds + histWords);
+  uint16_t* cover16 = (uint16_t*)(lds + histWords);
+  uint16_t* st16 = cover16 + ((a.max_nd + 3) & ~1);
+  __shared__ uint32_t s_red[256];
+
+  for (int w = tid; w < (nd + 1) / 2; w += 256) hist[w] = 0;
+  if (MEM) {
+    for (int b = tid; b < nd; b += 256) cover16[b] = 0;
+    for (int b = tid; b < nd + 2; b += 256) st16[b] = 0;
+  } else {
+    for (int b = tid; b < nd; b += 256) cover8[b] = 0;
+  }
+  __syncthreads();
+
+  // histogram of matching k-mer pairs per diagonal (diagenv.cpp:33-40), reads' k-mers against the
+  // reference's k-mer index
+  if (xLen >= k && yLen >= k) {
+    const uint32_t* starts = a.ref_bucket + (uint64_t)x * (a.nbuckets + 1);
+    const uint32_t* pos = a.ref_pos + xb;
+    for (int j = tid; j <= yLen - k; j += 256) {
+      const uint32_t km = a.skmer[yb + j];
+      const uint32_t s = starts[km], e = starts[km + 1];
+      for (uint32_t p = s; p < e; ++p) {
+        const int bin = (int)pos[p] - j + yLen - 1;
+        atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
+      }
+    }
+  }
+  __syncthreads();
+  auto count = [&](int bin) -> uint32_t { return (hist[bin >> 1] >> (16 * (bin & 1))) & 0xFFFFu; };
+  const int half = a.band / 2;
+
+  uint32_t accepted = 1;  // highest accepted level stamp (memory mode)
+  if (!MEM) {
+    const uint32_t thr = a.threshold > 1 ? (uint32_t)a.threshold : 1u;  // map holds only counts >= 1
+    for (int b = tid; b < nd; b += 256)
+      if (count(b) >= thr) {
+        const int seed = b + minD;
+        const int lo = max(minD, seed - half), hi = min(maxD, seed + half);
+        for (int d = lo; d <= hi; ++d) cover8[d - minD] = 1;
+      }
+    if (tid == 0) cover8[0 - minD] = 1;  // diagonal 0 always present, diagenv.cpp:52-54
+  } else {
+    // memory mode, diagenv.cpp:68-96: add whole count-levels in descending order while
+    // |storage diagonals| * diagSize < maxSize.
+    if (tid == 0) { cover16[0 - minD] = 1; st16[0 - minD + 1] = 1; }
+    uint32_t mx = 0;
+    for (int b = tid; b < nd; b += 256) mx = max(mx, count(b));
+    s_red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) { if (tid < o) s_red[tid] = max(s_red[tid], s_red[tid + o]); __syncthreads(); }
+    const uint32_t maxc = s_red[0];
+    __syncthreads();
+    const unsigned long long diagSize = (unsigned long long)min(xLen, yLen) * a.cell_size;
+    unsigned long long nst = 1;
+    uint32_t level = 1;
+    uint32_t c = maxc;
+    while (c >= 1) {
+      // mark every diagonal with exactly c matches under the next level stamp; find the next lower
+      // populated count on the way (levels = distinct counts, visited in descending order)
+      ++level;
+      uint32_t nextc = 0;
+      for (int b = tid; b < nd; b += 256) {
+        const uint32_t cb = count(b);
+        if (cb == c) {
+          const int seed = b + minD;
+          const int lo = max(minD, seed - half), hi = min(maxD, seed + half);
+          for (int d = lo; d <= hi; ++d) if (cover16[d - minD] == 0) cover16[d - minD] = (uint16_t)level;
+          for (int d = lo - 1; d <= hi + 1; ++d) if (st16[d - minD + 1] == 0) st16[d - minD + 1] = (uint16_t)level;
+        } else if (cb < c)
+          nextc = max(nextc, cb);
+      }
+      __syncthreads();
+      uint32_t added = 0;
+      for (int b = tid; b < nd + 2; b += 256) added += st16[b] == level;
+      s_red[tid] = added;
+      __syncthreads();
+      for (int o = 128; o; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
+      added = s_red[0];
+      __syncthreads();
+      s_red[tid] = nextc;
+      __syncthreads();
+      for (int o = 128; o; o >>= 1) { if (tid < o) s_red[tid] = max(s_red[tid], s_red[tid + o]); __syncthreads(); }
+      nextc = s_red[0];
+      __syncthreads();
+      if ((nst + added) * diagSize >= a.max_size) break;  // diagenv.cpp:88-89 (level rejected, stop)
+      nst += added;
+      accepted = level;
+      c = nextc;
+    }
+  }
+  __syncthreads();
+  auto member = [&](int b) -> bool {
+    if (MEM) { const uint32_t s = cover16[b]; return s != 0 && s <= accepted; }
+    return cover8[b] != 0;
+  };
+
+  // contiguous runs -> units; diagonal and cell counts
+  uint32_t nmem = 0;
+  unsigned long long cells = 0;
+  for (int b = tid; b < nd; b += 256) {
+    const bool in = member(b);
+    nmem += in;
+    if (a.dump_cover) a.dump_cover[b] = in;
+    if (in && (b == 0 || !member(b - 1))) {
+      int e = b;
+      while (e + 1 < nd && member(e + 1)) ++e;
+      const int cls = emit_unit(a, pair, b + minD, e + minD, xLen, yLen);
+      const unsigned long long bcells = band_cells(b + minD, e + minD, xLen, yLen);
+      cells += bcells;
+      if (cls >= 0) atomicAdd(&a.bc->cls_cells[cls], bcells);
+    }
+  }
+  s_red[tid] = nmem;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
+  if (tid == 0) a.pair_ndiag[pair] = s_red[0];
+  if (cells) {
+    atomicAdd(&a.pair_cells[pair], cells);
+    atomicAdd(&a.bc->total_cells, cells);
+  }
+}
+template __global__ void k_seed<false>(SeedArgs);
+template __global__ void k_seed<true>(SeedArgs);
+
+// ------------------------------------------------------------------------------------------------
+// Banded Viterbi fill: QuaffViterbiMatrix ctor, src/qmodel.cpp:1512-1560
+//
+// Lane l of a G-lane group owns B adjacent diagonals d0 = dlo + l*B ... and at step t works on read
+// column j = t - l + 1 (a skew of one column per lane).  With that skew every dependency is either in
+// the lane's own registers or one lane away:
+//   mat(i,j) <- (i-1,j-1): same diagonal, previous step               (own registers)
+//   ins(i,j) <- (i,  j-1): diagonal d+1, previous column              (own slot b+1, or lane l+1's slot 0,
+//                                                                       which lane l+1 finishes this very step)
+//   del(i,j) <- (i-1,j  ): diagonal d-1, same column                  (own slot b-1 this step, or lane l-1's
+//                                                                       last slot from the previous step)
+// so a group advances all its lanes every step.  Each cell records 4 traceback bits chosen exactly as
+// QuaffViterbiMatrix::alignment's updateMax sequence would choose them (src/qmodel.cpp:1590-1616).
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) U32x4 { uint32_t v[4]; };
+
+template <int G, int B, bool GAPCTX>
+__global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
+  constexpr int UPW = 64 / G;
+  constexpr int WPL = B > 8 ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int grp = lane / G, l = lane % G;
+  const uint32_t uidx = wave * UPW + grp;
+  const bool active = uidx < a.n_cls_units;
+
+  uint32_t uid = 0;
+  int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, xw = 0, tb_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb); xw = a.ref_woff[x];
+    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
+    dlo = u.dlo; dhi = u.dhi; tb_off = u.tb_off;
+  }
+  int T = active ? yLen + G - 1 : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+
+  const int d0 = dlo + l * B;
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg], c_m2e = trans[3 * Kg];
+
+  double M[B], I[B], D[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
+  double pubM = QF_NEG_INF, pubD = QF_NEG_INF;  // this lane's last slot (mat, del) after its latest step
+  double bestEnd = QF_NEG_INF;
+  uint32_t bestI = 0;
+
+  // reference tokens: 2-bit packed words, a 64-bit window (lo:hi) refreshed every 16 steps, one word
+  // prefetched ahead.  rtop(t) = 0-based reference index of the top slot's row at step t.
+  const uint32_t* __restrict__ xp = a.ref_packed + xw;
+  const int nxw = (xLen + 15) / 16 + 2;
+  const int rtop0 = d0 - l + B - 1;
+  const int q0 = rtop0 >> 4, sh0 = 2 * (rtop0 & 15);
+  auto xword = [&](int q) -> uint32_t { return xp[min(max(q, 0), nxw - 1)]; };
+  uint32_t xlo, xhi = xword(q0), xnx = xword(q0 + 1);
+  // token window: slot b at bits 2b; initialised with the rows the first step still needs
+  uint32_t win = 0;
+  {
+    const uint8_t* xt = a.ref_tok + xb;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int row = d0 - l - 1 + b;
+      const uint32_t t = (row >= 0 && row < xLen) ? xt[row] : 0u;
+      win |= t << (2 * b);
+    }
+  }
+  // read context words, 4 columns per load, one load ahead
+  const uint32_t* __restrict__ ctx = a.ctx + yb;  // padded: indices -kCtxPad .. +kCtxPad beyond the data are readable
+  U32x4 cwn = *(const U32x4*)(ctx + (0 - l));     // columns j = t-l+1 for t = 0..3 -> index j-1 = t-l
+  uint32_t gkPrev = 0;
+  uint32_t* __restrict__ tb = a.tb + tb_off;
+
+  int chunk = 0;
+  for (int t0 = 0; t0 < T; t0 += 16, ++chunk) {
+    xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
+    const unsigned long long xpair = ((unsigned long long)xhi << 32) | xlo;
+    for (int s4 = 0; s4 < 16; s4 += 4) {
+      const U32x4 cw = cwn;
+      cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = t0 + s4 + s;
+        const int j = t - l + 1;
+        const bool colvalid = active && j >= 1 && j <= yLen;
+        const uint32_t w = cw.v[s];
+        const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
+        double m2m, m2i, m2d;
+        if (GAPCTX) {
+          const uint32_t gp = j <= 1 ? 0u : gkPrev;  // yIndelKmer is padded with a leading 0 (qmodel.cpp:1322)
+          m2m = trans[gp]; m2i = trans[Kg + gp]; m2d = trans[2 * Kg + gk];
+          gkPrev = gk;
+        } else {
+          m2m = c_m2m; m2i = c_m2i; m2d = c_m2d;
+        }
+        const double insE = eins[insrow];
+        const uint32_t newTok = (uint32_t)(xpair >> (sh0 + 2 * (s4 + s))) & 3u;
+        win = (win >> 2) | (newTok << (2 * (B - 1)));
+
+        // neighbour below (diagonal d0-1, this column): lane l-1 published it at the end of the last step
+        double lowM = __shfl_up(pubM, 1, G), lowD = __shfl_up(pubD, 1, G);
+        if (l == 0) { lowM = QF_NEG_INF; lowD = QF_NEG_INF; }
+
+        double e[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) e[b] = ematch[erow4 + ((win >> (2 * b)) & 3u)];
+
+        const bool startCol = j == 1;
+        const bool endCol = j == yLen;
+        uint32_t tbw0 = 0, tbw1 = 0;
+        double nM0 = 0, nI0 = 0;  // new slot-0 values, handed to lane l-1
+        double upM = 0, upI = 0;  // lane l+1's new slot-0 values (its column is j-1)
+        double prevM = lowM, prevD = lowD;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const int d = d0 + b, i = d + j;
+          const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
+          // match state: candidates in traceback order M, I, D, Start (strict >)
+          const double tM = (M[b] + m2m) + e[b], tI = (I[b] + i2m) + e[b], tD = (D[b] + d2m) + e[b];
+          double nm = tM;
+          uint32_t sm = 0;
+          if (tI > nm) { nm = tI; sm = 1; }
+          if (tD > nm) { nm = tD; sm = 2; }
+          if (startCol && (i == 1 || local) && e[b] > nm) { nm = e[b]; sm = 3; }
+          // insert state: sources on diagonal d+1, previous column (M first, then I)
+          double srcM, srcI;
+          if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; }
+          else { srcM = upM; srcI = upI; }
+          const double cM = (srcM + m2i) + insE, cI = (srcI + i2i) + insE;
+          double ni = cM;
+          uint32_t si = 0;
+          if (cI > ni) { ni = cI; si = 1; }
+          // delete state: sources on diagonal d-1, this column (M first, then D)
+          const double gM = prevM + m2d, gD = prevD + d2d;
+          double ndl = gM;
+          uint32_t sd = 0;
+          if (gD > ndl) { ndl = gD; sd = 1; }
+          if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+          M[b] = nm; I[b] = ni; D[b] = ndl;
+          prevM = nm; prevD = ndl;
+          const uint32_t nib = sm | (si << 2) | (sd << 3);
+          if (b < 8) tbw0 |= nib << (4 * (b & 7)); else tbw1 |= nib << (4 * (b & 7));
+          if (endCol && valid && (local || i == xLen)) {
+            const double ev = nm + (GAPCTX ? trans[3 * Kg + gk] : c_m2e);
+            if (ev >= bestEnd) { bestEnd = ev; bestI = (uint32_t)i; }
+          }
+          if (b == 0) {
+            nM0 = nm; nI0 = ni;
+            // slot 0 of every lane is done: fetch lane l+1's (it is one column behind, i.e. column j-1)
+            upM = __shfl_down(nM0, 1, G); upI = __shfl_down(nI0, 1, G);
+            if (l == G - 1) { upM = QF_NEG_INF; upI = QF_NEG_INF; }
+          }
+        }
+        pubM = prevM; pubD = prevD;
+        if (colvalid) {
+          if (WPL == 1) tb[(uint64_t)t * G + l] = tbw0;
+          else { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
+        }
+      }
+    }
+  }
+  // end cell of the unit: max value, largest row on ties (lanes hold ascending rows)
+  for (int o = 1; o < G; o <<= 1) {
+    const double ov = __shfl_xor(bestEnd, o, G);
+    const uint32_t oi = __shfl_xor(bestI, o, G);
+    if (ov > bestEnd || (ov == bestEnd && oi > bestI)) { bestEnd = ov; bestI = oi; }
+  }
+  if (active && l == 0) {
+    a.units[uid].end_val = bestEnd;
+    a.units[uid].end_i = bestI;
+  }
+}
+
+// Single-diagonal units (the lone diagonal 0, wrong-strand pairs): no neighbours, so ins = del = -inf and
+// the match state is a serial chain.  One lane per unit, 8 traceback nibbles per word.
+__global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
+  const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0;
+  int d = 0, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, tb_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb);
+    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
+    d = u.dlo; tb_off = u.tb_off;
+  }
+  int T = active ? yLen : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ trans = a.dp.trans;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  uint32_t* __restrict__ tb = a.tb + tb_off;
+  double M = QF_NEG_INF, bestEnd = QF_NEG_INF;
+  uint32_t bestI = 0, word = 0, gkPrev = 0;
+  for (int j = 1; j <= T; ++j) {
+    const int i = d + j;
+    const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
+    const uint32_t w = ctx[j - 1];
+    const uint32_t gk = w >> 24;
+    const uint32_t tok = valid ? xt[i - 1] : 0u;
+    const double e = ematch[(w & 0x7FFFu) * 4u + tok];
+    const double tM = (M + trans[j <= 1 ? 0u : gkPrev]) + e;
+    gkPrev = gk;
+    double nm = tM;
+    uint32_t sm = 0;
+    if (j == 1 && (i == 1 || local) && e > nm) { nm = e; sm = 3; }
+    if (!valid) nm = QF_NEG_INF;
+    M = nm;
+    word |= sm << (4 * ((j - 1) & 7));
+    if (((j & 7) == 0 || j == yLen) && active && j <= yLen) { tb[(j - 1) >> 3] = word; word = 0; }
+    if (j == yLen && valid && (local || i == xLen)) { bestEnd = nm + trans[3 * Kg + gk]; bestI = (uint32_t)i; }
+  }
+  if (active) {
+    a.units[uid].end_val = bestEnd;
+    a.units[uid].end_i = bestI;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair-level result, best reference per read, traceback
+// ------------------------------------------------------------------------------------------------
+// result = max over the pair's bands; end cell = largest row among the maxima (the reference scans rows
+// downwards replacing only on strict '>', src/qmodel.cpp:1565-1575).
+__global__ void k_finalize_pairs(FinalArgs a) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n_pairs) return;
+  double best = QF_NEG_INF;
+  uint32_t bu = kNoUnit, bi = 0;
+  for (uint32_t uid = a.pair_head[p]; uid != kNoUnit; uid = a.units[uid].next) {
+    const double v = a.units[uid].end_val;
+    const uint32_t ei = a.units[uid].end_i;
+    if (v > best || (v == best && v > QF_NEG_INF && ei > bi)) { best = v; bu = uid; bi = ei; }
+  }
+  a.pair_score[p] = best;
+  a.pair_end_unit[p] = bu;
+}
+
+// QuaffAlignmentTask::run, src/qmodel.cpp:2764-2778: keep the best score-adjusted alignment per read,
+// the earlier reference on ties; or every finite one (-printall).
+__global__ void k_select(FinalArgs a) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n_reads) return;
+  const double nll = a.nll[r];
+  const uint32_t yLen = (uint32_t)(a.read_off[r + 1] - a.read_off[r]);
+  double bestAdj = QF_NEG_INF;
+  uint32_t bestX = kNoUnit;
+  for (uint32_t x = 0; x < a.n_refs; ++x) {
+    const uint32_t p = r * a.n_refs + x;
+    const double v = a.pair_score[p];
+    if (!(v > QF_NEG_INF)) continue;
+    const double adj = v - nll;
+    if (a.all) {
+      const Unit& u = a.units[a.pair_end_unit[p]];
+      const uint32_t cap = 2 * yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
+      const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
+      AlignRec rec{r, x, a.pair_end_unit[p], 0, v, adj, atomicAdd(&a.bc->n_runs, (unsigned long long)cap), 0, 0, 0, 0};
+      a.recs[idx] = rec;
+    } else if (bestX == kNoUnit || adj > bestAdj) {
+      bestAdj = adj;
+      bestX = x;
+    }
+  }
+  if (!a.all && bestX != kNoUnit) {
+    const uint32_t p = r * a.n_refs + bestX;
+    const Unit& u = a.units[a.pair_end_unit[p]];
+    const uint32_t cap = 2 * yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
+    const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
+    AlignRec rec{r, bestX, a.pair_end_unit[p], 0, a.pair_score[p], bestAdj,
+                 atomicAdd(&a.bc->n_runs, (unsigned long long)cap), 0, 0, 0, 0};
+    a.recs[idx] = rec;
+  }
+}
+
+// QuaffViterbiMatrix::alignment, src/qmodel.cpp:1576-1622, replayed from the packed traceback bits.
+// One thread per alignment; CIGAR runs are produced end-to-start, then written start-to-end.
+__global__ void k_traceback(FinalArgs a) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.n_recs) return;
+  AlignRec rec = a.recs[idx];
+  const Unit u = a.units[rec.unit];
+  const uint32_t yLen = (uint32_t)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+  const FillClass fc = fill_class((int)u.cls);
+  const uint32_t* __restrict__ tb = a.tb + u.tb_off;
+  auto nibble = [&](int i, int j) -> uint32_t {
+    if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0xFu;
+    const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
+    const uint64_t t = (uint64_t)(j - 1 + l);
+    const uint64_t w = fc.B > 8 ? (t * fc.G + l) * 2 + (b >> 3) : t * fc.G + l;
+    return (tb[w] >> (4 * (b & 7))) & 0xFu;
+  };
+  uint32_t* tmp = a.runs_tmp + rec.tmp_off;
+  int i = (int)u.end_i, j = (int)yLen;
+  const uint32_t xEnd = u.end_i;
+  uint32_t n = 0, ncol = 0, curOp = 3, curLen = 0;
+  int state = 1;  // 0 Start, 1 Match, 2 Insert, 3 Delete
+  while (state != 0 && i >= 0 && j >= 0 && (i > 0 || j > 0)) {
+    const uint32_t nib = (i >= 1 && j >= 1) ? nibble(i, j) : 0u;
+    uint32_t op;
+    if (state == 1) {
+      op = 0;
+      const uint32_t s = nib & 3u;
+      --i; --j;
+      state = s == 0 ? 1 : s == 1 ? 2 : s == 2 ? 3 : 0;
+    } else if (state == 2) {
+      op = 1;
+      --j;
+      state = (nib >> 2) & 1u ? 2 : 1;
+    } else {
+      op = 2;
+      --i;
+      state = (nib >> 3) & 1u ? 3 : 1;
+    }
+    ++ncol;
+    if (op == curOp) ++curLen;
+    else {
+      if (curLen) tmp[n++] = (curLen << 2) | curOp;
+      curOp = op; curLen = 1;
+    }
+  }
+  if (curLen) tmp[n++] = (curLen << 2) | curOp;
+  const unsigned long long off = atomicAdd(&a.bc->total_runs_out, (unsigned long long)n);
+  for (uint32_t c = 0; c < n; ++c) a.runs_out[off + c] = tmp[n - 1 - c];
+  rec.x_start = (uint32_t)(i + 1);
+  rec.x_end = xEnd;
+  rec.n_columns = ncol;
+  rec.n_runs = n;
+  rec.run_off = off;
+  rec.ok = state == 0;
+  a.recs[idx] = rec;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers (called from qf_api.cpp, which contains no device code)
+// ------------------------------------------------------------------------------------------------
+template <int G, int B>
+static void launch_fill_gb(const FillArgs& a, bool gapctx, hipStream_t s) {
+  const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
+  if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_viterbi_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s) {
+  if (a.n_cls_units == 0) return;
+  switch (cls) {
+    case 0: hipLaunchKernelGGL(k_viterbi_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a); break;
+    case 1: launch_fill_gb<16, 2>(a, gapctx, s); break;
+    case 2: launch_fill_gb<16, 3>(a, gapctx, s); break;
+    case 3: launch_fill_gb<16, 4>(a, gapctx, s); break;
+    case 4: launch_fill_gb<16, 5>(a, gapctx, s); break;
+    case 5: launch_fill_gb<16, 6>(a, gapctx, s); break;
+    case 6: launch_fill_gb<16, 8>(a, gapctx, s); break;
+    case 7: launch_fill_gb<64, 3>(a, gapctx, s); break;
+    case 8: launch_fill_gb<64, 4>(a, gapctx, s); break;
+    case 9: launch_fill_gb<64, 6>(a, gapctx, s); break;
+    case 10: launch_fill_gb<64, 8>(a, gapctx, s); break;
+    case 11: launch_fill_gb<64, 12>(a, gapctx, s); break;
+    case 12: launch_fill_gb<64, 16>(a, gapctx, s); break;
+  }
+}
+
+void launch_prep_ref(const char* seq, uint64_t total, uint8_t* tok, BatchCounters* bc, hipStream_t s) {
+  if (!total) return;
+  hipLaunchKernelGGL(k_prep_ref, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, seq, total, tok, bc);
+}
+void launch_pack_ref(const uint8_t* tok, const uint64_t* off, const uint64_t* woff, uint32_t n_refs, uint64_t max_len,
+                     uint32_t* packed, hipStream_t s) {
+  const uint64_t nw = (max_len + 15) / 16 + 2;
+  hipLaunchKernelGGL(k_pack_ref, dim3((uint32_t)((nw + 255) / 256), n_refs), dim3(256), 0, s, tok, off, woff, n_refs, packed);
+}
+void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, uint64_t max_len, uint32_t k,
+                      uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s) {
+  const dim3 grid((uint32_t)((max_len + 255) / 256), n_refs);
+  hipLaunchKernelGGL(k_ref_kmer_count, grid, dim3(256), 0, s, tok, off, k, nbuckets, starts);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(n_refs), dim3(1024), 0, s, starts, nbuckets);
+  hipLaunchKernelGGL(k_ref_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, starts, cursor, pos);
+}
+void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
+  if (n_reads) hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
+}
+size_t seed_lds_bytes(int max_nd, bool mem) {
+  const size_t hist = (size_t)((max_nd + 1) / 2) * 4;
+  return mem ? hist + (size_t)((max_nd + 3) & ~1) * 2 + (size_t)(max_nd + 4) * 2 : hist + (size_t)max_nd + 4;
+}
+int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
+  if (!n_pairs) return 0;
+  const size_t lds = seed_lds_bytes(a.max_nd, mem);
+  if (lds > 150 * 1024) return -1;
+  if (mem) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_seed<true>, dim3(n_pairs), dim3(256), lds, s, a);
+  } else {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_seed<false>, dim3(n_pairs), dim3(256), lds, s, a);
+  }
+  return 0;
+}
+void launch_finalize(const FinalArgs& a, hipStream_t s) {
+  if (a.n_pairs) hipLaunchKernelGGL(k_finalize_pairs, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_select(const FinalArgs& a, hipStream_t s) {
+  if (a.n_reads) hipLaunchKernelGGL(k_select, dim3((a.n_reads + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_traceback(const FinalArgs& a, hipStream_t s) {
+  if (a.n_recs) hipLaunchKernelGGL(k_traceback, dim3((a.n_recs + 63) / 64), dim3(64), 0, s, a);
+}
+
+}  // namespace qf

@@ -1,0 +1,101 @@
+// qf_kernels.hpp — argument blocks and launch entry points of the HIP kernels (qf_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "qf_device.hpp"
+
+namespace qf {
+
+constexpr int kNQualDev = 94;
+
+struct PrepArgs {
+  const char* seq;
+  const char* qual;        // NULL: no quality scores
+  const uint64_t* off;     // [n_reads+1]
+  uint32_t match_len, gap_len, seed_k;
+  uint8_t* tok;            // [total]
+  uint32_t* ctx;           // [total] (already offset past the front pad)
+  uint32_t* skmer;         // [total] seeding k-mer starting at each base
+  double* nll;             // [n_reads]
+  int has_null;
+  double null_logEmit, null_log1mEmit;
+  double null_logSym[4];
+  const double* null_logQual;  // [4][94]
+  BatchCounters* bc;
+};
+
+struct SeedArgs {
+  uint32_t pair_base, n_refs;
+  const uint64_t* ref_off;
+  const uint64_t* read_off;
+  const uint32_t* skmer;
+  const uint32_t* ref_bucket;  // [n_refs][nbuckets+1] exclusive starts
+  const uint32_t* ref_pos;     // [total ref bases] positions grouped by k-mer
+  uint32_t nbuckets;
+  int sparse, kmer_len, threshold, band;
+  unsigned long long cell_size, max_size;
+  int max_nd;
+  Unit* units;
+  uint32_t max_units;
+  uint32_t* cls_list;          // [kNumClasses][max_units]
+  uint32_t* pair_head;         // [n_pairs] (kNoUnit-initialised)
+  uint32_t* pair_ndiag;        // [n_pairs]
+  unsigned long long* pair_cells;  // [n_pairs] (zero-initialised)
+  uint8_t* dump_cover;         // optional [nd] membership of a single pair
+  BatchCounters* bc;
+};
+
+struct FillArgs {
+  uint32_t n_cls_units, n_refs;
+  const uint32_t* cls_list;    // this class's unit ids
+  Unit* units;
+  const uint64_t* ref_off;
+  const uint64_t* ref_woff;
+  const uint8_t* ref_tok;
+  const uint32_t* ref_packed;
+  const uint64_t* read_off;
+  const uint32_t* ctx;         // offset past the front pad
+  uint32_t* tb;
+  DpParams dp;
+};
+
+struct AlignRec {
+  uint32_t read, ref, unit, ok;
+  double viterbi, score;
+  unsigned long long tmp_off, run_off;
+  uint32_t x_start, x_end, n_columns, n_runs;
+};
+
+struct FinalArgs {
+  uint32_t n_pairs, n_reads, n_refs, n_recs;
+  int all;
+  Unit* units;
+  const uint32_t* pair_head;
+  double* pair_score;
+  uint32_t* pair_end_unit;
+  const double* nll;
+  const uint64_t* read_off;
+  AlignRec* recs;
+  const uint32_t* tb;
+  uint32_t* runs_tmp;
+  uint32_t* runs_out;
+  BatchCounters* bc;
+};
+
+void launch_prep_ref(const char* seq, uint64_t total, uint8_t* tok, BatchCounters* bc, hipStream_t s);
+void launch_pack_ref(const uint8_t* tok, const uint64_t* off, const uint64_t* woff, uint32_t n_refs, uint64_t max_len,
+                     uint32_t* packed, hipStream_t s);
+void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, uint64_t max_len, uint32_t k,
+                      uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s);
+void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s);
+size_t seed_lds_bytes(int max_nd, bool mem);
+int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
+void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s);
+void launch_finalize(const FinalArgs& a, hipStream_t s);
+void launch_select(const FinalArgs& a, hipStream_t s);
+void launch_traceback(const FinalArgs& a, hipStream_t s);
+
+}  // namespace qf

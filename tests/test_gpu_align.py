@@ -1,0 +1,238 @@
+"""GPU parity tests (run with -m gpu): the HIP path, called through the C ABI (quaff_amd.api is a
+ctypes shim), against the CPU oracle on the same seeded inputs.  Bit-exact for everything Viterbi:
+envelope diagonals, cell counts, scores (==, not approx), chosen reference, coordinates, CIGAR."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import rand_seq, make_reads, mutate, rand_qual
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+NULL_JSON = open(os.path.join(GOLDEN, "testquaffnullparams.json")).read()
+DEFAULT_JSON = open(os.path.join(GOLDEN, "defaultparams.json")).read()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import quaff_amd as Q
+    c = Q.Context(0)
+    c.set_params_json(None)
+    c.set_null_json(NULL_JSON)
+    yield c
+    c.close()
+
+
+def oracle_model(params_json=DEFAULT_JSON, null_json=NULL_JSON):
+    return O.Scores(O.Params.from_json(params_json)), O.NullParams.from_json(null_json)
+
+
+def both_strands(ref):
+    x = O.FastSeq("ref", ref)
+    return [x, x.revcomp()]
+
+
+def run_both(ctx, refs, reads, cfg_kw, sc, null, flags=0, quals=True):
+    import quaff_amd as Q
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads] if quals else None)
+    gcfg = Q.DPConfig(**cfg_kw)
+    res = ctx.align_resident(gcfg, flags)
+    ocfg = O.DPConfig(local=cfg_kw.get("local", True), sparse=cfg_kw.get("sparse", True), kmer_len=cfg_kw.get("kmer_len", 6),
+                      kmer_threshold=cfg_kw.get("kmer_threshold", 20), band=cfg_kw.get("band_size", 64),
+                      max_size=cfg_kw.get("max_size", 0))
+    return res, ocfg
+
+
+def check_against_oracle(ctx, refs, reads, cfg_kw, sc, null, quals=True, print_all=False):
+    res, ocfg = run_both(ctx, refs, reads, cfg_kw, sc, null, flags=1 if print_all else 0, quals=quals)
+    by_read = {}
+    for a in res["alignments"]:
+        by_read.setdefault(a["read"], []).append(a)
+    total = 0
+    for r, read in enumerate(reads):
+        rd = read if quals else O.FastSeq(read.name, read.seq, "")
+        rc = O.ReadCtx(rd, sc)
+        nll = null.loglike(rd)
+        assert res["null_loglike"][r] == nll, ("null loglike", r)
+        for x, ref in enumerate(refs):
+            xt = O.tokens(ref.seq)
+            d = O.envelope(xt, rc.tok, ocfg, 24)
+            assert res["n_diagonals"][r, x] == len(d), ("ndiag", r, x)
+            cells = O.envelope_cells(d, len(xt), len(rc.tok))
+            assert res["cells"][r, x] == cells, ("cells", r, x)
+            total += cells
+            v = O.viterbi(xt, rc, sc, d, ocfg.local, want_tb=False)
+            assert res["viterbi"][r, x] == v["result"], ("viterbi", r, x, res["viterbi"][r, x], v["result"])
+        kept = O.align_read(refs, rd, sc, null, ocfg, print_all=print_all)
+        got = by_read.get(r, [])
+        assert len(got) == len(kept), ("n alignments", r)
+        for g, k in zip(got, kept):
+            assert g["ref"] == k["ref"] and g["viterbi"] == k["raw"] and g["score"] == k["score"], (r, g, k)
+            assert (g["xStart"], g["xEnd"]) == (k["xStart"], k["xEnd"]), (r, g["xStart"], g["xEnd"], k["xStart"], k["xEnd"])
+            assert g["ops"] == k["ops"], ("cigar", r, g["cigar"], O.cigar(k["ops"]))
+    assert res["total_cells"] == total
+    return res
+
+
+def test_score_tables_match_oracle(ctx):
+    ml, gl, ins, mat, trans = ctx.get_scores()
+    sc, _ = oracle_model()
+    assert (ml, gl) == (1, 0)
+    assert np.array_equal(ins, sc.ins) and np.array_equal(mat, sc.mat) and np.array_equal(trans, sc.trans)
+    tab = np.ctypeslib.as_array(O.lib().qo_lse_table(), (100001,))
+    assert np.array_equal(ctx.lse_table(), tab)
+
+
+def test_envelopes_match_oracle(ctx):
+    import quaff_amd as Q
+    rng = np.random.default_rng(11)
+    ref = rand_seq(rng, 1500)
+    refs = both_strands(ref)
+    reads = make_reads(rng, ref, 6, 260)
+    reads.append(O.FastSeq("short", ref[40:80], rand_qual(rng, 40)))       # < 2(k+thr): full envelope
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    diag = lambda xl, yl: min(xl, yl)
+    cfgs = [dict(), dict(kmer_threshold=14), dict(kmer_len=5, band_size=16, kmer_threshold=3), dict(band_size=9, kmer_threshold=0),
+            dict(sparse=False)]
+    for nb in (0, 1, 30, 67, 68, 70, 140, 3000):
+        cfgs.append(dict(kmer_threshold=-1, max_size=nb * 260 * 24))
+    for kw in cfgs:
+        ocfg = O.DPConfig(sparse=kw.get("sparse", True), kmer_len=kw.get("kmer_len", 6), kmer_threshold=kw.get("kmer_threshold", 20),
+                          band=kw.get("band_size", 64), max_size=kw.get("max_size", 0))
+        for r, read in enumerate(reads):
+            for x, rf in enumerate(refs):
+                got = ctx.envelope(r, x, Q.DPConfig(**kw))
+                want = O.envelope(O.tokens(rf.seq), O.tokens(read.seq), ocfg, 24)
+                assert np.array_equal(got, want), (kw, r, x, len(got), len(want))
+
+
+def test_align_small_both_strands(ctx):
+    rng = np.random.default_rng(21)
+    ref = rand_seq(rng, 2000)
+    sc, null = oracle_model()
+    reads = make_reads(rng, ref, 24, 300)
+    res = check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
+    assert len(res["alignments"]) == 24
+    # the true strand wins and its band is a multi-diagonal one
+    assert all(a["ref"] == (a["read"] & 1) for a in res["alignments"])
+    assert res["n_diagonals"].max() > 65
+
+
+def test_align_ragged_lengths_and_bands(ctx):
+    """ragged read lengths (1 .. 900), narrow and odd bands, low thresholds -> several (G,B) classes."""
+    rng = np.random.default_rng(22)
+    ref = rand_seq(rng, 3000)
+    sc, null = oracle_model()
+    reads = []
+    for n, L in enumerate((1, 2, 5, 7, 51, 52, 60, 97, 128, 333, 600, 900)):
+        s = int(rng.integers(0, len(ref) - L))
+        seq = mutate(rng, ref[s:s + L]) or "A"
+        reads.append(O.FastSeq("r%d" % n, seq, rand_qual(rng, len(seq))))
+    refs = [O.FastSeq("ref", ref)]
+    for kw in (dict(band_size=20, kmer_threshold=8), dict(band_size=33, kmer_threshold=5), dict(band_size=100, kmer_threshold=10),
+               dict(band_size=4, kmer_threshold=2, kmer_len=5)):
+        # reads shorter than 2(k+thr) fall back to the full envelope (ref+read-1 diagonals), which the
+        # diagonal-space kernels only take up to 1024 diagonals: keep those out of this test
+        minlen = 2 * (kw.get("kmer_len", 6) + kw["kmer_threshold"])
+        sub = [r for r in reads if len(r.seq) >= minlen]
+        check_against_oracle(ctx, refs, sub, kw, sc, null)
+
+
+def test_align_global_noquals_printall(ctx):
+    rng = np.random.default_rng(23)
+    ref = rand_seq(rng, 700)
+    sc, null = oracle_model()
+    # global: reads spanning (almost) the whole reference
+    reads = [O.FastSeq("g%d" % n, s, rand_qual(rng, len(s))) for n, s in enumerate(mutate(rng, ref) for _ in range(6))]
+    check_against_oracle(ctx, [O.FastSeq("ref", ref)], reads, dict(local=False), sc, null)
+    reads = make_reads(rng, ref, 8, 200)
+    check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null, quals=False)
+    check_against_oracle(ctx, both_strands(ref), reads, dict(kmer_threshold=4), sc, null, print_all=True)
+
+
+def test_align_repeat_two_bands(ctx):
+    rng = np.random.default_rng(24)
+    unit = rand_seq(rng, 220)
+    ref = rand_seq(rng, 300) + unit + rand_seq(rng, 500) + unit + rand_seq(rng, 200)
+    sc, null = oracle_model()
+    reads = [O.FastSeq("rep%d" % n, s, rand_qual(rng, len(s))) for n, s in
+             enumerate(mutate(rng, unit, sub=0.02, ins=0.01, dele=0.01) for _ in range(5))]
+    res = check_against_oracle(ctx, [O.FastSeq("ref", ref)], reads, dict(kmer_threshold=12, band_size=32), sc, null)
+    assert res["n_units"] >= 3 * 5 - 2
+
+
+def synth_params_json(rng, match_len, gap_len):
+    """random but valid parameter set of a given order (train -order k writes matchOrder k+1, gapOrder k)."""
+    def sqd(p):
+        return '{ "p": %.6g, "q": %.6g, "r": %.6g, "m": 1, "sd": 1 }' % (p, rng.uniform(.55, .95), rng.uniform(8, 90))
+    Km, Kg = 4 ** match_len, 4 ** gap_len
+    o = '{\n  "matchOrder": %d,\n  "gapOrder": %d,\n  "refBase": { "A": 0.25, "C": 0.25, "G": 0.25, "T": 0.25 },\n' % (match_len, gap_len)
+    for name in ("beginInsert", "beginDelete"):
+        o += '  "%s": {%s },\n' % (name, ",".join(' "%s": %.6g' % (O.kmer_string(g, gap_len), rng.uniform(.01, .08)) for g in range(Kg)))
+    o += '  "extendInsert": 0.55,\n  "extendDelete": 0.6,\n  "insert": {\n'
+    o += ",\n".join('    "%s": %s' % ("ACGT"[i], sqd(.25)) for i in range(4)) + " },\n"
+    o += '  "match": {\n'
+    blocks = []
+    for jp in range(0, Km, 4):
+        rows = []
+        for i in range(4):
+            ps = rng.dirichlet([1, 1, 1, 1]) * 0.1
+            ps[i] += 0.9
+            rows.append('    "%s": {\n%s }' % ("ACGT"[i], ",\n".join('      "%s": %s' % ("ACGT"[js], sqd(ps[js])) for js in range(4))))
+        blocks.append('   "%s": {\n%s }' % (O.kmer_string(jp, match_len)[:match_len - 1], ",\n".join(rows)))
+    return o + ",\n".join(blocks) + " } }\n"
+
+
+def test_align_order2_contexts(ctx):
+    """-order 2 style parameters (match context 3, gap context 2): exercises context k-mers + GAPCTX kernels."""
+    rng = np.random.default_rng(25)
+    pj = synth_params_json(rng, 3, 2)
+    sc = O.Scores(O.Params.from_json(pj))
+    null = O.NullParams.from_json(NULL_JSON)
+    ctx.set_params_json(pj)
+    try:
+        ml, gl, ins, mat, trans = ctx.get_scores()
+        assert (ml, gl) == (3, 2) and np.array_equal(mat, sc.mat) and np.array_equal(trans, sc.trans)
+        ref = rand_seq(rng, 1200)
+        reads = make_reads(rng, ref, 10, 250)
+        check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
+    finally:
+        ctx.set_params_json(None)
+
+
+def test_c8f30_golden_through_gpu(ctx):
+    """The reference's own integration golden (Makefile:149-150), with the HIP path doing the DP."""
+    import quaff_amd as Q
+    reads = O.read_fastx(os.path.join(GOLDEN, "c8f30.fastq.gz"))
+    null = O.NullParams.fit(reads)
+    ctx.set_null_json(null.to_json())
+    try:
+        ctx.set_refs([reads[0].seq])
+        ctx.upload_reads([reads[0].seq], [reads[0].qual])
+        res = ctx.align_resident(Q.DPConfig(kmer_threshold=-1, max_size=10 << 20))
+        a = res["alignments"][0]
+        assert res["n_diagonals"][0, 0] == 1 and a["cigar"] == "M6604"
+        assert O.fmt(a["viterbi"]) == "-18710.3"
+        # the null model round-trips through 6-s.f. JSON here, so compare the formatted score only
+        al = dict(a, score=a["viterbi"] - null.loglike(reads[0]))
+        assert O.stockholm(reads[0], reads[0], al) == open(os.path.join(GOLDEN, "c8f30-self-align.json")).read()
+        res = ctx.align_resident(Q.DPConfig())           # default seeding: 65 diagonals, still M6604
+        assert res["n_diagonals"][0, 0] == 65 and res["alignments"][0]["cigar"] == "M6604"
+    finally:
+        ctx.set_null_json(NULL_JSON)
+
+
+def test_bad_symbol_and_errors(ctx):
+    import quaff_amd as Q
+    ctx.set_refs(["ACGTACGTACGTACGTACGTAAACCCGGGTTT" * 4])
+    ctx.upload_reads(["ACGTNACGT" * 8])
+    with pytest.raises(Q.QuaffHipError) as e:
+        ctx.align_resident()
+    assert e.value.code == -4
+    with pytest.raises(Q.QuaffHipError):
+        ctx.set_refs(["ACGTXX"])
