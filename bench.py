@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config 2:
+
+    banded Viterbi align, 1 synthetic 10 kb reference (+ its reverse complement) x 100 k synthetic
+    1 kb reads, -kmatchband 64 (k=6, threshold 20), DP cells/s.
+
+A "step" is one pass of the whole hot path (read prep, k-mer seeding, banded Viterbi fill, best
+reference per read, traceback to CIGAR runs, results copied to the host) over one batch of reads that
+is already resident in HBM.  Weak scaling: every rank owns its own --reads reads (different seeds) and
+one GPU; there is no data-path collective (read x reference pairs are independent), torch.distributed is
+used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof with the
+reference's algorithmic 24 B/cell; `cpu_baseline` times the oracle (a bit-exact CPU port
+of the reference algorithm, oracle/) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_CELL = 24.0        # 3 fp64 states per DP cell
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 2: 100000)")
+    ap.add_argument("--read-len", type=int, default=1000)
+    ap.add_argument("--ref-len", type=int, default=10000)
+    ap.add_argument("--band", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    return ap.parse_args()
+
+
+def cpu_baseline(ref, seq, qual, off, n_sample, threads, band, gpu_res):
+    """Oracle (oracle/, kind "port") on the first n_sample reads, one read per task on a thread pool —
+    the reference's execution model (runQuaffAlignmentTasks, src/qmodel.cpp:2870-2882).  Also checks the
+    GPU's alignments for those reads bit-for-bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    golden = os.path.join(ROOT, "tests", "golden")
+    sc = O.Scores(O.Params.from_json(open(os.path.join(golden, "defaultparams.json")).read()))
+    null = O.NullParams.from_json(open(os.path.join(golden, "testquaffnullparams.json")).read())
+    x = O.FastSeq("ref", ref.decode())
+    refs = [x, x.revcomp()]
+    cfg = O.DPConfig(band=band)
+    reads = [O.FastSeq("read%d" % n, seq[int(off[n]):int(off[n + 1])].decode(), qual[int(off[n]):int(off[n + 1])].decode())
+             for n in range(n_sample)]
+    O.lib()
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        out = list(ex.map(lambda r: O.align_read(refs, r, sc, null, cfg), reads))
+    dt = time.time() - t0
+    cells = 0
+    mismatches = 0
+    for n, kept in enumerate(out):
+        for xi in range(2):
+            cells += int(gpu_res["cells"][n, xi])
+        g = gpu_res["by_read"].get(n)
+        if not kept:
+            mismatches += g is not None
+            continue
+        k = kept[0]
+        if g is None or (g["ref"], g["viterbi"], g["xStart"], g["xEnd"], g["cigar"]) != \
+                (k["ref"], k["raw"], k["xStart"], k["xEnd"], O.cigar(k["ops"])):
+            mismatches += 1
+    return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
+            "sample": "first %d of the rank-0 reads x 2 strands (%d cells), oracle/quaff_oracle.c, %d threads, one read per task"
+                      % (n_sample, cells, threads),
+            "seconds": round(dt, 3), "gpu_parity_mismatches": mismatches}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl")   # nccl == RCCL on ROCm
+        dist = dist_mod
+    import numpy as np
+    import quaff_amd as Q
+    from quaff_amd import api
+
+    ctx = Q.Context(local_rank)
+    ctx.set_params_json(None)
+    ctx.set_null_json(open(os.path.join(ROOT, "tests", "golden", "testquaffnullparams.json")).read())
+    ref = api.synth_ref(1, a.ref_len)
+    ctx.set_refs([ref, api.revcomp(ref)])
+    seq, qual, off = api.synth_reads(2 + rank, ref, a.reads, a.read_len)
+    ctx.upload_reads_packed(seq, qual, off)          # resident in HBM before the timed region
+    cfg = Q.DPConfig(band_size=a.band)
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ctx.align_resident(cfg, 0, raw=True)
+    sync_all()
+    t0 = time.perf_counter()
+    cls_ms, cls_cells, cls_names = {}, {}, {}
+    phases = {"prep": 0.0, "seed": 0.0, "fill": 0.0, "traceback": 0.0, "total": 0.0}
+    total_cells = 0
+    for _ in range(a.steps):
+        res = ctx.align_resident(cfg, 0, raw=True)   # synchronous: returns after results are on the host
+        total_cells += int(res.total_cells)
+        for k in range(res.n_fill_classes):
+            if res.units_class[k]:
+                cls_ms[k] = cls_ms.get(k, 0.0) + res.ms_fill_class[k]
+                cls_cells[k] = int(res.cells_class[k])
+        for p in phases:
+            phases[p] += getattr(res, "ms_" + p)
+        tb_bytes, n_units, n_align = int(res.traceback_bytes), int(res.n_units), int(res.n_alignments)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([total_cells], device="cuda", dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_cells = int(c.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    dom = max(cls_ms, key=lambda k: cls_ms[k])
+    dom_ms = cls_ms[dom] / a.steps
+    dom_name = ctx.L.qf_fill_class_name(dom).decode()
+    achieved = BYTES_PER_CELL * cls_cells[dom] / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("kernel") == dom_name and tj.get("reads") == a.reads and tj.get("read_len") == a.read_len:
+            traffic = tj.get("hbm_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "cells_per_launch": cls_cells[dom], "bytes_per_cell": BYTES_PER_CELL, "ms_per_launch": round(dom_ms, 4)}
+
+    cpu = None
+    if a.cpu_sample > 0:
+        n_s = min(a.cpu_sample, a.reads)
+        full = ctx.align_resident(cfg, 0, reads_below=n_s)   # unpacked view of the same batch for the parity check
+        full["by_read"] = {al["read"]: al for al in full["alignments"]}
+        threads = a.cpu_threads or (os.cpu_count() or 1)
+        cpu = cpu_baseline(ref, seq, qual, off, n_s, threads, a.band, full)
+
+    out = {
+        "metric": "DP cells/sec (banded Viterbi)", "value": total_cells / dt, "unit": "DP cells/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: quaff align, 1 x %d bp ref (+revcomp) x %d x %d bp reads per GPU, "
+                               "-kmatchband %d, k=6, threshold 20, local, best alignment per read + CIGAR"
+                               % (a.ref_len, a.reads, a.read_len, a.band),
+                   "reads_per_gpu": a.reads, "pairs_per_gpu": 2 * a.reads, "cells_per_step_per_gpu": total_cells // (a.steps * world),
+                   "bands": n_units, "alignments": n_align, "traceback_bytes": tb_bytes,
+                   "phase_ms": {k: round(v / a.steps, 3) for k, v in phases.items()},
+                   "fill_kernels": {ctx.L.qf_fill_class_name(k).decode(): {"ms": round(cls_ms[k] / a.steps, 4), "cells": cls_cells[k]}
+                                    for k in sorted(cls_ms)}},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

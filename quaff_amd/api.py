@@ -137,6 +137,15 @@ def synth_reads(seed, ref, n_reads, read_len):
     return seq.raw[:tot], qual.raw[:tot], off
 
 
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCATGCA")
+
+
+def revcomp(seq):
+    """Reverse complement (revcomp(), src/fastseq.cpp:209-216) of bytes/str."""
+    b = seq.encode() if isinstance(seq, str) else seq
+    return b.translate(_COMP)[::-1]
+
+
 def pack(seqs):
     """list of str/bytes -> (concatenated bytes, offsets)."""
     bs = [s.encode() if isinstance(s, str) else s for s in seqs]
@@ -206,13 +215,13 @@ class Context:
         q = pack(quals)[0] if quals is not None else None
         self.upload_reads_packed(data, q, off)
 
-    def align_resident(self, cfg=None, flags=ALIGN_BEST, raw=False):
+    def align_resident(self, cfg=None, flags=ALIGN_BEST, raw=False, reads_below=None):
         cfg = cfg or DPConfig()
         res = _AlignResult()
         self._chk(self.L.qf_align_resident(self.h, C.byref(cfg), flags, C.byref(res)))
-        return res if raw else self._unpack(res)
+        return res if raw else self._unpack(res, reads_below)
 
-    def _unpack(self, res):
+    def _unpack(self, res, reads_below=None):
         n = res.n_reads * res.n_refs
         shape = (res.n_reads, res.n_refs)
         out = {
@@ -229,6 +238,8 @@ class Context:
         }
         for a in range(res.n_alignments):
             al = res.alignments[a]
+            if reads_below is not None and al.read >= reads_below:
+                continue
             runs = np.ctypeslib.as_array(C.cast(C.addressof(res.cigar_runs.contents) + 4 * al.run_offset,
                                                 C.POINTER(C.c_uint32)), (al.n_runs,)).copy() if al.n_runs else np.zeros(0, np.uint32)
             out["alignments"].append({
