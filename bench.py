@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--band", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = this process's CPU share (at most 16)")
     return ap.parse_args()
 
 
@@ -162,7 +162,8 @@ def main():
         n_s = min(a.cpu_sample, a.reads)
         full = ctx.align_resident(cfg, 0, reads_below=n_s)   # unpacked view of the same batch for the parity check
         full["by_read"] = {al["read"]: al for al in full["alignments"]}
-        threads = a.cpu_threads or (os.cpu_count() or 1)
+        # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe beyond the affinity mask
+        threads = a.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         cpu = cpu_baseline(ref, seq, qual, off, n_s, threads, a.band, full)
 
     out = {
