@@ -1,0 +1,98 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/quaff_hip.h declares,
+its host-only entry points (score tables from quaff's params JSON, CIGAR text, the synthetic generator)
+agree with the oracle, and it refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    import quaff_amd
+    from quaff_amd import api as A
+    if not os.path.exists(A.library_path()):
+        quaff_amd.build_library()
+    return A
+
+
+def test_exports_every_declared_symbol(api):
+    hdr = open(os.path.join(ROOT, "include", "quaff_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(qf_[a-z0-9_]+)\s*\(", body)))
+    assert len(declared) >= 15
+    L = api.load_library()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(api.EXPORTS) == declared
+
+
+def test_no_cpu_fallback(api):
+    import quaff_amd as Q
+    L = api.load_library()
+    h = C.c_void_p()
+    rc = L.qf_ctx_create(0, C.byref(h))
+    if rc == 0:          # a GPU is present: nothing to check here
+        L.qf_ctx_destroy(h)
+        pytest.skip("GPU present")
+    assert rc == -1 and b"no HIP device" in L.qf_last_error(None)
+    with pytest.raises(Q.QuaffHipError):
+        Q.Context(0)
+
+
+@pytest.mark.parametrize("name", ["defaultparams.json", "testquaffparams.json"])
+def test_score_tables_bit_equal_to_oracle(api, golden, name):
+    text = open(os.path.join(golden, name)).read()
+    ml, gl, ins, mat, trans = api.scores_from_json(text)
+    sc = O.Scores(O.Params.from_json(text))
+    assert (ml, gl) == (sc.match_len, sc.gap_len)
+    assert np.array_equal(ins, sc.ins) and np.array_equal(mat, sc.mat) and np.array_equal(trans, sc.trans)
+
+
+def test_builtin_defaults_are_the_reference_defaults(api, golden):
+    a = api.scores_from_json(None)
+    b = api.scores_from_json(open(os.path.join(golden, "defaultparams.json")).read())
+    assert all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:]))
+
+
+def test_params_errors(api):
+    import quaff_amd as Q
+    with pytest.raises(Q.QuaffHipError) as e:
+        api.scores_from_json('{ "beginInsert": { "": 0.1 } }')
+    assert e.value.code == -3 and "Missing parameter" in str(e.value)
+    with pytest.raises(Q.QuaffHipError):
+        api.scores_from_json("{ not json")
+
+
+def test_cigar_string_letter_first(api):
+    runs = np.array([(14 << 2) | 0, (1 << 2) | 1, (11 << 2) | 0, (2 << 2) | 2], np.uint32)
+    buf = C.create_string_buffer(64)
+    n = api.load_library().qf_cigar_string(runs.ctypes.data, len(runs), buf, 64)
+    assert buf.value == b"M14I1M11D2" and n == 10        # Alignment::cigarString, src/qmodel.cpp:625-653
+    assert O.cigar("M" * 14 + "I" + "M" * 11 + "DD") == "M14I1M11D2"
+
+
+def test_synthetic_generator(api):
+    ref = api.synth_ref(1, 5000)
+    assert ref == api.synth_ref(1, 5000) and ref != api.synth_ref(2, 5000)
+    assert set(ref) <= set(b"ACGT") and min(ref.count(c) for c in b"ACGT") > 1000
+    seq, qual, off = api.synth_reads(2, ref, 200, 400)
+    seq2, qual2, off2 = api.synth_reads(2, ref, 200, 400)
+    assert seq == seq2 and qual == qual2 and np.array_equal(off, off2)
+    lens = np.diff(off).astype(int)
+    assert len(seq) == len(qual) == int(off[-1]) and 330 < lens.mean() < 430 and lens.min() > 300
+    assert min(qual) >= 33 + 5 and max(qual) <= 33 + 25
+    # even reads come from the forward strand, odd ones from the reverse: check by seeding
+    sc_cfg = O.DPConfig()
+    xt, xr = O.tokens(ref.decode()), O.tokens(O.revcomp_str(ref.decode()))
+    for n in (0, 1, 2, 3):
+        y = O.tokens(seq[int(off[n]):int(off[n + 1])].decode())
+        nf, nr = len(O.envelope(xt, y, sc_cfg)), len(O.envelope(xr, y, sc_cfg))
+        assert (nf > 60 and nr == 1) if n % 2 == 0 else (nr > 60 and nf == 1)
+    assert api.revcomp(b"AACGT") == b"ACGTT"
