@@ -34,8 +34,8 @@ class DPConfig(C.Structure):
     _fields_ = [("local", C.c_int32), ("sparse", C.c_int32), ("kmer_len", C.c_int32), ("kmer_threshold", C.c_int32),
                 ("band_size", C.c_int32), ("reserved", C.c_int32), ("max_size", C.c_uint64)]
 
-    def __init__(self, local=True, sparse=True, kmer_len=6, kmer_threshold=20, band_size=64, max_size=0):
-        super().__init__(int(local), int(sparse), kmer_len, kmer_threshold, band_size, 0, max_size)
+    def __init__(self, local=True, sparse=True, kmer_len=6, kmer_threshold=20, band_size=64, max_size=0, debug_flags=0):
+        super().__init__(int(local), int(sparse), kmer_len, kmer_threshold, band_size, debug_flags, max_size)
 
 
 class _Alignment(C.Structure):

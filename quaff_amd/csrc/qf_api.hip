@@ -71,7 +71,7 @@ struct qf_ctx {
   bool reads_have_qual = false;
   DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll;
   // batch state
-  DevBuf d_units, d_cls_list, d_pair_head, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
+  DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
       d_recs, d_runs_tmp, d_runs_out, d_cover;
   // host results
   std::vector<double> h_viterbi, h_nll;
@@ -136,7 +136,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
                     &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_units, &c->d_cls_list,
-                    &c->d_pair_head, &c->d_pair_ndiag, &c->d_pair_cells, &c->d_pair_score, &c->d_pair_end_unit,
+                    &c->d_pair_head, &c->d_pair_bands, &c->d_pair_nbands, &c->d_ovf, &c->d_pair_ndiag, &c->d_pair_cells, &c->d_pair_score, &c->d_pair_end_unit,
                     &c->d_bc, &c->d_tb, &c->d_recs, &c->d_runs_tmp, &c->d_runs_out, &c->d_cover})
     b->release();
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -403,8 +403,13 @@ static void fill_seed_args(qf_ctx* c, const qf_dp_config* cfg, SeedArgs& s, uint
   s.max_units = max_units;
   s.cls_list = c->d_cls_list.as<uint32_t>();
   s.pair_head = c->d_pair_head.as<uint32_t>();
+  s.pair_bands = c->d_pair_bands.as<int2>();
+  s.pair_nbands = c->d_pair_nbands.as<uint32_t>();
+  s.ovf_bands = c->d_ovf.as<int4>();
+  s.ovf_cap = max_units;
   s.pair_ndiag = c->d_pair_ndiag.as<uint32_t>();
   s.pair_cells = c->d_pair_cells.as<unsigned long long>();
+  s.force_block_kernel = cfg->reserved & 1;  // debug/testing: workgroup-per-pair seeding kernel
   s.bc = c->d_bc.as<BatchCounters>();
 }
 
@@ -412,6 +417,10 @@ static int reserve_pair_buffers(qf_ctx* c, uint64_t n_pairs, uint32_t max_units)
   HIPCHK(c, c->d_units.reserve((size_t)max_units * sizeof(Unit)));
   HIPCHK(c, c->d_cls_list.reserve((size_t)kNumClasses * max_units * 4));
   HIPCHK(c, c->d_pair_head.reserve(n_pairs * 4));
+  HIPCHK(c, c->d_pair_bands.reserve(n_pairs * kMaxBandsPerPair * sizeof(int2)));
+  HIPCHK(c, c->d_pair_nbands.reserve(n_pairs * 4));
+  HIPCHK(c, c->d_ovf.reserve((size_t)max_units * sizeof(int4)));
+  HIPCHK(c, hipMemsetAsync(c->d_pair_nbands.p, 0, n_pairs * 4, c->stream));
   HIPCHK(c, c->d_pair_ndiag.reserve(n_pairs * 4));
   HIPCHK(c, c->d_pair_cells.reserve(n_pairs * 8));
   HIPCHK(c, c->d_pair_score.reserve(n_pairs * 8));
@@ -452,14 +461,23 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
     return fail(c, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
                                            " exceeds the LDS diagonal histogram (global-memory histogram not built yet)");
+  launch_bin_units(sa, n_pairs, 0, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   BatchCounters bc;
   if (int rc = read_counters(c, bc)) return rc;
+  if (bc.n_ovf && !(bc.error & 8u)) {  // pairs with more than kMaxBandsPerPair bands: second binning pass
+    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (int rc = read_counters(c, bc)) return rc;
+  }
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u)
     return fail(c, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels (" +
                                            std::to_string(kMaxBandDiagSpace) + "); the row-space full-DP kernel is not built yet");
+  if (bc.error & 8u)
+    return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
   if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
 
   // ---- fill

@@ -8,6 +8,7 @@ namespace qf {
 
 constexpr int kMaxRefK = 8;        // direct-addressed k-mer index up to 4^8 buckets per sequence
 constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
+constexpr int kMaxBandsPerPair = 8;  // disjoint diagonal runs recorded per (read, ref) pair
 constexpr int kCtxPad = 128;       // junk words before/after the per-column context array
 
 // Packed per-column read context word (one per read base), built by the prep kernel:
@@ -56,8 +57,9 @@ __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
 
 struct BatchCounters {
   uint32_t n_units;
+  uint32_t n_ovf;           // bands spilled past kMaxBandsPerPair
   uint32_t cls_count[kNumClasses];
-  uint32_t error;          // bit 0: unit overflow, bit 1: band too wide, bit 2: bad symbol
+  uint32_t error;          // bit 0: unit overflow, 1: band too wide, 2: bad symbol, 3: > kMaxBandsPerPair bands
   uint32_t error_detail;
   unsigned long long tb_words;
   unsigned long long total_cells;

@@ -147,21 +147,28 @@ __global__ __launch_bounds__(64) void k_prep_reads(PrepArgs a) {
       a.skmer[b + i] = sk;
     }
   }
-  if (lane == 0) {
-    double ll = 0;
-    if (a.has_null) {
-      ll = (double)L * a.null_logEmit + a.null_log1mEmit;
-      for (uint32_t i = 0; i < L; ++i) {
-        const uint32_t t = tokAt(i);
-        ll += a.null_logSym[t];
-        if (a.qual) {
-          int v = (int)(signed char)a.qual[b + i] - '!';
-          ll += a.null_logQual[t * kNQualDev + max(0, min(kNQualDev - 1, v))];
-        }
+}
+
+// Null-model log-likelihood (QuaffNullParams::logLikelihood, src/qmodel.cpp:1875-1890): a strictly
+// sequential fp64 sum per read, so one LANE per read (64 reads per wavefront) rather than one wave.
+__global__ __launch_bounds__(64) void k_null_ll(PrepArgs a, uint32_t n_reads) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  double ll = 0;
+  if (a.has_null) {
+    const uint64_t b = a.off[r];
+    const uint32_t L = (uint32_t)(a.off[r + 1] - b);
+    ll = (double)L * a.null_logEmit + a.null_log1mEmit;
+    for (uint32_t i = 0; i < L; ++i) {
+      const uint32_t t = a.tok[b + i];
+      ll += a.null_logSym[t];
+      if (a.qual) {
+        const int v = (int)(signed char)a.qual[b + i] - '!';
+        ll += a.null_logQual[t * kNQualDev + max(0, min(kNQualDev - 1, v))];
       }
     }
-    a.nll[r] = ll;
   }
+  a.nll[r] = ll;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -176,31 +183,19 @@ __device__ __forceinline__ unsigned long long band_cells(int dlo, int dhi, int x
   return c;
 }
 
-__device__ int emit_unit(const SeedArgs& a, uint32_t pair, int dlo, int dhi, int xLen, int yLen) {
-  const int cls = classify_width(dhi - dlo + 1);
-  if (cls < 0) {
-    atomicOr(&a.bc->error, 2u);
-    a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
-    return -1;
+// Seeding records each band of a pair in a fixed per-pair slot (an uncontended per-pair counter);
+// k_bin_units then classifies the bands and allocates unit ids, class-list slots and traceback space with
+// workgroup-aggregated atomics.  (Allocating straight from the seeding kernel put ~10^6 returning atomics
+// on three words: 10 ms at config 2.)
+__device__ __forceinline__ void record_band(const SeedArgs& a, uint32_t pair, int dlo, int dhi) {
+  const uint32_t slot = atomicAdd(&a.pair_nbands[pair], 1u);
+  if (slot < (uint32_t)kMaxBandsPerPair) {
+    a.pair_bands[(uint64_t)pair * kMaxBandsPerPair + slot] = make_int2(dlo, dhi);
+  } else {  // rare (very low thresholds / narrow bands): spill to the overflow list
+    const uint32_t o = atomicAdd(&a.bc->n_ovf, 1u);
+    if (o < a.ovf_cap) a.ovf_bands[o] = make_int4((int)pair, dlo, dhi, 0);
+    else atomicOr(&a.bc->error, 8u);
   }
-  const uint32_t uid = atomicAdd(&a.bc->n_units, 1u);
-  if (uid >= a.max_units) {
-    atomicOr(&a.bc->error, 1u);
-    return -1;
-  }
-  const uint32_t slot = atomicAdd(&a.bc->cls_count[cls], 1u);
-  a.cls_list[(uint64_t)cls * a.max_units + slot] = uid;
-  Unit u;
-  u.pair = pair;
-  u.dlo = dlo;
-  u.dhi = dhi;
-  u.tb_off = atomicAdd(&a.bc->tb_words, (unsigned long long)unit_tb_words(cls, (uint32_t)yLen));
-  u.end_val = QF_NEG_INF;
-  u.end_i = 0;
-  u.cls = (uint32_t)cls;
-  u.next = atomicExch(&a.pair_head[pair], uid);
-  a.units[uid] = u;
-  return cls;
 }
 
 // One 256-thread workgroup per (read, ref) pair.  LDS: a dense histogram of k-mer matches per diagonal
@@ -222,12 +217,8 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
   }
   if (full) {  // initFull, diagenv.cpp:11-18
     if (tid == 0) {
-      const int cls = emit_unit(a, pair, minD, maxD, xLen, yLen);
-      const unsigned long long cells = (unsigned long long)xLen * (unsigned long long)yLen;
+      record_band(a, pair, minD, maxD);
       a.pair_ndiag[pair] = (uint32_t)nd;
-      a.pair_cells[pair] = cells;
-      atomicAdd(&a.bc->total_cells, cells);
-      if (cls >= 0) atomicAdd(&a.bc->cls_cells[cls], cells);
     }
     if (a.dump_cover)
       for (int b = tid; b < nd; b += 256) a.dump_cover[b] = 1;
@@ -336,7 +327,6 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
 
   // contiguous runs -> units; diagonal and cell counts
   uint32_t nmem = 0;
-  unsigned long long cells = 0;
   for (int b = tid; b < nd; b += 256) {
     const bool in = member(b);
     nmem += in;
@@ -344,23 +334,231 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
     if (in && (b == 0 || !member(b - 1))) {
       int e = b;
       while (e + 1 < nd && member(e + 1)) ++e;
-      const int cls = emit_unit(a, pair, b + minD, e + minD, xLen, yLen);
-      const unsigned long long bcells = band_cells(b + minD, e + minD, xLen, yLen);
-      cells += bcells;
-      if (cls >= 0) atomicAdd(&a.bc->cls_cells[cls], bcells);
+      record_band(a, pair, b + minD, e + minD);
     }
   }
   s_red[tid] = nmem;
   __syncthreads();
   for (int o = 128; o; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
   if (tid == 0) a.pair_ndiag[pair] = s_red[0];
-  if (cells) {
-    atomicAdd(&a.pair_cells[pair], cells);
-    atomicAdd(&a.bc->total_cells, cells);
-  }
 }
 template __global__ void k_seed<false>(SeedArgs);
 template __global__ void k_seed<true>(SeedArgs);
+
+// Threshold-mode seeding, one WAVEFRONT per (read, ref) pair (the common case: `quaff align/overlap/train`
+// defaults).  Same semantics as k_seed<false>; restructured for memory-level parallelism: no workgroup
+// barriers, the read's k-mers and the reference bucket ranges are fetched as batches of independent loads,
+// bucket entries four at a time, the threshold scan reads eight 16-bit counters per lane per LDS read, and
+// envelope membership is a bitmap (atomicOr of band masks, run detection by bit tricks).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+struct __attribute__((packed, aligned(4))) U32x4u { uint32_t v[4]; };
+
+__global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + wv;
+  if (pidx >= n_pairs) return;
+  const uint32_t pair = a.pair_base + pidx;
+  const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
+  const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
+  const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
+  const int minD = 1 - yLen, maxD = xLen - 1, nd = xLen + yLen - 1;
+  const int k = a.kmer_len;
+  const uint32_t minLen = 2u * (uint32_t)(k + a.threshold);
+  if ((uint32_t)xLen < minLen || (uint32_t)yLen < minLen) {  // diagenv.cpp:23-29 -> initFull
+    if (lane == 0) {
+      record_band(a, pair, minD, maxD);
+      a.pair_ndiag[pair] = (uint32_t)nd;
+    }
+    if (a.dump_cover)
+      for (int b = lane; b < nd; b += 64) a.dump_cover[b] = 1;
+    return;
+  }
+  uint32_t* hist = lds + (size_t)wv * wave_lds_words;   // two 16-bit counters per dword
+  const int histWords = (nd + 1) / 2, histWords4 = (histWords + 3) & ~3;
+  uint32_t* bm = hist + (((a.max_nd + 1) / 2 + 3) & ~3);  // membership bitmap
+  const int bmWords = (nd + 31) / 32;
+
+  for (int w = lane * 4; w < histWords4; w += 256) *(uint4*)(hist + w) = make_uint4(0, 0, 0, 0);
+  for (int w = lane; w < bmWords; w += 64) bm[w] = 0;
+  wave_lds_sync();
+
+  // histogram (diagenv.cpp:33-40): R read positions per lane per round, loads issued in batches
+  const uint32_t* __restrict__ starts = a.ref_bucket + (uint64_t)x * (a.nbuckets + 1);
+  const uint32_t* __restrict__ pos = a.ref_pos + xb;
+  const uint32_t* __restrict__ sk = a.skmer + yb;
+  const int nk = yLen - k + 1;  // read k-mers (>= 1 here)
+  const uint32_t lastQuad = (uint32_t)max(xLen - 4, 0);
+  constexpr int R = 8;
+  for (int j0 = 0; j0 < nk; j0 += 64 * R) {
+    uint32_t km[R], s[R], e[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      const int j = j0 + c * 64 + (int)lane;
+      km[c] = j < nk ? sk[j] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      s[c] = km[c] != 0xFFFFFFFFu ? starts[km[c]] : 0u;
+      e[c] = km[c] != 0xFFFFFFFFu ? starts[km[c] + 1] : 0u;
+    }
+    U32x4u p4[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) p4[c] = *(const U32x4u*)(pos + min(s[c], lastQuad));
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      const int j = j0 + c * 64 + (int)lane;
+      const uint32_t n = e[c] - s[c];
+      const uint32_t shift = s[c] - min(s[c], lastQuad);  // bucket entry q sits at p4.v[q + shift]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((uint32_t)q < n && q + shift < 4) {
+          const int bin = (int)p4[c].v[q + shift] - j + yLen - 1;
+          atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
+        }
+      // entries beyond the quad (long bucket, or one straddling the clamped load): one at a time
+      for (uint32_t q = 4 - shift; q < n; ++q) {
+        const int bin = (int)pos[s[c] + q] - j + yLen - 1;
+        atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
+      }
+    }
+  }
+  wave_lds_sync();
+
+  // seeds -> band masks in the bitmap (diagenv.cpp:68-96, threshold mode)
+  const uint32_t thr = a.threshold > 1 ? (uint32_t)a.threshold : 1u;
+  const int half = a.band / 2;
+  auto mark = [&](int b) {
+    const int lo = max(0, b - half), hi = min(nd - 1, b + half);
+    for (int w = lo >> 5; w <= (hi >> 5); ++w) {
+      const int blo = max(lo, w * 32) & 31, bhi = min(hi, w * 32 + 31) & 31;
+      const uint32_t mask = (0xFFFFFFFFu >> (31 - bhi)) & (0xFFFFFFFFu << blo);
+      atomicOr(&bm[w], mask);
+    }
+  };
+  for (int w = lane * 4; w < histWords4; w += 256) {
+    const uint4 h = *(const uint4*)(hist + w);
+    const uint32_t hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if ((hv[c] & 0xFFFFu) >= thr && 2 * (w + c) < nd) mark(2 * (w + c));
+      if ((hv[c] >> 16) >= thr && 2 * (w + c) + 1 < nd) mark(2 * (w + c) + 1);
+    }
+  }
+  if (lane == 0) atomicOr(&bm[(yLen - 1) >> 5], 1u << ((yLen - 1) & 31));  // diagonal 0, diagenv.cpp:52-54
+  wave_lds_sync();
+
+  // runs of consecutive member diagonals -> units
+  auto member = [&](int b) -> bool { return (bm[b >> 5] >> (b & 31)) & 1u; };
+  uint32_t nmem = 0;
+  for (int w = lane; w < bmWords; w += 64) {
+    const uint32_t bits = bm[w];
+    nmem += __popc(bits);
+    if (a.dump_cover)
+      for (int c = 0; c < 32 && w * 32 + c < nd; ++c) a.dump_cover[w * 32 + c] = (bits >> c) & 1u;
+    const uint32_t prev = w ? bm[w - 1] >> 31 : 0u;
+    uint32_t st = bits & ~((bits << 1) | prev);
+    while (st) {
+      const int b = w * 32 + __ffs(st) - 1;
+      st &= st - 1;
+      int e2 = b;
+      while (e2 + 1 < nd && member(e2 + 1)) ++e2;
+      record_band(a, pair, b + minD, e2 + minD);
+    }
+  }
+  for (int o = 32; o; o >>= 1) nmem += __shfl_xor(nmem, o);
+  if (lane == 0) a.pair_ndiag[pair] = nmem;
+}
+
+// Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
+// (pair, band slot); one global atomic per workgroup and counter.
+__global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs, uint32_t n_ovf) {
+  __shared__ uint32_t s_cnt[kNumClasses], s_base[kNumClasses], s_nact, s_ubase;
+  __shared__ unsigned long long s_cells[kNumClasses], s_scan[256], s_tb_base;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t idx = (uint64_t)blockIdx.x * 256 + tid;
+  const uint32_t pidx = (uint32_t)(idx / kMaxBandsPerPair), slot = (uint32_t)(idx % kMaxBandsPerPair);
+  if (tid < kNumClasses) { s_cnt[tid] = 0; s_cells[tid] = 0; }
+  if (tid == 0) s_nact = 0;
+  __syncthreads();
+  bool act = false, have = false;
+  uint32_t pair = 0, lrank = 0, urank = 0;
+  int dlo = 0, dhi = 0, cls = 0, yLen = 0;
+  unsigned long long tbw = 0, cells = 0;
+  if (n_ovf) {  // overflow pass: one thread per spilled band
+    if (idx < n_ovf) {
+      const int4 ob = a.ovf_bands[idx];
+      pair = (uint32_t)ob.x; dlo = ob.y; dhi = ob.z;
+      have = true;
+    }
+  } else if (pidx < n_pairs) {
+    pair = a.pair_base + pidx;
+    if (slot < min(a.pair_nbands[pair], (uint32_t)kMaxBandsPerPair)) {
+      const int2 bd = a.pair_bands[(uint64_t)pair * kMaxBandsPerPair + slot];
+      dlo = bd.x; dhi = bd.y;
+      have = true;
+    }
+  }
+  {
+    if (have) {
+      const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
+      const int xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]);
+      yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
+      cls = classify_width(dhi - dlo + 1);
+      if (cls < 0) {
+        atomicOr(&a.bc->error, 2u);
+        a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
+      } else {
+        act = true;
+        lrank = atomicAdd(&s_cnt[cls], 1u);
+        urank = atomicAdd(&s_nact, 1u);
+        tbw = unit_tb_words(cls, (uint32_t)yLen);
+        cells = (dhi - dlo + 1 == xLen + yLen - 1) ? (unsigned long long)xLen * (unsigned long long)yLen
+                                                    : band_cells(dlo, dhi, xLen, yLen);
+        atomicAdd(&s_cells[cls], cells);
+      }
+    }
+  }
+  s_scan[tid] = tbw;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const unsigned long long v = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  if (tid < kNumClasses && s_cnt[tid]) {
+    s_base[tid] = atomicAdd(&a.bc->cls_count[tid], s_cnt[tid]);
+    atomicAdd(&a.bc->cls_cells[tid], s_cells[tid]);
+    atomicAdd(&a.bc->total_cells, s_cells[tid]);
+  }
+  if (tid == 0 && s_nact) {
+    s_ubase = atomicAdd(&a.bc->n_units, s_nact);
+    s_tb_base = atomicAdd(&a.bc->tb_words, s_scan[255]);
+  }
+  __syncthreads();
+  if (!act) return;
+  const uint32_t uid = s_ubase + urank;
+  if (uid >= a.max_units) {
+    atomicOr(&a.bc->error, 1u);
+    return;
+  }
+  a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
+  Unit u;
+  u.pair = pair;
+  u.dlo = dlo;
+  u.dhi = dhi;
+  u.tb_off = s_tb_base + s_scan[tid] - tbw;
+  u.end_val = QF_NEG_INF;
+  u.end_i = 0;
+  u.cls = (uint32_t)cls;
+  u.next = atomicExch(&a.pair_head[pair], uid);
+  a.units[uid] = u;
+  atomicAdd(&a.pair_cells[pair], cells);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Banded Viterbi fill: QuaffViterbiMatrix ctor, src/qmodel.cpp:1512-1560
@@ -753,7 +951,9 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
   hipLaunchKernelGGL(k_ref_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, starts, cursor, pos);
 }
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
-  if (n_reads) hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
+  if (!n_reads) return;
+  hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_null_ll, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, n_reads);
 }
 size_t seed_lds_bytes(int max_nd, bool mem) {
   const size_t hist = (size_t)((max_nd + 1) / 2) * 4;
@@ -761,6 +961,19 @@ size_t seed_lds_bytes(int max_nd, bool mem) {
 }
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
+  if (!mem && a.sparse && a.threshold >= 0 && !a.force_block_kernel) {
+    // one wavefront per pair; as many pairs per workgroup as the LDS allows (4, 2 or 1)
+    const uint32_t words = (uint32_t)((((a.max_nd + 1) / 2 + 3) & ~3) + (((a.max_nd + 31) / 32 + 3) & ~3));
+    for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
+      const size_t lds = (size_t)words * 4 * wpb;
+      if (lds <= 150 * 1024) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_seed_wave, dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), lds, s, a, n_pairs, words);
+        return 0;
+      }
+    }
+    return -1;
+  }
   const size_t lds = seed_lds_bytes(a.max_nd, mem);
   if (lds > 150 * 1024) return -1;
   if (mem) {
@@ -771,6 +984,11 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
     hipLaunchKernelGGL(k_seed<false>, dim3(n_pairs), dim3(256), lds, s, a);
   }
   return 0;
+}
+void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s) {
+  const uint64_t threads = n_ovf ? (uint64_t)n_ovf : (uint64_t)n_pairs * kMaxBandsPerPair;
+  if (!threads) return;
+  hipLaunchKernelGGL(k_bin_units, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, a, n_pairs, n_ovf);
 }
 void launch_finalize(const FinalArgs& a, hipStream_t s) {
   if (a.n_pairs) hipLaunchKernelGGL(k_finalize_pairs, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a);

@@ -41,10 +41,15 @@ struct SeedArgs {
   Unit* units;
   uint32_t max_units;
   uint32_t* cls_list;          // [kNumClasses][max_units]
+  int2* pair_bands;            // [n_pairs][kMaxBandsPerPair] (dlo, dhi) written by the seeding kernels
+  uint32_t* pair_nbands;       // [n_pairs] (zero-initialised)
+  int4* ovf_bands;             // [ovf_cap] (pair, dlo, dhi, -) bands beyond kMaxBandsPerPair
+  uint32_t ovf_cap;
   uint32_t* pair_head;         // [n_pairs] (kNoUnit-initialised)
   uint32_t* pair_ndiag;        // [n_pairs]
   unsigned long long* pair_cells;  // [n_pairs] (zero-initialised)
   uint8_t* dump_cover;         // optional [nd] membership of a single pair
+  int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
   BatchCounters* bc;
 };
 
@@ -93,6 +98,7 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s);
 size_t seed_lds_bytes(int max_nd, bool mem);
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
+void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s);
 void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s);
 void launch_finalize(const FinalArgs& a, hipStream_t s);
 void launch_select(const FinalArgs& a, hipStream_t s);

@@ -106,9 +106,10 @@ def test_envelopes_match_oracle(ctx):
                           band=kw.get("band_size", 64), max_size=kw.get("max_size", 0))
         for r, read in enumerate(reads):
             for x, rf in enumerate(refs):
-                got = ctx.envelope(r, x, Q.DPConfig(**kw))
                 want = O.envelope(O.tokens(rf.seq), O.tokens(read.seq), ocfg, 24)
-                assert np.array_equal(got, want), (kw, r, x, len(got), len(want))
+                for dbg in (0, 1):      # 0: wavefront-per-pair seeding kernel, 1: workgroup-per-pair kernel
+                    got = ctx.envelope(r, x, Q.DPConfig(debug_flags=dbg, **kw))
+                    assert np.array_equal(got, want), (kw, dbg, r, x, len(got), len(want))
 
 
 def test_align_small_both_strands(ctx):
