@@ -357,6 +357,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct __attribute__((packed, aligned(4))) U32x4u { uint32_t v[4]; };
 
 __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words) {
+  // Two-level histogram.  Pass 1 counts k-mer matches per COARSE bin of 32 diagonals; a diagonal can reach
+  // the threshold only inside a coarse bin that does, so pass 2 re-walks the matches and keeps exact
+  // per-diagonal counters for those candidate bins alone (none at all for unrelated / wrong-strand pairs).
+  // ~4 KB of LDS per wavefront instead of a dense 2 B/diagonal histogram: 32 waves per CU hide the
+  // dependent index loads.
+  constexpr int kCand = 32;  // candidate coarse bins refined per round
   extern __shared__ uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -377,81 +383,105 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
       for (int b = lane; b < nd; b += 64) a.dump_cover[b] = 1;
     return;
   }
-  uint32_t* hist = lds + (size_t)wv * wave_lds_words;   // two 16-bit counters per dword
-  const int histWords = (nd + 1) / 2, histWords4 = (histWords + 3) & ~3;
-  uint32_t* bm = hist + (((a.max_nd + 1) / 2 + 3) & ~3);  // membership bitmap
-  const int bmWords = (nd + 31) / 32;
+  const int nCoarse = (nd + 31) >> 5, coarseWords = (nCoarse + 1) / 2, bmWords = nCoarse;
+  uint32_t* coarse = lds + (size_t)wv * wave_lds_words;      // two 16-bit counters per dword; later: slot map
+  uint32_t* bm = coarse + (((a.max_nd + 31) / 32 + 1) / 2 + 1);  // membership bitmap, one bit per diagonal
+  uint32_t* fine = bm + ((a.max_nd + 31) / 32 + 1);          // [kCand][16] dwords = 32 x 16-bit counters each
+  uint32_t* misc = fine + kCand * 16;                        // [0] candidate count, [1..kCand] candidate bins
 
-  for (int w = lane * 4; w < histWords4; w += 256) *(uint4*)(hist + w) = make_uint4(0, 0, 0, 0);
+  for (int w = lane; w < coarseWords; w += 64) coarse[w] = 0;
   for (int w = lane; w < bmWords; w += 64) bm[w] = 0;
+  if (lane == 0) misc[0] = 0;
   wave_lds_sync();
 
-  // histogram (diagenv.cpp:33-40): R read positions per lane per round, loads issued in batches
   const uint32_t* __restrict__ starts = a.ref_bucket + (uint64_t)x * (a.nbuckets + 1);
   const uint32_t* __restrict__ pos = a.ref_pos + xb;
   const uint32_t* __restrict__ sk = a.skmer + yb;
   const int nk = yLen - k + 1;  // read k-mers (>= 1 here)
   const uint32_t lastQuad = (uint32_t)max(xLen - 4, 0);
-  constexpr int R = 8;
-  for (int j0 = 0; j0 < nk; j0 += 64 * R) {
-    uint32_t km[R], s[R], e[R];
+  // visit(bin) for every (i, j) with equal k-mers, bin = i - j + yLen - 1 (diagenv.cpp:33-40).
+  // R read positions per lane per round; the three dependent loads are issued as batches.
+  auto walk = [&](auto&& visit) {
+    constexpr int R = 4;
+    for (int j0 = 0; j0 < nk; j0 += 64 * R) {
+      uint32_t km[R], s[R], e[R];
 #pragma unroll
-    for (int c = 0; c < R; ++c) {
-      const int j = j0 + c * 64 + (int)lane;
-      km[c] = j < nk ? sk[j] : 0xFFFFFFFFu;
-    }
+      for (int c = 0; c < R; ++c) {
+        const int j = j0 + c * 64 + (int)lane;
+        km[c] = j < nk ? sk[j] : 0xFFFFFFFFu;
+      }
 #pragma unroll
-    for (int c = 0; c < R; ++c) {
-      s[c] = km[c] != 0xFFFFFFFFu ? starts[km[c]] : 0u;
-      e[c] = km[c] != 0xFFFFFFFFu ? starts[km[c] + 1] : 0u;
-    }
-    U32x4u p4[R];
+      for (int c = 0; c < R; ++c) {
+        s[c] = km[c] != 0xFFFFFFFFu ? starts[km[c]] : 0u;
+        e[c] = km[c] != 0xFFFFFFFFu ? starts[km[c] + 1] : 0u;
+      }
+      U32x4u p4[R];
 #pragma unroll
-    for (int c = 0; c < R; ++c) p4[c] = *(const U32x4u*)(pos + min(s[c], lastQuad));
+      for (int c = 0; c < R; ++c) p4[c] = *(const U32x4u*)(pos + min(s[c], lastQuad));
 #pragma unroll
-    for (int c = 0; c < R; ++c) {
-      const int j = j0 + c * 64 + (int)lane;
-      const uint32_t n = e[c] - s[c];
-      const uint32_t shift = s[c] - min(s[c], lastQuad);  // bucket entry q sits at p4.v[q + shift]
+      for (int c = 0; c < R; ++c) {
+        const int j = j0 + c * 64 + (int)lane;
+        const uint32_t n = e[c] - s[c];
+        const uint32_t shift = s[c] - min(s[c], lastQuad);  // bucket entry q sits at p4.v[q + shift]
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if ((uint32_t)q < n && q + shift < 4) {
-          const int bin = (int)p4[c].v[q + shift] - j + yLen - 1;
-          atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
-        }
-      // entries beyond the quad (long bucket, or one straddling the clamped load): one at a time
-      for (uint32_t q = 4 - shift; q < n; ++q) {
-        const int bin = (int)pos[s[c] + q] - j + yLen - 1;
-        atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
+        for (int q = 0; q < 4; ++q)
+          if ((uint32_t)q < n && q + shift < 4) visit((int)p4[c].v[q + shift] - j + yLen - 1);
+        for (uint32_t q = 4 - shift; q < n; ++q) visit((int)pos[s[c] + q] - j + yLen - 1);  // long buckets
       }
     }
-  }
+  };
+  walk([&](int bin) { atomicAdd(&coarse[bin >> 6], 1u << (16 * ((bin >> 5) & 1))); });
   wave_lds_sync();
 
-  // seeds -> band masks in the bitmap (diagenv.cpp:68-96, threshold mode)
+  // candidate coarse bins; afterwards the coarse array holds each bin's candidate slot (0xFFFF = none)
   const uint32_t thr = a.threshold > 1 ? (uint32_t)a.threshold : 1u;
+  uint32_t ncand = 0;
+  for (int w0 = 0; w0 < coarseWords; w0 += 64) {
+    const int w = w0 + (int)lane;
+    uint32_t hv = w < coarseWords ? coarse[w] : 0u, outv = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (((hv >> (16 * c)) & 0xFFFFu) >= thr) {
+        const uint32_t slot = atomicAdd(&misc[0], 1u);
+        if (slot < 0xFFFFu) outv = (outv & ~(0xFFFFu << (16 * c))) | (slot << (16 * c));
+      }
+    if (w < coarseWords) coarse[w] = outv;
+  }
+  wave_lds_sync();
+  ncand = min(misc[0], 0xFFFEu);
+
   const int half = a.band / 2;
   auto mark = [&](int b) {
     const int lo = max(0, b - half), hi = min(nd - 1, b + half);
     for (int w = lo >> 5; w <= (hi >> 5); ++w) {
       const int blo = max(lo, w * 32) & 31, bhi = min(hi, w * 32 + 31) & 31;
-      const uint32_t mask = (0xFFFFFFFFu >> (31 - bhi)) & (0xFFFFFFFFu << blo);
-      atomicOr(&bm[w], mask);
+      atomicOr(&bm[w], (0xFFFFFFFFu >> (31 - bhi)) & (0xFFFFFFFFu << blo));
     }
   };
-  for (int w = lane * 4; w < histWords4; w += 256) {
-    const uint4 h = *(const uint4*)(hist + w);
-    const uint32_t hv[4] = {h.x, h.y, h.z, h.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if ((hv[c] & 0xFFFFu) >= thr && 2 * (w + c) < nd) mark(2 * (w + c));
-      if ((hv[c] >> 16) >= thr && 2 * (w + c) + 1 < nd) mark(2 * (w + c) + 1);
+  auto slotOf = [&](int cb) -> uint32_t { return (coarse[cb >> 1] >> (16 * (cb & 1))) & 0xFFFFu; };
+  for (uint32_t base = 0; base < ncand; base += kCand) {  // almost always one round
+    for (int w = lane; w < kCand * 16; w += 64) fine[w] = 0;
+    wave_lds_sync();
+    walk([&](int bin) {
+      const uint32_t slot = slotOf(bin >> 5) - base;  // 0xFFFF - base is never < kCand
+      if (slot < (uint32_t)kCand) atomicAdd(&fine[slot * 16 + ((bin & 31) >> 1)], 1u << (16 * (bin & 1)));
+    });
+    wave_lds_sync();
+    // seeds: diagonals of this round's candidate bins reaching the threshold (diagenv.cpp:68-96)
+    for (int cb = lane; cb < nCoarse; cb += 64) {
+      const uint32_t slot = slotOf(cb) - base;
+      if (slot >= (uint32_t)kCand) continue;
+      for (int c = 0; c < 32; ++c) {
+        const uint32_t cnt = (fine[slot * 16 + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
+        if (cnt >= thr && cb * 32 + c < nd) mark(cb * 32 + c);
+      }
     }
+    wave_lds_sync();
   }
   if (lane == 0) atomicOr(&bm[(yLen - 1) >> 5], 1u << ((yLen - 1) & 31));  // diagonal 0, diagenv.cpp:52-54
   wave_lds_sync();
 
-  // runs of consecutive member diagonals -> units
+  // runs of consecutive member diagonals -> bands
   auto member = [&](int b) -> bool { return (bm[b >> 5] >> (b & 31)) & 1u; };
   uint32_t nmem = 0;
   for (int w = lane; w < bmWords; w += 64) {
@@ -962,15 +992,14 @@ size_t seed_lds_bytes(int max_nd, bool mem) {
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
   if (!mem && a.sparse && a.threshold >= 0 && !a.force_block_kernel) {
-    // one wavefront per pair; as many pairs per workgroup as the LDS allows (4, 2 or 1)
-    const uint32_t words = (uint32_t)((((a.max_nd + 1) / 2 + 3) & ~3) + (((a.max_nd + 31) / 32 + 3) & ~3));
-    for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
-      const size_t lds = (size_t)words * 4 * wpb;
-      if (lds <= 150 * 1024) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_seed_wave, dim3((n_pairs + wpb - 1) / wpb), dim3(64 * wpb), lds, s, a, n_pairs, words);
-        return 0;
-      }
+    // one wavefront per pair, four pairs per workgroup; LDS per wave: coarse counters + bitmap + fine counters
+    const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
+    const uint32_t words = ((nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
+    const size_t lds = (size_t)words * 4 * 4;
+    if (lds <= 150 * 1024) {
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_seed_wave, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
+      return 0;
     }
     return -1;
   }
