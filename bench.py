@@ -84,16 +84,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl")   # nccl == RCCL on ROCm
-        dist = dist_mod
     import numpy as np
     import quaff_amd as Q
-    from quaff_amd import api
+    from quaff_amd import api, dist
+    if world > 1:
+        dist.init("nccl")                     # nccl == RCCL on ROCm; one process per GPU
 
     ctx = Q.Context(local_rank)
     ctx.set_params_json(None)
@@ -105,11 +100,8 @@ def main():
     cfg = Q.DPConfig(band_size=a.band)
 
     def sync_all():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()                    # barrier + torch.cuda.synchronize() on both sides
 
     for _ in range(a.warmup):
         ctx.align_resident(cfg, 0, raw=True)
@@ -130,17 +122,11 @@ def main():
         tb_bytes, n_units, n_align = int(res.traceback_bytes), int(res.n_units), int(res.n_alignments)
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([total_cells], device="cuda", dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = int(c.item())
+    if world > 1:
+        dt = dist.allreduce_max(dt)
+        total_cells = int(dist.allreduce_sum(np.array([float(total_cells)]))[0])
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        dist.finalize()
         return
 
     dom = max(cls_ms, key=lambda k: cls_ms[k])
@@ -182,8 +168,7 @@ def main():
     }
     print(json.dumps(out))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.finalize()
 
 
 if __name__ == "__main__":

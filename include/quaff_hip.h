@@ -22,6 +22,11 @@
  *   QuaffViterbiMatrix::alignment    src/qmodel.cpp:1562-1646 qf_align_batch (traceback kernel)
  *   QuaffAlignmentTask::run          src/qmodel.cpp:2764-2778 qf_align_batch (best ref per read)
  *   Alignment::cigarString           src/qmodel.cpp:625-653   qf_cigar_string
+ *   QuaffForwardMatrix ctor          src/qmodel.cpp:1343-1391 qf_count_resident (forward kernels)
+ *   QuaffBackwardMatrix ctor         src/qmodel.cpp:1393-1510 qf_count_resident (backward kernels + counts)
+ *   QuaffCountingTask::run           src/qmodel.cpp:2238-2271 qf_count_resident (pruning, weights, new order)
+ *   QuaffParamCounts(QuaffCounts)    src/qmodel.cpp:407-417   qf_count_result.counts layout
+ *   QuaffTrainer::getCounts reduce   src/qmodel.cpp:2416-2422 sum over the batch (+ caller's all-reduce)
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative qf_status otherwise (message via qf_last_error); nothing throws or exits across
@@ -142,6 +147,34 @@ int qf_align_resident(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t flags, qf_a
 /* Convenience: qf_upload_reads + qf_align_resident. */
 int qf_align_batch(qf_ctx *ctx, const qf_dp_config *cfg, const char *seq, const char *qual,
                    const uint64_t *offsets, uint32_t n_reads, uint32_t flags, qf_align_result *out);
+
+/* ---- Forward-Backward E-step (quaff train / count) -------------------------------------- */
+#define QF_COUNT_FORCE 1u     /* -force: no null model in the per-read normalisation (yLogLike starts at -inf) */
+
+typedef struct qf_count_result {
+  uint32_t n_reads, n_refs;
+  const double *forward;        /* [n_reads * n_refs] Forward log-likelihood; -inf for references not in the order */
+  const double *weight;         /* [n_reads * n_refs] posterior weight exp(LL - yLogLike) of pairs that got a Backward pass, else 0 */
+  const double *read_loglike;   /* [n_reads] yLogLike = lse(null, LL_x ...) */
+  const uint32_t *sort_order;   /* [n_reads * n_refs] next iteration's reference order per read ... */
+  const uint32_t *sort_count;   /* [n_reads]          ... and how many entries of it are valid */
+  /* flattened QuaffParamCounts summed over the batch (qf_counts_size doubles):
+   *   insert[4][94] | match[4][Km][94] | beginInsertNo[Kg] beginInsertYes[Kg] beginDeleteNo[Kg] beginDeleteYes[Kg]
+   *   | extendInsertNo extendInsertYes extendDeleteNo extendDeleteYes */
+  const double *counts;
+  uint32_t counts_size;
+  double loglike;               /* sum over reads of yLogLike (QuaffCountingScheduler::finalLogLike) */
+  uint64_t total_cells;         /* envelope cells of the pairs that were seeded (each visited by Forward, and by Backward if weighted) */
+  uint64_t backward_cells;
+  uint64_t forward_bytes;       /* Forward matrix bytes materialised */
+  float ms_prep, ms_seed, ms_forward, ms_plan, ms_backward, ms_total;
+} qf_count_result;
+
+/* One E-step over the resident reads.  sort_in / sort_n_in (optional, [n_reads*n_refs] / [n_reads]) give each
+ * read's reference order from the previous EM iteration (defaultSortOrder = all references in index order). */
+int qf_count_resident(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t flags, const uint32_t *sort_in,
+                      const uint32_t *sort_n_in, qf_count_result *out);
+uint32_t qf_counts_size(const qf_ctx *ctx);
 
 /* Envelope only (DiagonalEnvelope::diagonals for pair (read, ref)); returns the number of
  * diagonals, writes at most cap of them.  For tests and debugging. */

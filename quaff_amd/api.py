@@ -55,10 +55,20 @@ class _AlignResult(C.Structure):
                 ("n_fill_classes", C.c_uint32)]
 
 
+class _CountResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_refs", C.c_uint32), ("forward", C.POINTER(C.c_double)),
+                ("weight", C.POINTER(C.c_double)), ("read_loglike", C.POINTER(C.c_double)),
+                ("sort_order", C.POINTER(C.c_uint32)), ("sort_count", C.POINTER(C.c_uint32)),
+                ("counts", C.POINTER(C.c_double)), ("counts_size", C.c_uint32), ("loglike", C.c_double),
+                ("total_cells", C.c_uint64), ("backward_cells", C.c_uint64), ("forward_bytes", C.c_uint64),
+                ("ms_prep", C.c_float), ("ms_seed", C.c_float), ("ms_forward", C.c_float), ("ms_plan", C.c_float),
+                ("ms_backward", C.c_float), ("ms_total", C.c_float)]
+
+
 EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
-           "qf_fill_class_name"]
+           "qf_fill_class_name", "qf_count_resident", "qf_counts_size"]
 
 
 def load_library():
@@ -93,6 +103,10 @@ def load_library():
         L.qf_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.qf_scores_from_json.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_char_p, C.c_size_t]
+        L.qf_count_resident.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.POINTER(_CountResult)]
+        L.qf_counts_size.restype = C.c_uint32
+        L.qf_counts_size.argtypes = [C.c_void_p]
         L.qf_fill_class_name.restype = C.c_char_p
         L.qf_fill_class_name.argtypes = [C.c_uint32]
         _LIB = L
@@ -248,6 +262,33 @@ class Context:
                 "cigar": "".join("MID"[int(r) & 3] + str(int(r) >> 2) for r in runs),
                 "ops": "".join("MID"[int(r) & 3] * (int(r) >> 2) for r in runs)})
         return out
+
+    def count_resident(self, cfg=None, force=False, sort_order=None):
+        """One Forward-Backward E-step over the resident reads.  sort_order: optional list (per read) of reference
+        indices from the previous iteration.  Returns dict(forward, weight, read_loglike, sort_order, counts, ...)."""
+        cfg = cfg or DPConfig()
+        res = _CountResult()
+        si = sn = None
+        if sort_order is not None:
+            si = np.zeros((self.n_reads, self.n_refs), np.uint32)
+            sn = np.zeros(self.n_reads, np.uint32)
+            for r, o in enumerate(sort_order):
+                si[r, :len(o)] = o
+                sn[r] = len(o)
+        self._chk(self.L.qf_count_resident(self.h, C.byref(cfg), 1 if force else 0,
+                                           si.ctypes.data if si is not None else None,
+                                           sn.ctypes.data if sn is not None else None, C.byref(res)))
+        n = res.n_reads * res.n_refs
+        shape = (res.n_reads, res.n_refs)
+        arr = lambda ptr, cnt, shp=None: (np.ctypeslib.as_array(ptr, (cnt,)).copy().reshape(shp or (cnt,)) if cnt else np.zeros(shp or (0,)))
+        order = arr(res.sort_order, n, shape)
+        cnt = arr(res.sort_count, res.n_reads)
+        return {"forward": arr(res.forward, n, shape), "weight": arr(res.weight, n, shape),
+                "read_loglike": arr(res.read_loglike, res.n_reads),
+                "sort_order": [list(map(int, order[r, :int(cnt[r])])) for r in range(res.n_reads)],
+                "counts": arr(res.counts, res.counts_size), "loglike": res.loglike, "total_cells": int(res.total_cells),
+                "backward_cells": int(res.backward_cells), "forward_bytes": int(res.forward_bytes),
+                "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "forward", "plan", "backward", "total")}}
 
     def envelope(self, read, ref, cfg=None):
         cfg = cfg or DPConfig()

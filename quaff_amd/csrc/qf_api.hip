@@ -72,13 +72,17 @@ struct qf_ctx {
   DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll;
   // batch state
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
-      d_recs, d_runs_tmp, d_runs_out, d_cover;
+      d_recs, d_runs_tmp, d_runs_out, d_cover, d_lse, d_fw, d_weight, d_fwd_out, d_counts, d_order_in, d_order_n_in,
+      d_order_out, d_order_n_out, d_rll, d_skip;
   // host results
   std::vector<double> h_viterbi, h_nll;
   std::vector<uint64_t> h_cells;
   std::vector<uint32_t> h_ndiag, h_runs;
   std::vector<qf_alignment> h_align;
   std::vector<AlignRec> h_recs;
+  std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
+  std::vector<uint32_t> h_order, h_order_n;
+  bool lse_uploaded = false;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -137,7 +141,9 @@ void qf_ctx_destroy(qf_ctx* c) {
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
                     &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_units, &c->d_cls_list,
                     &c->d_pair_head, &c->d_pair_bands, &c->d_pair_nbands, &c->d_ovf, &c->d_pair_ndiag, &c->d_pair_cells, &c->d_pair_score, &c->d_pair_end_unit,
-                    &c->d_bc, &c->d_tb, &c->d_recs, &c->d_runs_tmp, &c->d_runs_out, &c->d_cover})
+                    &c->d_bc, &c->d_tb, &c->d_recs, &c->d_runs_tmp, &c->d_runs_out, &c->d_cover, &c->d_lse, &c->d_fw,
+                    &c->d_weight, &c->d_fwd_out, &c->d_counts, &c->d_order_in, &c->d_order_n_in, &c->d_order_out,
+                    &c->d_order_n_out, &c->d_rll, &c->d_skip})
     b->release();
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->cls_ev) if (ev) (void)hipEventDestroy(ev);
@@ -624,6 +630,229 @@ int qf_align_batch(qf_ctx* c, const qf_dp_config* cfg, const char* seq, const ch
                    uint32_t n_reads, uint32_t flags, qf_align_result* out) {
   if (int rc = qf_upload_reads(c, seq, qual, offsets, n_reads)) return rc;
   return qf_align_resident(c, cfg, flags, out);
+}
+
+// ------------------------------------------------------------------------- Forward-Backward E-step
+uint32_t qf_counts_size(const qf_ctx* c) {
+  if (!c || !c->have_params) return 0;
+  return (uint32_t)((4 + 4 * c->scores.Km) * kNQual + 4 * c->scores.Kg + 4);
+}
+
+int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const uint32_t* sort_in,
+                      const uint32_t* sort_n_in, qf_count_result* out) {
+  if (int rc = check_cfg(c, cfg)) return rc;
+  if (!out) return fail(c, QF_ERR_ARG, "null result");
+  if ((sort_in == nullptr) != (sort_n_in == nullptr)) return fail(c, QF_ERR_ARG, "sort_in and sort_n_in go together");
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
+  const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
+  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
+  const uint32_t n_pairs = (uint32_t)n_pairs64;
+  out->n_reads = n_reads;
+  out->n_refs = n_refs;
+  const uint32_t csize = qf_counts_size(c);
+  out->counts_size = csize;
+  c->h_pcounts.assign(csize, 0.0);
+  out->counts = c->h_pcounts.data();
+  if (!n_pairs) return QF_OK;
+  if (!c->reads_have_qual)  // QuaffBackwardMatrix ctor, src/qmodel.cpp:1398
+    return fail(c, QF_ERR_ARG, "Forward-Backward algorithm requires quality scores to fit model");
+  const bool use_null = !(flags & QF_COUNT_FORCE);
+  if (use_null && !c->have_null) return fail(c, QF_ERR_STATE, "no null model set (qf_set_null_json) and QF_COUNT_FORCE not given");
+  const bool sparse = cfg->sparse != 0;
+  const bool mem = sparse && cfg->kmer_threshold < 0;
+  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
+  if (!c->lse_uploaded) {
+    const std::vector<double>& t = lse_table();
+    HIPCHK(c, c->d_lse.reserve(t.size() * 8));
+    HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    c->lse_uploaded = true;
+  }
+
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const uint32_t max_units = n_pairs * 4 + 1024;
+  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  // pairs outside the read's reference order are not even seeded (their LL stays -inf, qmodel.cpp:2245)
+  HIPCHK(c, c->d_order_in.reserve((size_t)n_pairs * 4));
+  HIPCHK(c, c->d_order_n_in.reserve((size_t)n_reads * 4));
+  const uint8_t* d_skip = nullptr;
+  if (sort_in) {
+    std::vector<uint8_t> skip(n_pairs, 1);
+    for (uint32_t r = 0; r < n_reads; ++r) {
+      if (sort_n_in[r] > n_refs) return fail(c, QF_ERR_ARG, "sort_n_in out of range");
+      for (uint32_t k = 0; k < sort_n_in[r]; ++k) {
+        const uint32_t x = sort_in[(size_t)r * n_refs + k];
+        if (x >= n_refs) return fail(c, QF_ERR_ARG, "sort_in out of range");
+        skip[(size_t)r * n_refs + x] = 0;
+      }
+    }
+    HIPCHK(c, c->d_skip.reserve(n_pairs));
+    HIPCHK(c, hipMemcpyAsync(c->d_skip.p, skip.data(), n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_order_in.p, sort_in, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_order_n_in.p, sort_n_in, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // `skip` is a stack-lifetime host buffer
+    d_skip = c->d_skip.as<uint8_t>();
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+  // ---- seeding (cellSize = 2 * 24 for counting, qmodel.cpp:2249; only matters in memory mode)
+  const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
+  SeedArgs sa;
+  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  sa.cell_size = 48;
+  sa.storage_mode = 1;
+  sa.pair_skip = d_skip;
+  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
+    return fail(c, QF_ERR_UNSUPPORTED, "reference + read length exceeds the LDS diagonal histogram");
+  launch_bin_units(sa, n_pairs, 0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  BatchCounters bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  if (bc.n_ovf && !(bc.error & 8u)) {
+    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (int rc = read_counters(c, bc)) return rc;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  if (bc.error & 2u)
+    return fail(c, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels");
+  if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
+  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
+
+  // ---- Forward
+  const uint64_t fw_bytes = (uint64_t)bc.tb_words * 8;
+  if (fw_bytes > (220ull << 30))
+    return fail(c, QF_ERR_MEMORY, "Forward matrices need " + std::to_string(fw_bytes >> 30) + " GiB; upload fewer reads per batch");
+  HIPCHK(c, c->d_fw.reserve(fw_bytes + 64));
+  HIPCHK(c, c->d_weight.reserve((size_t)n_pairs * 8));
+  HIPCHK(c, c->d_fwd_out.reserve((size_t)n_pairs * 8));
+  HIPCHK(c, c->d_counts.reserve((size_t)csize * 8));
+  HIPCHK(c, c->d_order_out.reserve((size_t)n_pairs * 4));
+  HIPCHK(c, c->d_order_n_out.reserve((size_t)n_reads * 4));
+  HIPCHK(c, c->d_rll.reserve((size_t)n_reads * 8));
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)csize * 8, c->stream));
+  const Scores& sc = c->scores;
+  FbArgs fa{};
+  fa.n_refs = n_refs;
+  fa.units = c->d_units.as<Unit>();
+  fa.ref_off = c->d_ref_off.as<uint64_t>();
+  fa.ref_tok = c->d_ref_tok.as<uint8_t>();
+  fa.read_off = c->d_roff.as<uint64_t>();
+  fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+  fa.fw = c->d_fw.as<double>();
+  fa.lse = c->d_lse.as<double>();
+  fa.dp.ematch = c->d_ematch.as<double>();
+  fa.dp.eins = c->d_eins.as<double>();
+  fa.dp.trans = c->d_trans.as<double>();
+  fa.dp.d2d = sc.trans[4 * sc.Kg + 0];
+  fa.dp.d2m = sc.trans[4 * sc.Kg + 1];
+  fa.dp.i2i = sc.trans[4 * sc.Kg + 2];
+  fa.dp.i2m = sc.trans[4 * sc.Kg + 3];
+  fa.dp.Kg = sc.Kg;
+  fa.dp.local = cfg->local;
+  fa.pair_fwd = c->d_pair_score.as<double>();
+  fa.pair_weight = c->d_weight.as<double>();
+  fa.counts = c->d_counts.as<double>();
+  fa.Km = sc.Km;
+  for (int cls = kNumClasses - 1; cls >= 1; --cls) {
+    fa.n_cls_units = bc.cls_count[cls];
+    fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+    launch_forward_fill(cls, fa, c->stream);
+  }
+  FinalArgs fin{};
+  fin.n_pairs = n_pairs;
+  fin.n_reads = n_reads;
+  fin.n_refs = n_refs;
+  fin.units = c->d_units.as<Unit>();
+  fin.pair_head = c->d_pair_head.as<uint32_t>();
+  fin.pair_score = c->d_pair_score.as<double>();
+  launch_pair_forward(fin, c->d_lse.as<double>(), c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+
+  // ---- per-read plan: running log-likelihood, Backward flags, weights, next order
+  CountPlanArgs pa{};
+  pa.n_reads = n_reads;
+  pa.n_refs = n_refs;
+  pa.use_null = use_null;
+  pa.nll = c->d_nll.as<double>();
+  pa.lse = c->d_lse.as<double>();
+  pa.pair_fwd = c->d_pair_score.as<double>();
+  pa.pair_fwd_out = c->d_fwd_out.as<double>();
+  pa.weight = c->d_weight.as<double>();
+  pa.order_in = sort_in ? c->d_order_in.as<uint32_t>() : nullptr;
+  pa.order_n_in = sort_in ? c->d_order_n_in.as<uint32_t>() : nullptr;
+  pa.order_out = c->d_order_out.as<uint32_t>();
+  pa.order_n_out = c->d_order_n_out.as<uint32_t>();
+  pa.read_loglike = c->d_rll.as<double>();
+  launch_count_plan(pa, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+
+  // ---- Backward + counts
+  for (int cls = kNumClasses - 1; cls >= 1; --cls) {
+    fa.n_cls_units = bc.cls_count[cls];
+    fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+    launch_backward_fill(cls, fa, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+
+  c->h_fwd.resize(n_pairs);
+  c->h_weight.resize(n_pairs);
+  c->h_rll.resize(n_reads);
+  c->h_counts.resize(csize);
+  c->h_order.resize(n_pairs);
+  c->h_order_n.resize(n_reads);
+  c->h_cells.resize(n_pairs);
+  HIPCHK(c, hipMemcpyAsync(c->h_fwd.data(), c->d_fwd_out.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_weight.data(), c->d_weight.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_rll.data(), c->d_rll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_order.data(), c->d_order_out.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_order_n.data(), c->d_order_n_out.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_cells.data(), c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+
+  // QuaffParamCounts(const QuaffCounts&), src/qmodel.cpp:407-417 (linear, so it commutes with the weighted sum)
+  const size_t ne = (size_t)(4 + 4 * sc.Km) * kNQual, Kg = sc.Kg;
+  const double* q = c->h_counts.data();
+  double* pc = c->h_pcounts.data();
+  std::copy(q, q + ne, pc);
+  for (size_t g = 0; g < Kg; ++g) {
+    const double m2m = q[ne + g], m2i = q[ne + Kg + g], m2d = q[ne + 2 * Kg + g], m2e = q[ne + 3 * Kg + g];
+    pc[ne + g] = m2m + m2d;            // beginInsertNo
+    pc[ne + Kg + g] = m2i + m2e;       // beginInsertYes
+    pc[ne + 2 * Kg + g] = m2m;         // beginDeleteNo
+    pc[ne + 3 * Kg + g] = m2d;         // beginDeleteYes
+  }
+  pc[ne + 4 * Kg + 0] = q[ne + 4 * Kg + 3];  // extendInsertNo  = i2m
+  pc[ne + 4 * Kg + 1] = q[ne + 4 * Kg + 2];  // extendInsertYes = i2i
+  pc[ne + 4 * Kg + 2] = q[ne + 4 * Kg + 1];  // extendDeleteNo  = d2m
+  pc[ne + 4 * Kg + 3] = q[ne + 4 * Kg + 0];  // extendDeleteYes = d2d
+  double ll = 0;
+  for (uint32_t r = 0; r < n_reads; ++r) ll += c->h_rll[r];  // serial read-order sum, qmodel.cpp:2420-2422
+  uint64_t bcells = 0;
+  for (uint32_t p = 0; p < n_pairs; ++p) if (c->h_weight[p] > 0) bcells += c->h_cells[p];
+  out->forward = c->h_fwd.data();
+  out->weight = c->h_weight.data();
+  out->read_loglike = c->h_rll.data();
+  out->sort_order = c->h_order.data();
+  out->sort_count = c->h_order_n.data();
+  out->loglike = ll;
+  out->total_cells = bc.total_cells;
+  out->backward_cells = bcells;
+  out->forward_bytes = fw_bytes;
+  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&out->ms_seed, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&out->ms_forward, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&out->ms_plan, c->ev[3], c->ev[4]);
+  (void)hipEventElapsedTime(&out->ms_backward, c->ev[4], c->ev[5]);
+  (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
+  return QF_OK;
 }
 
 int64_t qf_envelope(qf_ctx* c, const qf_dp_config* cfg, uint32_t read, uint32_t ref, int32_t* diags, uint64_t cap) {

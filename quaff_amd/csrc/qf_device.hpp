@@ -55,6 +55,14 @@ __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   return (uint64_t)(yLen + fc.G - 1) * fc.G * (fc.B > 8 ? 2 : 1);
 }
 
+// Forward-matrix doubles a unit occupies (3 states x B slots x G lanes per step); single-diagonal bands run on
+// the (16,2) kernel in Forward/Backward mode.
+__host__ __device__ inline int fb_class(int cls) { return cls == 0 ? 1 : cls; }
+__host__ __device__ inline uint64_t unit_fw_doubles(int cls, uint32_t yLen) {
+  const FillClass fc = fill_class(fb_class(cls));
+  return (uint64_t)(yLen + fc.G - 1) * fc.G * fc.B * 3;
+}
+
 struct BatchCounters {
   uint32_t n_units;
   uint32_t n_ovf;           // bands spilled past kMaxBandsPerPair

@@ -1,0 +1,420 @@
+// qf_fb.hip — Forward and Backward fills with E-step counts (the `quaff train` / `count` hot path):
+// QuaffForwardMatrix ctor src/qmodel.cpp:1343-1391, QuaffBackwardMatrix ctor + transCount :1393-1510,
+// QuaffCountingTask::run :2238-2271.  Same skewed G x B wavefront as the Viterbi fill (qf_kernels.hip); max
+// is replaced by the reference's table log-sum-exp (src/logsumexp.cpp:34-103: 1e-4-step table, linear
+// interpolation, cut-off at 10), whose table is built on the host and shared.  The Forward matrix IS
+// materialised (24 B/cell, step-major so every store/load is a coalesced segment); Backward re-reads it and
+// never stores its own matrix.  Results are compared with 1e-4 relative tolerance (north_star), so sums may
+// be re-associated: per-column count partials are combined in an LDS ring and flushed with fp64 atomics.
+#include <hip/hip_runtime.h>
+
+#include "qf_kernels.hpp"
+
+namespace qf {
+
+#define QF_NEG_INF (-__builtin_huge_val())
+
+// log_sum_exp, src/logsumexp.cpp:34-50 + log_sum_exp_unary :84-103 (x >= 10, NaN, inf -> 0).
+// n = (int)(x / 1e-4) is evaluated as x * 1e4: at worst the neighbouring interval of the same piecewise-
+// linear function is used (the interpolant is continuous), far inside the 1e-4 tolerance.
+__device__ __forceinline__ double lse2(const double* __restrict__ tab, double a, double b) {
+  const double mx = a > b ? a : b, mn = a > b ? b : a;
+  const double diff = mx - mn;  // -inf - -inf = NaN -> treated as 0 below, like the reference's a == b case
+  if (!(diff < 10.0)) return a == b ? mx + tab[0] : mx;
+  const int n = (int)(diff * 10000.0);
+  const double dx = diff - n * .0001;
+  const double f0 = tab[n], f1 = tab[n + 1];
+  return mx + (f0 + (f1 - f0) * (dx * 10000.0));
+}
+
+template <int G, int B>
+__global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
+  constexpr int UPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int grp = lane / G, l = lane % G;
+  const uint32_t uidx = wave * UPW + grp;
+  const bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0;
+  int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, fw_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb);
+    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
+    dlo = u.dlo; dhi = u.dhi; fw_off = u.tb_off;
+  }
+  int T = active ? yLen + G - 1 : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+  const int d0 = dlo + l * B;
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const double* __restrict__ tab = a.lse;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  double* __restrict__ fw = a.fw + fw_off;
+
+  double M[B], I[B], D[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
+  double pubM = QF_NEG_INF, pubD = QF_NEG_INF;
+  double endTerm[B];  // mat(i,yLen) + m2e for this lane's rows of the last column
+#pragma unroll
+  for (int b = 0; b < B; ++b) endTerm[b] = QF_NEG_INF;
+  uint32_t gkPrev = 0;
+  for (int t = 0; t < T; ++t) {
+    const int j = t - l + 1;
+    const bool colvalid = active && j >= 1 && j <= yLen;
+    const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+    const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
+    const uint32_t gp = j > 1 ? gkPrev : 0u;  // yIndelKmer is padded with a leading 0 (qmodel.cpp:1322)
+    const double m2m = trans[gp], m2i = trans[Kg + gp], m2d = trans[2 * Kg + gk];
+    gkPrev = gk;
+    const double insE = eins[insrow];
+    double lowM = __shfl_up(pubM, 1, G), lowD = __shfl_up(pubD, 1, G);
+    if (l == 0) { lowM = QF_NEG_INF; lowD = QF_NEG_INF; }
+    double upM = 0, upI = 0, prevM = lowM, prevD = lowD;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int d = d0 + b, i = d + j;
+      const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
+      const uint32_t tok = valid ? xt[i - 1] : 0u;
+      const double e = ematch[erow4 + tok];
+      // mat(i,j) = lse(lse(mat' + m2m, del' + d2m), ins' + i2m) [lse with start at column 1] + emit
+      double nm = lse2(tab, lse2(tab, M[b] + m2m, D[b] + d2m), I[b] + i2m);
+      if (j == 1 && (i == 1 || local)) nm = lse2(tab, nm, 0.0);
+      nm += e;
+      double srcM, srcI;
+      if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
+      double ni = insE + lse2(tab, srcI + i2i, srcM + m2i);
+      double ndl = lse2(tab, prevD + d2d, prevM + m2d);
+      if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+      M[b] = nm; I[b] = ni; D[b] = ndl;
+      prevM = nm; prevD = ndl;
+      if (colvalid) {
+        const uint64_t base = ((uint64_t)t * B + b) * 3 * G + l;
+        fw[base] = nm; fw[base + G] = ni; fw[base + 2 * G] = ndl;
+      }
+      if (j == yLen && valid && (local || i == xLen)) endTerm[b] = nm + trans[3 * Kg + gk];
+      if (b == 0) {
+        upM = __shfl_down(nm, 1, G); upI = __shfl_down(ni, 1, G);
+        if (l == G - 1) { upM = QF_NEG_INF; upI = QF_NEG_INF; }
+      }
+    }
+    pubM = prevM; pubD = prevD;
+  }
+  // end = lse(end, mat(i,yLen) + m2e) accumulated over rows in ascending order (src/qmodel.cpp:1379-1381): chain the
+  // lanes one after the other
+  double endv = QF_NEG_INF;
+  for (int s = 0; s < G; ++s) {
+    double v = endv;
+#pragma unroll
+    for (int b = 0; b < B; ++b) if (endTerm[b] > QF_NEG_INF) v = lse2(tab, v, endTerm[b]);
+    endv = __shfl(l == s ? v : endv, s, G);
+  }
+  if (active && l == 0) a.units[uid].end_val = endv;
+}
+
+// Forward result of a pair = lse over its bands (the reference accumulates `end` over all envelope cells of
+// the last column, src/qmodel.cpp:1379-1381).
+__global__ void k_pair_forward(FinalArgs a, const double* __restrict__ tab) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n_pairs) return;
+  double v = QF_NEG_INF;
+  int last = -2147483647 - 1;
+  while (true) {  // bands in ascending diagonal (= ascending row) order, like the reference's row loop
+    uint32_t pick = kNoUnit;
+    int best = 2147483647;
+    for (uint32_t uid = a.pair_head[p]; uid != kNoUnit; uid = a.units[uid].next) {
+      const int dl = a.units[uid].dlo;
+      if (dl > last && dl < best) { best = dl; pick = uid; }
+    }
+    if (pick == kNoUnit) break;
+    last = best;
+    const double ev = a.units[pick].end_val;
+    if (ev > QF_NEG_INF) v = lse2(tab, v, ev);
+  }
+  a.pair_score[p] = v;
+}
+
+// QuaffCountingTask::run, src/qmodel.cpp:2238-2271, the sequential part: running log-likelihood over the
+// read's reference order, which references get a Backward pass (LL >= running - 20), the posterior weights
+// exp(LL_x - yLogLike), and the next iteration's order (LL descending, cut at yLogLike - 20).
+__global__ void k_count_plan(CountPlanArgs a) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n_reads) return;
+  const double* __restrict__ tab = a.lse;
+  double ylog = a.use_null ? a.nll[r] : QF_NEG_INF;
+  const uint32_t nord = a.order_in ? a.order_n_in[r] : a.n_refs;
+  for (uint32_t k = 0; k < a.n_refs; ++k) a.weight[(uint64_t)r * a.n_refs + k] = 0.0;
+  for (uint32_t k = 0; k < nord; ++k) {
+    const uint32_t x = a.order_in ? a.order_in[(uint64_t)r * a.n_refs + k] : k;
+    const double ll = a.pair_fwd[(uint64_t)r * a.n_refs + x];
+    if (ll >= ylog - 20.0) a.weight[(uint64_t)r * a.n_refs + x] = 1.0;  // marks "run Backward"
+    ylog = lse2(tab, ylog, ll);
+  }
+  // references outside the input order keep LL = -inf (xyLogLike initialisation, :2245)
+  uint32_t* out = a.order_out + (uint64_t)r * a.n_refs;
+  uint32_t n = 0;
+  for (uint32_t x = 0; x < a.n_refs; ++x) {
+    bool listed = !a.order_in;
+    for (uint32_t k = 0; !listed && k < nord; ++k) listed = a.order_in[(uint64_t)r * a.n_refs + k] == x;
+    const uint64_t p = (uint64_t)r * a.n_refs + x;
+    const double ll = listed ? a.pair_fwd[p] : QF_NEG_INF;
+    if (!listed) a.pair_fwd_out[p] = QF_NEG_INF; else a.pair_fwd_out[p] = ll;
+    a.weight[p] = (a.weight[p] != 0.0 && ll > QF_NEG_INF) ? exp(ll - ylog) : 0.0;
+    if (!(ll < ylog - 20.0)) {  // insertion sort, LL descending (ties: lower index first)
+      uint32_t k = n++;
+      while (k > 0) {
+        const uint32_t y = out[k - 1];
+        const double lly = a.pair_fwd_out[(uint64_t)r * a.n_refs + y];
+        if (lly >= ll) break;
+        out[k] = y;
+        --k;
+      }
+      out[k] = x;
+    }
+  }
+  a.order_n_out[r] = n;
+  a.read_loglike[r] = ylog;
+}
+
+// Backward sweep.  Lane l handles column j = yLen - (t - (G-1-l)); slots run from high diagonal to low, so
+//   (i+1,j+1): same diagonal, previous step (own registers)
+//   (i+1,j  ): diagonal d+1, same column   (own slot b+1 this step, or lane l+1's slot 0 from the previous step)
+//   (i,  j+1): diagonal d-1, next column   (own slot b-1 from the previous step, or lane l-1's last slot, which that
+//                                           lane finishes first in this very step)
+// Each cell is treated as a SOURCE: its Backward values are the lse of (transition + emission + Backward of the
+// destination), and the expected count of each of those transitions is exp(F_src + term - F_result) — the same
+// operands, in the same association, as transCount (src/qmodel.cpp:1504-1510).
+template <int G, int B>
+__global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
+  constexpr int UPW = 64 / G;
+  constexpr int RING = 2 * G;      // per-unit ring of per-column count partials (8 doubles each)
+  __shared__ double s_ring[4][UPW][RING][8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int grp = lane / G, l = lane % G, rl = G - 1 - l;
+  const uint32_t uidx = wave * UPW + grp;
+  bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0;
+  int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, fw_off = 0;
+  double Fres = 0, wgt = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb);
+    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
+    dlo = u.dlo; dhi = u.dhi; fw_off = u.tb_off;
+    Fres = a.pair_fwd[u.pair];
+    wgt = a.pair_weight[u.pair];
+    if (!(wgt > 0.0) || !(Fres > QF_NEG_INF)) active = false;  // pruned pair: no Backward (qmodel.cpp:2252)
+  }
+  int T = active ? yLen + G - 1 : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+  if (T == 0) return;
+  double (*ring)[8] = s_ring[wv][grp];
+  for (int c = l; c < RING * 8; c += G) (&ring[0][0])[c] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  const int d0 = dlo + l * B;
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const double* __restrict__ tab = a.lse;
+  const uint32_t Kg = a.dp.Kg, Km = a.Km;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  const double* __restrict__ fw = a.fw + fw_off;
+  double* __restrict__ cnt = a.counts;
+  const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
+
+  double Bm[B], Bi[B], Bd[B];   // Backward values of this lane's diagonals at the column of its previous step
+#pragma unroll
+  for (int b = 0; b < B; ++b) Bm[b] = Bi[b] = Bd[b] = QF_NEG_INF;
+  double pubD = QF_NEG_INF;     // slot 0's del after this lane's latest step (for lane l-1)
+  double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
+  uint32_t wNext = 0;           // context word of column j+1 (this lane's previous step)
+  uint32_t gkEnd = 0;
+
+  for (int t = 0; t < T; ++t) {
+    const int j = yLen - (t - rl);
+    const bool colvalid = active && j >= 1 && j <= yLen;
+    const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+    const uint32_t gk = w >> 24;
+    if (j == yLen) gkEnd = gk;
+    const double m2m = trans[gk], m2i = trans[Kg + gk], m2d = trans[2 * Kg + gk];
+    const uint32_t erowN4 = (wNext & 0x7FFFu) * 4u;
+    const double insEN = eins[(wNext >> 15) & 0x1FFu];
+    // (i+1, j) for the top slot: lane l+1's slot 0 at column j, finished in the previous step
+    double hiD = __shfl_down(pubD, 1, G);
+    if (l == G - 1) hiD = QF_NEG_INF;
+    double pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // match-by-token[4], insert, m2m, m2i, m2d partial counts (source column j)
+    double pc0[4] = {0, 0, 0, 0};             // start -> mat(i,1) counts by token (source "column 0")
+    double loI = QF_NEG_INF;                   // Bi(i, j+1) for slot 0: lane l-1's top slot, exchanged below
+    double nextD = hiD;                        // Bd(i+1, j): slot b+1 of this step, or lane l+1's slot 0
+#pragma unroll
+    for (int b = B - 1; b >= 0; --b) {
+      const int d = d0 + b, i = d + j;
+      const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
+      const uint32_t tokN = (i >= 0 && i < xLen) ? xt[i] : 0u;  // token of row i+1
+      const double eN = ematch[erowN4 + tokN];
+      const double BmN = Bm[b];                                   // Bm(i+1, j+1), own diagonal, previous step
+      const double BiN = b > 0 ? Bi[b - 1] : loI;                 // Bi(i, j+1), diagonal d-1 (not yet overwritten)
+      const double BdN = nextD;                                   // Bd(i+1, j), diagonal d+1
+      const double T_mm = (m2m + eN) + BmN, T_im = (i2m + eN) + BmN, T_dm = (d2m + eN) + BmN;
+      const double T_mi = (m2i + insEN) + BiN, T_ii = (i2i + insEN) + BiN;
+      const double T_md = m2d + BdN, T_dd = d2d + BdN;
+      const bool isEnd = j == yLen && (local || i == xLen);
+      const double T_me = isEnd ? trans[3 * Kg + gk] : QF_NEG_INF;
+      // accumulation order of the reference's push-style sweep (columns descending, rows descending): the
+      // contribution from mat(i+1,j+1) arrives first, then ins(i,j+1), then del(i+1,j), then the end transition.
+      // The table log-sum-exp is not associative at the 1e-4 level (its x >= 10 cut-off drops up to 4.5e-5 per
+      // call), so the order is part of the numerical contract.
+      double nbm = lse2(tab, lse2(tab, T_mm, T_mi), T_md);
+      if (isEnd) nbm = lse2(tab, nbm, T_me);
+      double nbi = lse2(tab, T_im, T_ii);
+      double nbd = lse2(tab, T_dm, T_dd);
+      if (!valid) { nbm = QF_NEG_INF; nbi = QF_NEG_INF; nbd = QF_NEG_INF; }
+      if (valid) {
+        const uint64_t base = ((uint64_t)(j - 1 + l) * B + b) * 3 * G + l;
+        const double Fm = fw[base] - Fres, Fi = fw[base + G] - Fres, Fd = fw[base + 2 * G] - Fres;
+        // NB (F - Fres) + T differs from the reference's (F + T) - Fres only in rounding
+        const double c_mm = wgt * exp(Fm + T_mm), c_im = wgt * exp(Fi + T_im), c_dm = wgt * exp(Fd + T_dm);
+        const double c_mi = wgt * exp(Fm + T_mi), c_ii = wgt * exp(Fi + T_ii);
+        const double c_md = wgt * exp(Fm + T_md), c_dd = wgt * exp(Fd + T_dd);
+        const double cmat = c_mm + c_im + c_dm;
+        pc[0] += tokN == 0 ? cmat : 0.0; pc[1] += tokN == 1 ? cmat : 0.0;
+        pc[2] += tokN == 2 ? cmat : 0.0; pc[3] += tokN == 3 ? cmat : 0.0;
+        pc[4] += c_mi + c_ii;
+        pc[5] += c_mm; pc[6] += c_mi; pc[7] += c_md;
+        acc_i2m += c_im; acc_d2m += c_dm; acc_i2i += c_ii; acc_d2d += c_dd;
+        if (isEnd) acc_m2e += wgt * exp(Fm + T_me);
+        if (j == 1 && (i == 1 || local)) {  // start -> mat(i,1), src/qmodel.cpp:1448-1454
+          const uint32_t tok = xt[i - 1];
+          const double S = ematch[(w & 0x7FFFu) * 4u + tok] + nbm;
+          const double cs = wgt * exp(S - Fres);
+          pc0[0] += tok == 0 ? cs : 0.0; pc0[1] += tok == 1 ? cs : 0.0;
+          pc0[2] += tok == 2 ? cs : 0.0; pc0[3] += tok == 3 ? cs : 0.0;
+          startv = lse2(tab, startv, S);
+        }
+      }
+      Bm[b] = nbm; Bi[b] = nbi; Bd[b] = nbd;
+      nextD = nbd;
+      if (b == B - 1) {  // lane l-1 (one column behind) has just produced Bi of its top slot at column j+1
+        loI = __shfl_up(nbi, 1, G);
+        if (l == 0) loI = QF_NEG_INF;
+      }
+    }
+    pubD = Bd[0];
+    // ---- per-column partials -> LDS ring; the last lane to touch a column flushes it
+    if (colvalid) {
+      double* slot = ring[j & (RING - 1)];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+      if (j == 1) {
+        double* slot0 = ring[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (pc0[c] != 0.0) unsafeAtomicAdd(&slot0[c], pc0[c]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (colvalid && l == 0) {  // rl = G-1: the last lane of the unit to process column j
+      for (int jj = j; jj >= (j == 1 ? 0 : j); --jj) {
+        double* slot = ring[jj & (RING - 1)];
+        // emission rows belong to the destination column jj+1; transition contexts to the source column jj
+        const uint32_t wd = ctx[jj];  // context word of column jj+1 (index jj); jj == yLen has no destination
+        const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+        const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
+        if (jj < yLen && q < (uint32_t)kNQualDev) {
+#pragma unroll
+          for (int tk = 0; tk < 4; ++tk)
+            if (slot[tk] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)tk * Km + mk) * kNQualDev + q], slot[tk]);
+          if (slot[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], slot[4]);
+        }
+        if (jj >= 1) {
+          const uint32_t gs = ctx[jj - 1] >> 24;
+          if (slot[5] != 0.0) unsafeAtomicAdd(&cnt[cTr + gs], slot[5]);
+          if (slot[6] != 0.0) unsafeAtomicAdd(&cnt[cTr + Kg + gs], slot[6]);
+          if (slot[7] != 0.0) unsafeAtomicAdd(&cnt[cTr + 2 * Kg + gs], slot[7]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) slot[c] = 0.0;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    wNext = w;
+  }
+  // context-free transitions, m2e and the Backward result (start), reduced over the unit's lanes
+  for (int o = 1; o < G; o <<= 1) {
+    acc_i2m += __shfl_xor(acc_i2m, o, G); acc_d2m += __shfl_xor(acc_d2m, o, G);
+    acc_i2i += __shfl_xor(acc_i2i, o, G); acc_d2d += __shfl_xor(acc_d2d, o, G);
+    acc_m2e += __shfl_xor(acc_m2e, o, G);
+    startv = lse2(tab, startv, __shfl_xor(startv, o, G));
+    gkEnd = max(gkEnd, (uint32_t)__shfl_xor((int)gkEnd, o, G));
+  }
+  if (active && l == 0) {
+    if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], acc_m2e);
+    if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], acc_d2d);
+    if (acc_d2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 1], acc_d2m);
+    if (acc_i2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 2], acc_i2i);
+    if (acc_i2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 3], acc_i2m);
+    a.units[uid].end_val = startv;  // Backward result of this band (diagnostic: should equal Forward's)
+  }
+}
+
+
+template <int G, int B>
+static void launch_fwd_gb(const FbArgs& a, hipStream_t s) {
+  const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
+  hipLaunchKernelGGL((k_forward_fill<G, B>), dim3(blocks), dim3(256), 0, s, a);
+}
+template <int G, int B>
+static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
+  const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
+  hipLaunchKernelGGL((k_backward_fill<G, B>), dim3(blocks), dim3(256), 0, s, a);
+}
+#define QF_FB_DISPATCH(FN)                         \
+  switch (cls) {                                   \
+    case 1: FN<16, 2>(a, s); break;                \
+    case 2: FN<16, 3>(a, s); break;                \
+    case 3: FN<16, 4>(a, s); break;                \
+    case 4: FN<16, 5>(a, s); break;                \
+    case 5: FN<16, 6>(a, s); break;                \
+    case 6: FN<16, 8>(a, s); break;                \
+    case 7: FN<64, 3>(a, s); break;                \
+    case 8: FN<64, 4>(a, s); break;                \
+    case 9: FN<64, 6>(a, s); break;                \
+    case 10: FN<64, 8>(a, s); break;               \
+    case 11: FN<64, 12>(a, s); break;              \
+    case 12: FN<64, 16>(a, s); break;              \
+  }
+void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
+  if (!a.n_cls_units) return;
+  QF_FB_DISPATCH(launch_fwd_gb)
+}
+void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s) {
+  if (!a.n_cls_units) return;
+  QF_FB_DISPATCH(launch_bwd_gb)
+}
+void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s) {
+  if (a.n_pairs) hipLaunchKernelGGL(k_pair_forward, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a, lse);
+}
+void launch_count_plan(const CountPlanArgs& a, hipStream_t s) {
+  if (a.n_reads) hipLaunchKernelGGL(k_count_plan, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
+}
+
+}  // namespace qf

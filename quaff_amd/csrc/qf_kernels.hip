@@ -204,6 +204,7 @@ template <bool MEM>
 __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   const uint32_t pair = a.pair_base + blockIdx.x, tid = threadIdx.x;
+  if (a.pair_skip && a.pair_skip[pair]) return;
   const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + wv;
   if (pidx >= n_pairs) return;
   const uint32_t pair = a.pair_base + pidx;
+  if (a.pair_skip && a.pair_skip[pair]) return;
   const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
@@ -543,9 +545,10 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
       } else {
         act = true;
+        if (a.storage_mode == 1) cls = fb_class(cls);
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
-        tbw = unit_tb_words(cls, (uint32_t)yLen);
+        tbw = a.storage_mode == 1 ? unit_fw_doubles(cls, (uint32_t)yLen) : unit_tb_words(cls, (uint32_t)yLen);
         cells = (dhi - dlo + 1 == xLen + yLen - 1) ? (unsigned long long)xLen * (unsigned long long)yLen
                                                     : band_cells(dlo, dhi, xLen, yLen);
         atomicAdd(&s_cells[cls], cells);

@@ -49,6 +49,8 @@ struct SeedArgs {
   uint32_t* pair_ndiag;        // [n_pairs]
   unsigned long long* pair_cells;  // [n_pairs] (zero-initialised)
   uint8_t* dump_cover;         // optional [nd] membership of a single pair
+  const uint8_t* pair_skip;    // optional [n_pairs]: 1 = do not seed this pair (train: pruned references)
+  int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
   int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
   BatchCounters* bc;
 };
@@ -65,6 +67,38 @@ struct FillArgs {
   const uint32_t* ctx;         // offset past the front pad
   uint32_t* tb;
   DpParams dp;
+};
+
+struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
+  uint32_t n_cls_units, n_refs;
+  const uint32_t* cls_list;
+  Unit* units;
+  const uint64_t* ref_off;
+  const uint8_t* ref_tok;
+  const uint64_t* read_off;
+  const uint32_t* ctx;
+  double* fw;                  // Forward matrix, unit u at fw + units[u].tb_off
+  const double* lse;           // 100001-entry log(1+exp(-x)) table
+  DpParams dp;
+  const double* pair_fwd;      // [n_pairs] Forward result (Backward only)
+  const double* pair_weight;   // [n_pairs] posterior weight, 0 = no Backward
+  double* counts;              // flattened weighted QuaffCounts accumulators
+  uint32_t Km;
+};
+
+struct CountPlanArgs {
+  uint32_t n_reads, n_refs;
+  int use_null;
+  const double* nll;
+  const double* lse;
+  const double* pair_fwd;
+  double* pair_fwd_out;
+  double* weight;
+  const uint32_t* order_in;    // optional [n_reads][n_refs]
+  const uint32_t* order_n_in;  // optional [n_reads]
+  uint32_t* order_out;
+  uint32_t* order_n_out;
+  double* read_loglike;
 };
 
 struct AlignRec {
@@ -101,6 +135,10 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
 void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s);
 void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s);
 void launch_finalize(const FinalArgs& a, hipStream_t s);
+void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s);
+void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s);
+void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s);
+void launch_count_plan(const CountPlanArgs& a, hipStream_t s);
 void launch_select(const FinalArgs& a, hipStream_t s);
 void launch_traceback(const FinalArgs& a, hipStream_t s);
 

@@ -1,0 +1,126 @@
+"""GPU parity for the Forward-Backward E-step (quaff count / train): HIP path through the C ABI vs the oracle's
+QuaffCountingTask restatement.  Tolerance 1e-4 relative (BASELINE.json north_star): the reference's own table
+log-sum-exp carries that much error, and the GPU re-associates the count sums."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import rand_seq, make_reads
+from tests.test_gpu_align import NULL_JSON, DEFAULT_JSON, both_strands, synth_params_json
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import quaff_amd as Q
+    c = Q.Context(0)
+    c.set_params_json(None)
+    c.set_null_json(NULL_JSON)
+    yield c
+    c.close()
+
+
+def oracle_estep(refs, reads, sc, null, cfg, orders=None, use_null=True):
+    tot = np.zeros(O.counts_size(sc.Km, sc.Kg))
+    ylogs, new_orders, fwd = [], [], []
+    for r, read in enumerate(reads):
+        c, yl, no = O.count_read(refs, read, sc, null, cfg, None if orders is None else orders[r], use_null)
+        tot += c
+        ylogs.append(yl)
+        new_orders.append(no)
+    return tot, np.array(ylogs), new_orders
+
+
+def assert_counts_close(got, want, what=""):
+    scale = max(1.0, np.abs(want).max())
+    bad = np.abs(got - want) > RTOL * np.maximum(np.abs(want), 1e-3 * scale)
+    assert not bad.any(), (what, np.flatnonzero(bad)[:10], got[bad][:5], want[bad][:5])
+
+
+def run_case(ctx, refs, reads, sc, null, cfg_kw=None, orders=None, force=False):
+    import quaff_amd as Q
+    cfg_kw = cfg_kw or {}
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    res = ctx.count_resident(Q.DPConfig(**cfg_kw), force=force, sort_order=orders)
+    ocfg = O.DPConfig(local=cfg_kw.get("local", True), kmer_threshold=cfg_kw.get("kmer_threshold", 20),
+                      band=cfg_kw.get("band_size", 64), kmer_len=cfg_kw.get("kmer_len", 6))
+    want, ylogs, new_orders = oracle_estep(refs, reads, sc, null, ocfg, orders, use_null=not force)
+    np.testing.assert_allclose(res["read_loglike"], ylogs, rtol=RTOL)
+    assert abs(res["loglike"] - ylogs.sum()) <= RTOL * abs(ylogs.sum())
+    assert_counts_close(res["counts"], want, "counts")
+    assert res["sort_order"] == new_orders
+    return res, want
+
+
+def test_count_small_both_strands(ctx):
+    rng = np.random.default_rng(31)
+    ref = rand_seq(rng, 1500)
+    sc, null = O.Scores(O.Params.from_json(DEFAULT_JSON)), O.NullParams.from_json(NULL_JSON)
+    reads = make_reads(rng, ref, 10, 280)
+    refs = both_strands(ref)
+    res, want = run_case(ctx, refs, reads, sc, null)
+    # Forward per pair against the oracle, and emitted-base conservation
+    for r, read in enumerate(reads):
+        rc = O.ReadCtx(read, sc)
+        for x, rf in enumerate(refs):
+            xt = O.tokens(rf.seq)
+            f, _, _ = O.forward_backward(xt, rc, sc, O.envelope(xt, rc.tok, O.DPConfig(), 48), want_back=False)
+            assert abs(res["forward"][r, x] - f) <= RTOL * abs(f), (r, x)
+    ne = (4 + 4 * sc.Km) * O.NQUAL
+    assert abs(res["counts"][:ne].sum() - want[:ne].sum()) < 1e-3 * want[:ne].sum()
+    # second EM iteration: feed the pruned order back (wrong-strand references drop out)
+    orders = res["sort_order"]
+    assert all(len(o) == 1 for o in orders)
+    res2, _ = run_case(ctx, refs, reads, sc, null, orders=orders)
+    assert np.all(np.isneginf(res2["forward"][np.arange(10), 1 - np.array([o[0] for o in orders])]))
+
+
+def test_count_force_global_and_bands(ctx):
+    rng = np.random.default_rng(32)
+    ref = rand_seq(rng, 900)
+    sc, null = O.Scores(O.Params.from_json(DEFAULT_JSON)), O.NullParams.from_json(NULL_JSON)
+    reads = make_reads(rng, ref, 6, 300)[::2]
+    run_case(ctx, [O.FastSeq("ref", ref)], reads, sc, null, force=True)
+    run_case(ctx, [O.FastSeq("ref", ref)], reads, sc, null, cfg_kw=dict(band_size=24, kmer_threshold=10))
+    from tests.helpers import mutate, rand_qual
+    greads = [O.FastSeq("g%d" % n, s, rand_qual(rng, len(s))) for n, s in enumerate(mutate(rng, ref) for _ in range(3))]
+    run_case(ctx, [O.FastSeq("ref", ref)], greads, sc, null, cfg_kw=dict(local=False))
+
+
+def test_count_order2(ctx):
+    rng = np.random.default_rng(33)
+    pj = synth_params_json(rng, 3, 2)
+    sc, null = O.Scores(O.Params.from_json(pj)), O.NullParams.from_json(NULL_JSON)
+    ctx.set_params_json(pj)
+    try:
+        ref = rand_seq(rng, 1000)
+        run_case(ctx, both_strands(ref), make_reads(rng, ref, 6, 250), sc, null)
+    finally:
+        ctx.set_params_json(None)
+
+
+def test_c8f30_counts_golden_through_gpu(ctx):
+    """The reference's count golden (Makefile:146-147) with the HIP path doing Forward-Backward: 6 s.f. text."""
+    import quaff_amd as Q
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    reads = O.read_fastx(os.path.join(golden, "c8f30.fastq.gz"))
+    null = O.NullParams.fit(reads)
+    ctx.set_null_json(null.to_json())
+    try:
+        ctx.set_refs([reads[0].seq])
+        ctx.upload_reads([reads[0].seq], [reads[0].qual])
+        res = ctx.count_resident(Q.DPConfig(kmer_threshold=-1, max_size=10 << 20))
+        want = open(os.path.join(golden, "c8f30-self-counts.json")).read()
+        got = O.param_counts_json(res["counts"], 1, 0)
+        if got != want:   # allow last-digit differences of the 6-s.f. rendering (tolerance 1e-4)
+            import re
+            g, w = (list(map(float, re.findall(r"-?\d+\.?\d*(?:e[-+]?\d+)?", t))) for t in (got, want))
+            assert len(g) == len(w)
+            np.testing.assert_allclose(g, w, rtol=RTOL, atol=1e-6)
+    finally:
+        ctx.set_null_json(NULL_JSON)
