@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--band", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="testing only: every rank uses GPU 0 (rehearse the N>1 path on a one-GPU box)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = this process's CPU share (at most 16)")
     return ap.parse_args()
 
@@ -87,8 +89,12 @@ def main():
     import numpy as np
     import quaff_amd as Q
     from quaff_amd import api, dist
+    if a.single_device:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     if world > 1:
-        dist.init("nccl")                     # nccl == RCCL on ROCm; one process per GPU
+        # nccl == RCCL on ROCm, one process per GPU (RCCL refuses two ranks on one GPU, so the rehearsal uses gloo)
+        dist.init("gloo" if a.single_device else "nccl")
 
     ctx = Q.Context(local_rank)
     ctx.set_params_json(None)
