@@ -221,7 +221,7 @@ const char* qf_fill_class_name(uint32_t cls) {
   static std::string names[kNumClasses];
   if (cls >= (uint32_t)kNumClasses) return nullptr;
   if (names[cls].empty())
-    names[cls] = cls == 0 ? std::string("k_viterbi_single")
+    names[cls] = cls == 0 ? std::string("k_viterbi_single") : cls == (uint32_t)kRowClass ? std::string("k_viterbi_rows")
                           : "k_viterbi_fill<" + std::to_string(fill_class((int)cls).G) + "," + std::to_string(fill_class((int)cls).B) + ">";
   return names[cls].c_str();
 }
@@ -479,9 +479,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
     if (int rc = read_counters(c, bc)) return rc;
   }
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
-  if (bc.error & 2u)
-    return fail(c, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels (" +
-                                           std::to_string(kMaxBandDiagSpace) + "); the row-space full-DP kernel is not built yet");
+  if (bc.error & 2u) return fail(c, QF_ERR_UNSUPPORTED, "unsupported band of " + std::to_string(bc.error_detail) + " diagonals");
   if (bc.error & 8u)
     return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
   if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
@@ -534,6 +532,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   fin.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
   fin.nll = c->d_nll.as<double>();
   fin.read_off = c->d_roff.as<uint64_t>();
+  fin.ref_off = c->d_ref_off.as<uint64_t>();
   fin.tb = c->d_tb.as<uint32_t>();
   fin.bc = c->d_bc.as<BatchCounters>();
   launch_finalize(fin, c->stream);

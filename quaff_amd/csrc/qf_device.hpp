@@ -35,18 +35,52 @@ struct Unit {
 // Fill-kernel classes: class 0 = single diagonal (one lane per unit); class c>0 = G lanes x B
 // diagonals per lane.  Kept in one table so host and device agree.
 struct FillClass { int G, B; };
-constexpr int kNumClasses = 13;
+constexpr int kNumClasses = 14;
+constexpr int kRowClass = 13;   // row-space kernel: bands wider than the diagonal-space kernels take (full DP)
 __host__ __device__ constexpr FillClass fill_class(int c) {
   constexpr FillClass t[kNumClasses] = {{1, 1},  {16, 2}, {16, 3}, {16, 4}, {16, 5},  {16, 6},  {16, 8},
-                                        {64, 3}, {64, 4}, {64, 6}, {64, 8}, {64, 12}, {64, 16}};
+                                        {64, 3}, {64, 4}, {64, 6}, {64, 8}, {64, 12}, {64, 16},
+                                        {64, 8}};
   return t[c];
 }
 constexpr int kMaxBandDiagSpace = 64 * 16;  // widest band the diagonal-space kernels take
 __host__ __device__ inline int classify_width(int W) {
   if (W <= 1) return 0;
-  for (int c = 1; c < kNumClasses; ++c)
+  for (int c = 1; c < kRowClass; ++c)
     if (fill_class(c).G * fill_class(c).B >= W) return c;
-  return -1;  // needs the row-space kernel
+  return kRowClass;
+}
+
+// Row-space geometry (class kRowClass): the band's rows [ilo, ihi] are cut into stripes of kRowStripe rows; stripe s
+// sweeps the columns [jlo, jhi] that its rows' band segments cover.
+constexpr int kRowStripe = 64 * 8;
+struct RowGeom { int ilo, ihi, nStripes; };
+__host__ __device__ inline RowGeom row_geom(int dlo, int dhi, int xLen, int yLen) {
+  RowGeom g;
+  g.ilo = 1 + dlo > 1 ? 1 + dlo : 1;
+  g.ihi = yLen + dhi < xLen ? yLen + dhi : xLen;
+  g.nStripes = g.ihi >= g.ilo ? (g.ihi - g.ilo + kRowStripe) / kRowStripe : 0;
+  return g;
+}
+__host__ __device__ inline void row_stripe_cols(const RowGeom& g, int s, int dlo, int dhi, int yLen, int& jlo, int& jhi) {
+  const int i0 = g.ilo + s * kRowStripe, i1 = i0 + kRowStripe - 1 < g.ihi ? i0 + kRowStripe - 1 : g.ihi;
+  jlo = i0 - dhi > 1 ? i0 - dhi : 1;
+  jhi = i1 - dlo < yLen ? i1 - dlo : yLen;
+}
+// storage of a row-space unit, in 4-byte words: [ (nStripes+1) u64 stripe offsets | 2 boundary rows x 3 states x
+// (yLen+2) doubles | per stripe: steps x 64 traceback words ]
+__host__ __device__ inline uint64_t row_header_words(const RowGeom& g, int yLen) {
+  return 2ull * (g.nStripes + 1) + 2ull * 2 * 3 * (uint64_t)(yLen + 2);
+}
+__host__ __device__ inline uint64_t row_unit_words(int dlo, int dhi, int xLen, int yLen) {
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  uint64_t w = row_header_words(g, yLen);
+  for (int s = 0; s < g.nStripes; ++s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + 63) * 64;
+  }
+  return w;
 }
 // traceback words a unit occupies
 __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {

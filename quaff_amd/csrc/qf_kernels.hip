@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
       const int xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]);
       yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
       cls = classify_width(dhi - dlo + 1);
+      if (cls == kRowClass && a.storage_mode == 1) cls = -1;  // Forward-Backward has no row-space kernel yet
       if (cls < 0) {
         atomicOr(&a.bc->error, 2u);
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
@@ -548,7 +549,10 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         if (a.storage_mode == 1) cls = fb_class(cls);
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
-        tbw = a.storage_mode == 1 ? unit_fw_doubles(cls, (uint32_t)yLen) : unit_tb_words(cls, (uint32_t)yLen);
+        tbw = a.storage_mode == 1 ? unit_fw_doubles(cls, (uint32_t)yLen)
+              : cls == kRowClass  ? row_unit_words(dlo, dhi, xLen, yLen)
+                                  : unit_tb_words(cls, (uint32_t)yLen);
+        tbw = (tbw + 1) & ~1ull;  // keep every unit 8-byte aligned (row-space units hold doubles)
         cells = (dhi - dlo + 1 == xLen + yLen - 1) ? (unsigned long long)xLen * (unsigned long long)yLen
                                                     : band_cells(dlo, dhi, xLen, yLen);
         atomicAdd(&s_cells[cls], cells);
@@ -826,6 +830,151 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-space Viterbi fill for bands wider than 1024 diagonals (-kmatchoff, or the full-envelope fallback of short
+// sequences against long references).  One wavefront per unit; the band's rows are cut into stripes of 64 lanes x 8
+// rows.  Lane l owns 8 consecutive rows and at step t is at column jlo + t - l, so
+//   ins(i,j) <- (i,  j-1): own registers (previous step)
+//   del(i,j) <- (i-1,j  ): own slot b-1 this step, or lane l-1's last row, which it finished one step ago
+//   mat(i,j) <- (i-1,j-1): own slot b-1 before this step's update, or lane l-1's last row two steps ago
+// The last row of a stripe is kept in a global boundary buffer for the next stripe (ping-pong).  Same arithmetic,
+// candidate order and 4-bit traceback records as k_viterbi_fill.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_viterbi_rows(FillArgs a) {
+  constexpr int G = 64, B = 8, S = kRowStripe;
+  const uint32_t uidx = blockIdx.x;
+  if (uidx >= a.n_cls_units) return;
+  const int l = threadIdx.x;
+  const uint32_t uid = a.cls_list[uidx];
+  const Unit u = a.units[uid];
+  const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+  const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
+  const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
+  const int dlo = u.dlo, dhi = u.dhi;
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  uint32_t* base = a.tb + u.tb_off;
+  unsigned long long* stripe_off = (unsigned long long*)base;                 // [nStripes+1]
+  double* bnd = (double*)(base + 2ull * (g.nStripes + 1));                   // [2][3][yLen+2]
+  uint32_t* tbw = base + row_header_words(g, yLen);
+  const size_t bndStride = 3ull * (yLen + 2);
+  // stripe offsets (lane 0) and the row-0 boundary (-inf)
+  if (l == 0) {
+    unsigned long long w = 0;
+    for (int s = 0; s < g.nStripes; ++s) {
+      int jlo, jhi;
+      row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+      stripe_off[s] = w;
+      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + 63) * 64;
+    }
+    stripe_off[g.nStripes] = w;
+  }
+  for (size_t c = l; c < bndStride; c += 64) bnd[c] = QF_NEG_INF;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  double bestEnd = QF_NEG_INF;
+  uint32_t bestI = 0;
+  unsigned long long woff = 0;
+
+  for (int s = 0; s < g.nStripes; ++s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    const int i0 = g.ilo + s * S + l * B;           // this lane's first row
+    const double* __restrict__ bprev = bnd + (size_t)(s & 1) * bndStride;      // last row of the previous stripe
+    double* __restrict__ bnext = bnd + (size_t)((s + 1) & 1) * bndStride;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (jhi < jlo) {  // no cell of this stripe is inside the band: its last row is all -inf
+      for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      continue;
+    }
+    for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
+    uint32_t tk[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) tk[b] = (i0 + b >= 1 && i0 + b <= xLen) ? xt[i0 + b - 1] : 0u;
+    double M[B], I[B], D[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
+    double p1M = QF_NEG_INF, p1D = QF_NEG_INF;                     // last row, column of the previous step
+    double p2M = QF_NEG_INF, p2I = QF_NEG_INF, p2D = QF_NEG_INF;   // last row, column of two steps ago
+    double p1I = QF_NEG_INF;
+    const int steps = jhi - jlo + 1 + G - 1;
+    for (int t = 0; t < steps; ++t) {
+      const int j = jlo + t - l;
+      const bool colvalid = j >= jlo && j <= jhi;
+      const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+      const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
+      const uint32_t gp = j > 1 ? (ctx[min(j - 2, yLen + 4)] >> 24) : 0u;  // yIndelKmer[j-1]; padded 0 for j == 1
+      const double m2m = trans[gp], m2i = trans[Kg + gp], m2d = trans[2 * Kg + gk];
+      const double insE = eins[insrow];
+      // row above slot 0: lane l-1's last row (column j one step ago, column j-1 two steps ago) or the boundary
+      double upM = __shfl_up(p1M, 1, G), upD = __shfl_up(p1D, 1, G);
+      double dgM = __shfl_up(p2M, 1, G), dgI = __shfl_up(p2I, 1, G), dgD = __shfl_up(p2D, 1, G);
+      if (l == 0) {
+        const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
+        upM = bprev[jc]; upD = bprev[2 * (yLen + 2) + jc];
+        dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
+      }
+      uint32_t tbword = 0;
+      double aboveM = upM, aboveD = upD;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int i = i0 + b, dgl = i - j;
+        const bool valid = colvalid && i >= 1 && i <= xLen && dgl >= dlo && dgl <= dhi;
+        const double e = ematch[erow4 + tk[b]];
+        const double oM = M[b], oI = I[b], oD = D[b];   // (i, j-1)
+        const double tM = (dgM + m2m) + e, tI = (dgI + i2m) + e, tD = (dgD + d2m) + e;
+        double nm = tM;
+        uint32_t sm = 0;
+        if (tI > nm) { nm = tI; sm = 1; }
+        if (tD > nm) { nm = tD; sm = 2; }
+        if (j == 1 && (i == 1 || local) && e > nm) { nm = e; sm = 3; }
+        const double cM = (oM + m2i) + insE, cI = (oI + i2i) + insE;
+        double ni = cM;
+        uint32_t si = 0;
+        if (cI > ni) { ni = cI; si = 1; }
+        const double gM = aboveM + m2d, gD = aboveD + d2d;
+        double ndl = gM;
+        uint32_t sd = 0;
+        if (gD > ndl) { ndl = gD; sd = 1; }
+        if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+        M[b] = nm; I[b] = ni; D[b] = ndl;
+        dgM = oM; dgI = oI; dgD = oD;       // (i, j-1) is the diagonal neighbour of row i+1
+        aboveM = nm; aboveD = ndl;
+        tbword |= (sm | (si << 2) | (sd << 3)) << (4 * b);
+        if (j == yLen && valid && (local || i == xLen)) {
+          const double ev = nm + trans[3 * Kg + gk];
+          if (ev >= bestEnd) { bestEnd = ev; bestI = (uint32_t)i; }
+        }
+      }
+      p2M = p1M; p2I = p1I; p2D = p1D;
+      p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
+      if (colvalid) {
+        tbw[woff + (unsigned long long)t * G + l] = tbword;
+        if (l == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
+      }
+    }
+    woff += (unsigned long long)steps * G;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  for (int o = 1; o < G; o <<= 1) {
+    const double ov = __shfl_xor(bestEnd, o, G);
+    const uint32_t oi = __shfl_xor(bestI, o, G);
+    if (ov > bestEnd || (ov == bestEnd && oi > bestI)) { bestEnd = ov; bestI = oi; }
+  }
+  if (l == 0) {
+    a.units[uid].end_val = bestEnd;
+    a.units[uid].end_i = bestI;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pair-level result, best reference per read, traceback
 // ------------------------------------------------------------------------------------------------
 // result = max over the pair's bands; end cell = largest row among the maxima (the reference scans rows
@@ -890,8 +1039,19 @@ __global__ void k_traceback(FinalArgs a) {
   const uint32_t yLen = (uint32_t)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
   const FillClass fc = fill_class((int)u.cls);
   const uint32_t* __restrict__ tb = a.tb + u.tb_off;
+  const uint32_t xR = rec.ref;
+  const int xLenR = (int)(a.ref_off[xR + 1] - a.ref_off[xR]);
+  const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, (int)yLen) : RowGeom{0, 0, 0};
   auto nibble = [&](int i, int j) -> uint32_t {
     if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0xFu;
+    if (u.cls == (uint32_t)kRowClass) {
+      const int rr = i - rg.ilo, s = rr / kRowStripe, li = (rr % kRowStripe) / 8, b = rr % 8;
+      int jlo, jhi;
+      row_stripe_cols(rg, s, u.dlo, u.dhi, (int)yLen, jlo, jhi);
+      const unsigned long long* so = (const unsigned long long*)tb;
+      const uint32_t* words = tb + row_header_words(rg, (int)yLen);
+      return (words[so[s] + (unsigned long long)(j - jlo + li) * 64 + li] >> (4 * b)) & 0xFu;
+    }
     const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
     const uint64_t t = (uint64_t)(j - 1 + l);
     const uint64_t w = fc.B > 8 ? (t * fc.G + l) * 2 + (b >> 3) : t * fc.G + l;
@@ -964,6 +1124,7 @@ void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s)
     case 10: launch_fill_gb<64, 8>(a, gapctx, s); break;
     case 11: launch_fill_gb<64, 12>(a, gapctx, s); break;
     case 12: launch_fill_gb<64, 16>(a, gapctx, s); break;
+    case 13: hipLaunchKernelGGL(k_viterbi_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); break;
   }
 }
 

@@ -117,6 +117,7 @@ struct FinalArgs {
   uint32_t* pair_end_unit;
   const double* nll;
   const uint64_t* read_off;
+  const uint64_t* ref_off;
   AlignRec* recs;
   const uint32_t* tb;
   uint32_t* runs_tmp;

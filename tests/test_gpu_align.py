@@ -137,11 +137,8 @@ def test_align_ragged_lengths_and_bands(ctx):
     refs = [O.FastSeq("ref", ref)]
     for kw in (dict(band_size=20, kmer_threshold=8), dict(band_size=33, kmer_threshold=5), dict(band_size=100, kmer_threshold=10),
                dict(band_size=4, kmer_threshold=2, kmer_len=5)):
-        # reads shorter than 2(k+thr) fall back to the full envelope (ref+read-1 diagonals), which the
-        # diagonal-space kernels only take up to 1024 diagonals: keep those out of this test
-        minlen = 2 * (kw.get("kmer_len", 6) + kw["kmer_threshold"])
-        sub = [r for r in reads if len(r.seq) >= minlen]
-        check_against_oracle(ctx, refs, sub, kw, sc, null)
+        # reads shorter than 2(k+thr) fall back to the full envelope (3000+L-1 diagonals -> row-space kernel)
+        check_against_oracle(ctx, refs, reads, kw, sc, null)
 
 
 def test_align_global_noquals_printall(ctx):
@@ -165,6 +162,26 @@ def test_align_repeat_two_bands(ctx):
              enumerate(mutate(rng, unit, sub=0.02, ins=0.01, dele=0.01) for _ in range(5))]
     res = check_against_oracle(ctx, [O.FastSeq("ref", ref)], reads, dict(kmer_threshold=12, band_size=32), sc, null)
     assert res["n_units"] >= 3 * 5 - 2
+
+
+def test_align_full_dp_and_wide_bands(ctx):
+    """-kmatchoff (full DP), the short-read full-envelope fallback, and bands wider than 1024 diagonals: the row-space
+    kernel.  Includes a reference longer than one 512-row stripe and reads longer than one stripe's column span."""
+    rng = np.random.default_rng(26)
+    sc, null = oracle_model()
+    ref = rand_seq(rng, 1400)
+    reads = make_reads(rng, ref, 6, 180)
+    reads.append(O.FastSeq("tiny", ref[700:730], rand_qual(rng, 30)))
+    reads.append(O.FastSeq("one", "G", "5"))
+    check_against_oracle(ctx, both_strands(ref), reads, dict(sparse=False), sc, null)
+    check_against_oracle(ctx, [O.FastSeq("ref", ref)], reads[:4], dict(sparse=False, local=False), sc, null)
+    # sparse mode, reads shorter than 2(k+threshold) -> initFull against a 1400 bp reference (1400+L-1 diagonals)
+    shorts = [O.FastSeq("s%d" % n, ref[s:s + L], rand_qual(rng, L)) for n, (s, L) in enumerate(((5, 40), (900, 51), (1349, 51)))]
+    check_against_oracle(ctx, both_strands(ref), shorts, dict(), sc, null)
+    # a very wide seeded band (band size 1500) on a longer read
+    long_read = make_reads(rng, ref, 1, 1100)
+    check_against_oracle(ctx, [O.FastSeq("ref", ref)], long_read, dict(band_size=1500, kmer_threshold=10), sc, null)
+    check_against_oracle(ctx, [O.FastSeq("ref", ref)], long_read, dict(sparse=False), sc, null)
 
 
 def synth_params_json(rng, match_len, gap_len):
