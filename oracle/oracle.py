@@ -646,3 +646,129 @@ def param_counts_json(pc, match_len, gap_len):
     e = tr[4 * Kg:]
     o += '  "extendInsertNo": %s,\n  "extendInsertYes": %s,\n  "extendDeleteNo": %s,\n  "extendDeleteYes": %s }' % tuple(fmt(x) for x in e)
     return o
+
+
+# ------------------------------------------------------------------- overlap
+class OverlapScores:
+    """QuaffOverlapScores, src/qoverlap.cpp:9-75, for one strand flag."""
+
+    def __init__(self, params, sc, y_complemented):
+        self.Km, self.Kg, self.match_len, self.gap_len = sc.Km, sc.Kg, sc.match_len, sc.gap_len
+        self.y_complemented = bool(y_complemented)
+        self.mmi = np.zeros((sc.Km, sc.Km, NQ1, NQ1))
+        self.gap = np.zeros(3 * sc.Kg * sc.Kg + 6)
+        self.ins = sc.ins
+        lib().qo_overlap_scores(sc.Km, sc.Kg, (C.c_double * 4)(*params.refBase), (C.c_double * sc.Kg)(*params.beginInsert),
+                                (C.c_double * sc.Kg)(*params.beginDelete), C.c_double(params.extendInsert),
+                                C.c_double(params.extendDelete), _vp(sc.ins), _vp(sc.mat), int(self.y_complemented),
+                                _vp(self.mmi), _vp(self.gap))
+
+
+def overlap_pair(x, y, y_complemented, osc, sc, null, cfg):
+    """QuaffOverlapTask::run + QuaffOverlapViterbiMatrix (+alignment, scoreAdjustedAlignment),
+    src/qoverlap.cpp:77-302,457-464.  x, y: FastSeq (y is the sequence as stored, i.e. already reverse-complemented
+    when y_complemented).  Returns None if no finite path, else dict(result, score, xStart..yEnd, ops (raw states))."""
+    xt, yt = tokens(x.seq), tokens(y.seq)
+    xmk, xgk = kmers(xt, sc.match_len), kmers(xt, sc.gap_len)
+    xq = quals(x.qual) if (x.has_qual() and len(x.qual)) else None
+    yq = quals(y.qual) if (y.has_qual() and len(y.qual)) else None
+    if y_complemented:                     # :91-98: arrays of revcomp(y), reversed
+        yrt = tokens(revcomp_str(y.seq))
+        ytok_eff = yrt[::-1].copy()
+        ymk = kmers(yrt, sc.match_len)[::-1].copy()
+        ygk = kmers(yrt, sc.gap_len)[::-1].copy()
+    else:
+        ytok_eff, ymk, ygk = yt, kmers(yt, sc.match_len), kmers(yt, sc.gap_len)
+    d = envelope(xt, yt, cfg, 24)
+    xlen, ylen = len(xt), len(yt)
+    ops = C.create_string_buffer(xlen + ylen + 2)
+    xs, xe, ys, ye, nops = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-1)
+    lib().qo_overlap_viterbi.restype = C.c_double
+    end = lib().qo_overlap_viterbi(xlen, ylen, sc.Km, sc.Kg, _vp(xmk), _vp(xgk), _vp(xq), _vp(ymk), _vp(ygk), _vp(yq),
+                                   _vp(osc.mmi), _vp(osc.gap), _vp(d), len(d), 1, C.byref(xs), C.byref(xe), C.byref(ys),
+                                   C.byref(ye), ops, xlen + ylen + 2, C.byref(nops))
+    # xInsertScore / yInsertScore, :105-113 (sequential sums)
+    xins = 0.0
+    for i in range(xlen):
+        xins += sc.ins[xt[i], xq[i] if xq is not None else NQUAL]
+    yins = 0.0
+    for j in range(ylen):
+        yins += sc.ins[ytok_eff[j], yq[j] if yq is not None else NQUAL]
+    result = end + xins + yins
+    out = {"end": end, "result": result, "ndiag": len(d), "cells": envelope_cells(d, xlen, ylen)}
+    if not (end > NEG_INF):
+        return None
+    if nops.value < 0:
+        raise RuntimeError("oracle overlap traceback failed (%d)" % nops.value)
+    ynull = null.loglike(y.revcomp() if y_complemented else y)   # :295
+    score = result - null.loglike(x)
+    score -= ynull
+    out.update(score=score, xStart=xs.value, xEnd=xe.value, yStart=ys.value, yEnd=ye.value, ops=ops.raw[:nops.value].decode())
+    return out
+
+
+def overlap_rows(x, y, al):
+    """Gapped rows with the indel squashing of src/qoverlap.cpp:231-267: a run of adjacent insertions and deletions
+    (between two matches) is re-paired into aligned columns first, then surplus deletions, then surplus insertions."""
+    xr, yr, xq, yq = [], [], [], []
+    i, j = al["xStart"] - 1, al["yStart"] - 1
+    hx, hy = x.has_qual(), y.has_qual()
+    ops = al["ops"]
+    k = 0
+    while k < len(ops):
+        if ops[k] == "M":
+            xr.append(x.seq[i]); yr.append(y.seq[j]); xq.append(x.qual[i] if hx else ""); yq.append(y.qual[j] if hy else "")
+            i += 1; j += 1; k += 1
+            continue
+        e = k
+        while e < len(ops) and ops[e] != "M":
+            e += 1
+        nins = ops[k:e].count("I")
+        ndel = (e - k) - nins
+        shared = min(nins, ndel)
+        xs, ys = x.seq[i:i + ndel], y.seq[j:j + nins]
+        xqs, yqs = (x.qual[i:i + ndel] if hx else ""), (y.qual[j:j + nins] if hy else "")
+        # aligned pairs, then surplus deletions (x only), then surplus insertions (y only)
+        xr.append(xs[:shared] + xs[shared:] + "-" * (nins - shared))
+        yr.append(ys[:shared] + "-" * (ndel - shared) + ys[shared:])
+        if hx:
+            xq.append(xqs[:shared] + xqs[shared:] + "~" * (nins - shared))
+        if hy:
+            yq.append(yqs[:shared] + "~" * (ndel - shared) + yqs[shared:])
+        i += ndel; j += nins; k = e
+    return "".join(xr), "".join(yr), "".join(xq), "".join(yq)
+
+
+def overlap_stockholm(x, y, al):
+    """Alignment::writeStockholm (src/qmodel.cpp:553-606) for the read_x / read_y alignment of src/qoverlap.cpp:271-289."""
+    xrow, yrow, xq, yq = overlap_rows(x, y, al)
+    cons = "".join("-" if (a in "-." or b in "-.") else (a.upper() if a.upper() == b.upper() else ":") for a, b in zip(xrow, yrow))
+    names, data = ["read_x"], [xrow]
+    if x.has_qual():
+        names.append("#=GR read_x QS"); data.append(xq)
+    idx1 = len(names)
+    names.append("read_y"); data.append(yrow)
+    if y.has_qual():
+        names.append("#=GR read_y QS"); data.append(yq)
+    names.insert(idx1, "#=GC id"); data.insert(idx1, cons)
+    if x.has_qual():
+        names[0], names[1] = names[1], names[0]
+        data[0], data[1] = data[1], data[0]
+    nw = max(len(n) for n in names)
+    dw = max(nw, 79 - nw)
+    out = ["# STOCKHOLM 1.0", "#=GF Score " + fmt(al["score"]),
+           "#=GS CC read_x substr(%s,%d..%d)" % (x.name, al["xStart"], al["xEnd"]),
+           "#=GS CC read_y substr(%s,%d..%d)" % (y.name, al["yStart"], al["yEnd"])]
+    for col in range(0, len(xrow), dw):
+        if col > 0:
+            out.append("")
+        for n, d in zip(names, data):
+            out.append(n.ljust(nw) + " " + d[col: col + dw])
+    out.append("//")
+    return "\n".join(out) + "\n"
+
+
+def overlap_task_pairs(n_originals, n_total):
+    """Pair enumeration of QuaffOverlapScheduler (src/qoverlap.cpp:475-480,528-547): (nx, ny, yComplemented) with
+    0 <= nx <= N-2, nx < ny < n_total, yComplemented = ny >= N."""
+    return [(nx, ny, ny >= n_originals) for nx in range(max(n_originals - 1, 0)) for ny in range(nx + 1, n_total)]

@@ -610,3 +610,169 @@ double qo_forward_backward(int xLen, int yLen, int Km, int Kg, int local,
     mx_free(&f);
     return fres;
 }
+
+/* ------------------------------------------------------------------------ */
+/* read-vs-read overlap: src/qoverlap.cpp                                    */
+/* ------------------------------------------------------------------------ */
+
+/* QuaffOverlapScores ctor, src/qoverlap.cpp:9-75.
+ *   mmi_out[Km][Km][95][95]: [qi][qj] = logSymQualPairProb; [qi][94] = logSymPairXQualProb; [94][qj] = ...YQualProb;
+ *                            [94][94] = logSymPairProb  (all "match minus insert")
+ *   gap_out: m2m[Kg][Kg] m2i[Kg][Kg] m2d[Kg][Kg] | i2m i2i i2d d2m d2i d2d   (3*Kg*Kg + 6 doubles)
+ * ins/mat/trans-free inputs are the QuaffScores tables of qo_build_scores. */
+void qo_overlap_scores(int Km, int Kg, const double *refBase, const double *beginInsert, const double *beginDelete,
+                       double extendInsert, double extendDelete, const double *ins, const double *mat,
+                       int yComplemented, double *mmi_out, double *gap_out)
+{
+    if (!lse_table) qo_lse_table();
+    double *gapOpen = (double *)malloc(sizeof(double) * Kg);
+    double pGapIsInsertSum = 0, gapAdjSum = 0;
+    for (int j = 0; j < Kg; ++j) {                      /* :24-32 */
+        const double readInsertProb = beginInsert[j];
+        const double readDeleteProb = (1 - beginInsert[j]) * beginDelete[j];
+        gapOpen[j] = readInsertProb + readDeleteProb;
+        const double pGapIsInsert = readInsertProb / gapOpen[j];
+        const double gapAdjacentProb = pGapIsInsert * readInsertProb + (1 - pGapIsInsert) * gapOpen[j] / (1 - extendDelete * (1 - gapOpen[j]));
+        pGapIsInsertSum += pGapIsInsert;                /* accumulate(..., 0.) in index order, :41,:44 */
+        gapAdjSum += gapAdjacentProb;
+    }
+    double *m2m = gap_out, *m2i = gap_out + Kg * Kg, *m2d = gap_out + 2 * Kg * Kg, *sc = gap_out + 3 * Kg * Kg;
+    for (int i = 0; i < Kg; ++i)
+        for (int j = 0; j < Kg; ++j) {                  /* :34-39 */
+            m2m[i * Kg + j] = log(1 - gapOpen[i]) + log(1 - gapOpen[j]);
+            m2i[i * Kg + j] = log(gapOpen[i]);
+            m2d[i * Kg + j] = log(1 - gapOpen[i]) + log(gapOpen[j]);
+        }
+    const double pGapIsInsert = pGapIsInsertSum / Kg;
+    const double meanGapLength = pGapIsInsert / extendInsert + (1 - pGapIsInsert) / extendDelete;
+    const double gapExtendProb = 1 / meanGapLength;
+    const double gapAdjacentProb = gapAdjSum / Kg;
+    sc[1] = sc[5] = log(gapExtendProb);                                   /* i2i = d2d */
+    sc[2] = sc[4] = log(1 - gapExtendProb) + log(gapAdjacentProb);       /* i2d = d2i */
+    sc[0] = sc[3] = log(1 - gapExtendProb) + log(1 - gapAdjacentProb);   /* i2m = d2m */
+    const size_t Q2 = (size_t)QO_NQ1 * QO_NQ1;
+    for (int i = 0; i < Km; ++i)
+        for (int j = 0; j < Km; ++j) {
+            const int iS = i & 3, jS = j & 3;          /* k-mer suffix = the emitted base (:54-58) */
+            double *t = mmi_out + ((size_t)i * Km + j) * Q2;
+            for (int a = 0; a < QO_NQ1; ++a) t[a * QO_NQ1 + QO_NQUAL] = NEG_INF;
+            for (int a = 0; a < QO_NQ1; ++a) t[QO_NQUAL * QO_NQ1 + a] = NEG_INF;
+            for (int ik = 0; ik < QO_NQUAL; ++ik)
+                for (int jk = 0; jk < QO_NQUAL; ++jk) {
+                    double mij = NEG_INF;
+                    for (int r = 0; r < 4; ++r) {
+                        const int yr = yComplemented ? 3 - r : r;
+                        mij = qo_lse(mij, log(refBase[r]) + mat[((size_t)r * Km + i) * QO_NQ1 + ik] + mat[((size_t)yr * Km + j) * QO_NQ1 + jk]);
+                    }
+                    const double *xi = ins + (size_t)iS * QO_NQ1, *yi = ins + (size_t)jS * QO_NQ1;
+                    t[ik * QO_NQ1 + jk] = mij - xi[ik] - yi[jk];
+                    t[ik * QO_NQ1 + QO_NQUAL] = qo_lse(t[ik * QO_NQ1 + QO_NQUAL], mij - xi[ik] - yi[QO_NQUAL]);
+                    t[QO_NQUAL * QO_NQ1 + jk] = qo_lse(t[QO_NQUAL * QO_NQ1 + jk], mij - xi[QO_NQUAL] - yi[jk]);
+                    t[QO_NQUAL * QO_NQ1 + QO_NQUAL] = qo_lse(t[QO_NQUAL * QO_NQ1 + QO_NQUAL], mij - xi[QO_NQUAL] - yi[QO_NQUAL]);
+                }
+        }
+    free(gapOpen);
+}
+
+typedef struct {
+    int xLen, yLen, Km, Kg;
+    const uint32_t *xmk, *xgk, *ymk, *ygk;   /* context k-mers; y-side already in the (possibly complemented) orientation */
+    const uint8_t *xq, *yq;                 /* NULL => no quality */
+    const double *mmi, *gap;
+} qo_opair;
+/* accessor swaps of src/qoverlap.h:46-50, replicated literally: i2mScore()=i2i, i2iScore()=i2m, i2dScore()=i2d,
+ * d2mScore()=d2i, d2iScore()=d2m, d2dScore()=d2d.  gap scalars: [0]=i2m [1]=i2i [2]=i2d [3]=d2m [4]=d2i [5]=d2d */
+#define O_SC(p) ((p)->gap + 3 * (p)->Kg * (p)->Kg)
+static inline double o_i2mScore(const qo_opair *p) { return O_SC(p)[1]; }
+static inline double o_i2iScore(const qo_opair *p) { return O_SC(p)[0]; }
+static inline double o_i2dScore(const qo_opair *p) { return O_SC(p)[2]; }
+static inline double o_d2mScore(const qo_opair *p) { return O_SC(p)[4]; }
+static inline double o_d2iScore(const qo_opair *p) { return O_SC(p)[3]; }
+static inline double o_d2dScore(const qo_opair *p) { return O_SC(p)[5]; }
+static inline int o_gx(const qo_opair *p, int i) { return i == 0 ? 0 : (int)p->xgk[i - 1]; }
+static inline int o_gy(const qo_opair *p, int j) { return j == 0 ? 0 : (int)p->ygk[j - 1]; }
+static inline double o_m2m(const qo_opair *p, int i, int j) { return p->gap[o_gx(p, i) * p->Kg + o_gy(p, j)]; }
+static inline double o_m2i(const qo_opair *p, int i, int j) { return p->gap[p->Kg * p->Kg + o_gx(p, i) * p->Kg + o_gy(p, j)]; }
+static inline double o_m2d(const qo_opair *p, int i, int j) { return p->gap[2 * p->Kg * p->Kg + o_gx(p, i) * p->Kg + o_gy(p, j)]; }
+static inline double o_emit(const qo_opair *p, int i, int j)   /* matchEmitScore, src/qoverlap.h:52-61 */
+{
+    const int qi = p->xq ? p->xq[i - 1] : QO_NQUAL, qj = p->yq ? p->yq[j - 1] : QO_NQUAL;
+    return p->mmi[((size_t)p->xmk[i - 1] * p->Km + p->ymk[j - 1]) * QO_NQ1 * QO_NQ1 + qi * QO_NQ1 + qj];
+}
+
+/* QuaffOverlapViterbiMatrix ctor (fill) + alignment() (end cell, traceback), src/qoverlap.cpp:77-290.
+ * Returns `end` (max over the last row / last column of mat; the caller adds the two insert scores);
+ * ops_out: raw traceback states 'M','I','D' in alignment order (before indel squashing). */
+double qo_overlap_viterbi(int xLen, int yLen, int Km, int Kg,
+                          const uint32_t *xmk, const uint32_t *xgk, const uint8_t *xq,
+                          const uint32_t *ymk, const uint32_t *ygk, const uint8_t *yq,
+                          const double *mmi, const double *gap, const int *diags, int nd,
+                          int want_tb, int *xStart, int *xEnd, int *yStart, int *yEnd, char *ops, int ops_cap, int *n_ops)
+{
+    qo_opair p = { xLen, yLen, Km, Kg, xmk, xgk, ymk, ygk, xq, yq, mmi, gap };
+    qo_matrix m;
+    mx_init(&m, diags, nd, xLen, yLen);
+    if (!lse_table) qo_lse_table();
+    double end = NEG_INF;
+    for (int j = 1; j <= yLen; ++j)
+        for (int a = 0; a < nd; ++a) {
+            const int d = diags[a], i = d + j;
+            if (i < 1 || i > xLen) continue;
+            const long c = (long)a * (yLen + 1) + j;
+            double mt = dmax(dmax(MAT(&m, i - 1, j - 1) + o_m2m(&p, i - 1, j - 1), DEL(&m, i - 1, j - 1) + o_d2mScore(&p)),
+                             INS(&m, i - 1, j - 1) + o_i2mScore(&p));
+            if (j == 1 || i == 1) mt = dmax(mt, 0.);
+            mt += o_emit(&p, i, j);
+            m.mat[c] = mt;
+            m.ins[c] = dmax(qo_lse(INS(&m, i, j - 1) + o_i2iScore(&p), DEL(&m, i, j - 1) + o_d2iScore(&p)), MAT(&m, i, j - 1) + o_m2i(&p, i, j - 1));
+            m.del[c] = dmax(qo_lse(DEL(&m, i - 1, j) + o_d2dScore(&p), INS(&m, i - 1, j) + o_d2iScore(&p)), MAT(&m, i - 1, j) + o_m2d(&p, i - 1, j));
+            if (j == yLen || i == xLen) end = dmax(end, mt);
+        }
+    if (n_ops) *n_ops = -1;
+    if (want_tb && end > NEG_INF) {
+        int xe = xLen, ye = yLen;
+        double best = MAT(&m, xLen, yLen), sc;
+        for (int ie = xLen; ie > 0; --ie) { sc = MAT(&m, ie, yLen); if (sc > best) { best = sc; xe = ie; ye = yLen; } }
+        for (int je = yLen; je > 0; --je) { sc = MAT(&m, xLen, je); if (sc > best) { best = sc; xe = xLen; ye = je; } }
+        int i = xe, j = ye, n = 0;
+        enum { Start, Match, Insert, Delete } state = Match;
+        char *rev = (char *)malloc((size_t)xLen + yLen + 2);
+        int bad = 0;
+        while (state != Start) {
+            double src = NEG_INF, e, cnd;
+            switch (state) {
+            case Match:
+                e = o_emit(&p, i, j); --i; --j; rev[n++] = 'M';
+                cnd = MAT(&m, i, j) + o_m2m(&p, i, j) + e; if (cnd > src) { src = cnd; state = Match; }
+                cnd = INS(&m, i, j) + o_i2mScore(&p) + e;  if (cnd > src) { src = cnd; state = Insert; }
+                cnd = DEL(&m, i, j) + o_d2mScore(&p) + e;  if (cnd > src) { src = cnd; state = Delete; }
+                if (j == 0 || i == 0) { if (e > src) { src = e; state = Start; } }
+                break;
+            case Insert:
+                --j; rev[n++] = 'I';
+                cnd = MAT(&m, i, j) + o_m2i(&p, i, j);     if (cnd > src) { src = cnd; state = Match; }
+                cnd = INS(&m, i, j) + o_i2iScore(&p);      if (cnd > src) { src = cnd; state = Insert; }
+                cnd = DEL(&m, i, j) + o_d2iScore(&p);      if (cnd > src) { src = cnd; state = Delete; }
+                break;
+            case Delete:
+                --i; rev[n++] = 'D';
+                cnd = MAT(&m, i, j) + o_m2d(&p, i, j);     if (cnd > src) { src = cnd; state = Match; }
+                cnd = INS(&m, i, j) + o_i2dScore(&p);      if (cnd > src) { src = cnd; state = Insert; }
+                cnd = DEL(&m, i, j) + o_d2dScore(&p);      if (cnd > src) { src = cnd; state = Delete; }
+                break;
+            default: break;
+            }
+            if (n > xLen + yLen || i < 0 || j < 0) { bad = 1; break; }
+        }
+        if (bad) *n_ops = -2;
+        else if (n > ops_cap) *n_ops = -3;
+        else {
+            *xStart = i + 1; *xEnd = xe; *yStart = j + 1; *yEnd = ye;
+            for (int a = 0; a < n; ++a) ops[a] = rev[n - 1 - a];
+            *n_ops = n;
+        }
+        free(rev);
+    }
+    mx_free(&m);
+    return end;
+}

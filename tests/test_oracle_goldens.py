@@ -38,6 +38,22 @@ def test_self_counts_golden(c8f30, golden):
     assert O.param_counts_json(tot, 1, 0) == open(os.path.join(golden, "c8f30-self-counts.json")).read()
 
 
+def test_self_overlap_golden(golden):
+    """quaff overlap c8f30 copy-of-c8f30 -kmatchmb 10 -fwdstrand == data/c8f30-self-overlap.json (Makefile:152-156;
+    the copy is the same read with `channel` -> `copy` in its name)."""
+    reads = O.read_fastx(os.path.join(golden, "c8f30.fastq.gz"))
+    cp = O.FastSeq(reads[0].name.replace("channel", "copy", 1), reads[0].seq, reads[0].qual)
+    seqs = [reads[0], cp]
+    p = O.Params.from_json(open(os.path.join(golden, "defaultparams.json")).read())
+    sc = O.Scores(p)
+    osc = O.OverlapScores(p, sc, False)
+    null = O.NullParams.fit(seqs)
+    assert O.overlap_task_pairs(2, 2) == [(0, 1, False)]
+    al = O.overlap_pair(seqs[0], seqs[1], False, osc, sc, null, O.DPConfig(kmer_threshold=-1, max_size=10 << 20))
+    assert O.fmt(al["score"]) == "6876.76" and O.cigar(al["ops"]) == "M6604"
+    assert O.overlap_stockholm(seqs[0], seqs[1], al) == open(os.path.join(golden, "c8f30-self-overlap.json")).read()
+
+
 def test_default_threshold_seeding_anchor(c8f30):
     """with the align default (threshold 20) c8f30 vs itself seeds one diagonal -> 65."""
     reads, sc, null, cfg = c8f30
