@@ -27,6 +27,10 @@
  *   QuaffCountingTask::run           src/qmodel.cpp:2238-2271 qf_count_resident (pruning, weights, new order)
  *   QuaffParamCounts(QuaffCounts)    src/qmodel.cpp:407-417   qf_count_result.counts layout
  *   QuaffTrainer::getCounts reduce   src/qmodel.cpp:2416-2422 sum over the batch (+ caller's all-reduce)
+ *   QuaffOverlapScores ctor          src/qoverlap.cpp:9-75    (built inside qf_overlap_resident, once per strand flag)
+ *   QuaffOverlapViterbiMatrix ctor   src/qoverlap.cpp:77-160  qf_overlap_resident (overlap fill kernel)
+ *   QuaffOverlapViterbiMatrix::alignment :162-290, scoreAdjustedAlignment :292-302   qf_overlap_resident
+ *   QuaffOverlapTask::run            src/qoverlap.cpp:457-464 qf_overlap_resident (one task per pair)
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative qf_status otherwise (message via qf_last_error); nothing throws or exits across
@@ -175,6 +179,38 @@ typedef struct qf_count_result {
 int qf_count_resident(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t flags, const uint32_t *sort_in,
                       const uint32_t *sort_n_in, qf_count_result *out);
 uint32_t qf_counts_size(const qf_ctx *ctx);
+
+/* ---- read-vs-read overlap (quaff overlap) -------------------------------------------------- */
+typedef struct qf_overlap_alignment {
+  uint32_t pair;             /* index into the pair list */
+  double viterbi;            /* QuaffOverlapViterbiMatrix::result (end + both insert scores) */
+  double score;              /* result - null(x) - null(y), scoreAdjustedAlignment */
+  uint32_t x_start, x_end, y_start, y_end;  /* 1-based closed intervals */
+  uint32_t n_columns, n_runs;
+  uint64_t run_offset;       /* first run in qf_overlap_result.state_runs */
+} qf_overlap_alignment;
+
+typedef struct qf_overlap_result {
+  uint32_t n_pairs;
+  const double *viterbi;         /* [n_pairs] -inf where no path exists */
+  const double *score;           /* [n_pairs] */
+  const uint64_t *cells;         /* [n_pairs] */
+  const uint32_t *n_diagonals;   /* [n_pairs] */
+  uint64_t total_cells;
+  uint32_t n_alignments;         /* pairs with a finite result, ordered by pair index */
+  const qf_overlap_alignment *alignments;
+  /* traceback STATE runs (length << 2 | state, 0=M 1=I 2=D) in alignment order, before the indel squashing of
+   * src/qoverlap.cpp:231-267 (a host-side re-pairing of adjacent I/D runs when the rows are written) */
+  const uint32_t *state_runs;
+  float ms_prep, ms_seed, ms_fill, ms_traceback, ms_total;
+  uint64_t traceback_bytes;
+} qf_overlap_result;
+
+/* Align pairs of the resident sequences (qf_upload_reads: originals followed, if wanted, by their reverse complements,
+ * as SeqList::loadSequences builds them).  pair_x / pair_y index the resident set; y_complemented[p] != 0 tells the
+ * scorer that y is a reverse-complemented read (QuaffOverlapScheduler: ny >= nOriginals). */
+int qf_overlap_resident(qf_ctx *ctx, const qf_dp_config *cfg, const uint32_t *pair_x, const uint32_t *pair_y,
+                        const uint8_t *y_complemented, uint32_t n_pairs, qf_overlap_result *out);
 
 /* Envelope only (DiagonalEnvelope::diagonals for pair (read, ref)); returns the number of
  * diagonals, writes at most cap of them.  For tests and debugging. */

@@ -65,10 +65,24 @@ class _CountResult(C.Structure):
                 ("ms_backward", C.c_float), ("ms_total", C.c_float)]
 
 
+class _OverlapAlignment(C.Structure):
+    _fields_ = [("pair", C.c_uint32), ("viterbi", C.c_double), ("score", C.c_double), ("x_start", C.c_uint32),
+                ("x_end", C.c_uint32), ("y_start", C.c_uint32), ("y_end", C.c_uint32), ("n_columns", C.c_uint32),
+                ("n_runs", C.c_uint32), ("run_offset", C.c_uint64)]
+
+
+class _OverlapResult(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint32), ("viterbi", C.POINTER(C.c_double)), ("score", C.POINTER(C.c_double)),
+                ("cells", C.POINTER(C.c_uint64)), ("n_diagonals", C.POINTER(C.c_uint32)), ("total_cells", C.c_uint64),
+                ("n_alignments", C.c_uint32), ("alignments", C.POINTER(_OverlapAlignment)),
+                ("state_runs", C.POINTER(C.c_uint32)), ("ms_prep", C.c_float), ("ms_seed", C.c_float),
+                ("ms_fill", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float), ("traceback_bytes", C.c_uint64)]
+
+
 EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
-           "qf_fill_class_name", "qf_count_resident", "qf_counts_size"]
+           "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident"]
 
 
 def load_library():
@@ -105,6 +119,8 @@ def load_library():
                                           C.c_void_p, C.c_char_p, C.c_size_t]
         L.qf_count_resident.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.POINTER(_CountResult)]
+        L.qf_overlap_resident.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                          C.POINTER(_OverlapResult)]
         L.qf_counts_size.restype = C.c_uint32
         L.qf_counts_size.argtypes = [C.c_void_p]
         L.qf_fill_class_name.restype = C.c_char_p
@@ -289,6 +305,30 @@ class Context:
                 "counts": arr(res.counts, res.counts_size), "loglike": res.loglike, "total_cells": int(res.total_cells),
                 "backward_cells": int(res.backward_cells), "forward_bytes": int(res.forward_bytes),
                 "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "forward", "plan", "backward", "total")}}
+
+    def overlap_resident(self, pairs, cfg=None):
+        """pairs: list of (x index, y index, y_complemented) over the resident sequences.  quaff overlap's defaults are
+        kmer_threshold=14 (DEFAULT_KMER_THRESHOLD, src/diagenv.h:15)."""
+        cfg = cfg or DPConfig(kmer_threshold=14)
+        px = np.array([q[0] for q in pairs], np.uint32)
+        py = np.array([q[1] for q in pairs], np.uint32)
+        pc = np.array([1 if q[2] else 0 for q in pairs], np.uint8)
+        res = _OverlapResult()
+        self._chk(self.L.qf_overlap_resident(self.h, C.byref(cfg), px.ctypes.data, py.ctypes.data, pc.ctypes.data, len(pairs),
+                                             C.byref(res)))
+        n = res.n_pairs
+        arr = lambda ptr, dt=None: np.ctypeslib.as_array(ptr, (n,)).copy() if n else np.zeros(0)
+        out = {"viterbi": arr(res.viterbi), "score": arr(res.score), "cells": arr(res.cells), "n_diagonals": arr(res.n_diagonals),
+               "total_cells": int(res.total_cells), "traceback_bytes": int(res.traceback_bytes),
+               "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "fill", "traceback", "total")}, "alignments": {}}
+        for a in range(res.n_alignments):
+            al = res.alignments[a]
+            runs = np.ctypeslib.as_array(C.cast(C.addressof(res.state_runs.contents) + 4 * al.run_offset,
+                                                C.POINTER(C.c_uint32)), (al.n_runs,)).copy() if al.n_runs else np.zeros(0, np.uint32)
+            out["alignments"][al.pair] = {"pair": al.pair, "result": al.viterbi, "score": al.score, "xStart": al.x_start,
+                                          "xEnd": al.x_end, "yStart": al.y_start, "yEnd": al.y_end,
+                                          "ops": "".join("MID"[int(r) & 3] * (int(r) >> 2) for r in runs)}
+        return out
 
     def envelope(self, read, ref, cfg=None):
         cfg = cfg or DPConfig()

@@ -73,7 +73,8 @@ struct qf_ctx {
   // batch state
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
       d_recs, d_runs_tmp, d_runs_out, d_cover, d_lse, d_fw, d_weight, d_fwd_out, d_counts, d_order_in, d_order_n_in,
-      d_order_out, d_order_n_out, d_rll, d_skip;
+      d_order_out, d_order_n_out, d_rll, d_skip, d_ctxc, d_ins_sum, d_ins_sum_c, d_nll_c, d_rbucket, d_rcursor, d_rpos,
+      d_px, d_py, d_pc, d_mmi0, d_mmi1, d_gap0, d_gap1, d_pair_result, d_pair_ij;
   // host results
   std::vector<double> h_viterbi, h_nll;
   std::vector<uint64_t> h_cells;
@@ -83,6 +84,10 @@ struct qf_ctx {
   std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
+  bool ov_scores[2] = {false, false};
+  int read_index_k = 0;
+  std::vector<double> h_ov_result, h_ov_score;
+  std::vector<qf_overlap_alignment> h_ov_align;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -143,7 +148,9 @@ void qf_ctx_destroy(qf_ctx* c) {
                     &c->d_pair_head, &c->d_pair_bands, &c->d_pair_nbands, &c->d_ovf, &c->d_pair_ndiag, &c->d_pair_cells, &c->d_pair_score, &c->d_pair_end_unit,
                     &c->d_bc, &c->d_tb, &c->d_recs, &c->d_runs_tmp, &c->d_runs_out, &c->d_cover, &c->d_lse, &c->d_fw,
                     &c->d_weight, &c->d_fwd_out, &c->d_counts, &c->d_order_in, &c->d_order_n_in, &c->d_order_out,
-                    &c->d_order_n_out, &c->d_rll, &c->d_skip})
+                    &c->d_order_n_out, &c->d_rll, &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
+                    &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
+                    &c->d_gap0, &c->d_gap1, &c->d_pair_result, &c->d_pair_ij})
     b->release();
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->cls_ev) if (ev) (void)hipEventDestroy(ev);
@@ -184,6 +191,7 @@ int qf_set_params_json(qf_ctx* c, const char* text) {
   HIPCHK(c, hipMemcpy(c->d_eins.p, s.ins.data(), s.ins.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_trans.p, s.trans.data(), s.trans.size() * 8, hipMemcpyHostToDevice));
   c->have_params = true;
+  c->ov_scores[0] = c->ov_scores[1] = false;
   return QF_OK;
 }
 
@@ -350,6 +358,7 @@ int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t
   HIPCHK(c, hipMemsetAsync(c->d_ctx.p, 0, (tot + 2 * kCtxPad) * 4, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->reads_have_qual = qual != nullptr;
+  c->read_index_k = 0;
   c->n_reads = n_reads;
   return QF_OK;
 }
@@ -850,6 +859,243 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   (void)hipEventElapsedTime(&out->ms_forward, c->ev[2], c->ev[3]);
   (void)hipEventElapsedTime(&out->ms_plan, c->ev[3], c->ev[4]);
   (void)hipEventElapsedTime(&out->ms_backward, c->ev[4], c->ev[5]);
+  (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
+  return QF_OK;
+}
+
+// ------------------------------------------------------------------------------ read-vs-read overlap
+static int ensure_lse(qf_ctx* c) {
+  if (c->lse_uploaded) return QF_OK;
+  const std::vector<double>& t = lse_table();
+  HIPCHK(c, c->d_lse.reserve(t.size() * 8));
+  HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+  c->lse_uploaded = true;
+  return QF_OK;
+}
+
+int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair_x, const uint32_t* pair_y,
+                        const uint8_t* y_comp, uint32_t n_pairs, qf_overlap_result* out) {
+  if (!c) return QF_ERR_ARG;
+  if (!cfg || !out) return fail(c, QF_ERR_ARG, "null argument");
+  if (!c->have_params) return fail(c, QF_ERR_STATE, "no parameters set (qf_set_params_json)");
+  if (cfg->band_size < 0) return fail(c, QF_ERR_ARG, "negative band size");
+  if (cfg->sparse && (cfg->kmer_len < 1 || cfg->kmer_len > 32)) return fail(c, QF_ERR_ARG, "kmer_len out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  out->n_pairs = n_pairs;
+  if (!n_pairs) return QF_OK;
+  if (!pair_x || !pair_y || !y_comp) return fail(c, QF_ERR_ARG, "null pair list");
+  const uint32_t n_seqs = c->n_reads;
+  bool need[2] = {false, false};
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    if (pair_x[p] >= n_seqs || pair_y[p] >= n_seqs) return fail(c, QF_ERR_ARG, "pair index out of range");
+    need[y_comp[p] ? 1 : 0] = true;
+  }
+  const bool sparse = cfg->sparse != 0;
+  const bool mem = sparse && cfg->kmer_threshold < 0;
+  if (int rc = ensure_lse(c)) return rc;
+  const Scores& sc = c->scores;
+  // pair-emission tables: once per (parameters, strand flag), not once per pair (src/qoverlap.cpp:79)
+  for (int v = 0; v < 2; ++v) {
+    if (!need[v] || c->ov_scores[v]) continue;
+    OverlapScores os;
+    os.build(c->params, sc, v == 1);
+    DevBuf& dm = v ? c->d_mmi1 : c->d_mmi0;
+    DevBuf& dg = v ? c->d_gap1 : c->d_gap0;
+    HIPCHK(c, dm.reserve(os.mmi.size() * 8));
+    HIPCHK(c, dg.reserve(os.gap.size() * 8));
+    HIPCHK(c, hipMemcpy(dm.p, os.mmi.data(), os.mmi.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dg.p, os.gap.data(), os.gap.size() * 8, hipMemcpyHostToDevice));
+    c->ov_scores[v] = true;
+  }
+  // k-mer index over the resident sequences themselves (every sequence can be an x)
+  if (sparse && c->read_index_k != cfg->kmer_len) {
+    const int k = cfg->kmer_len;
+    if (k > kMaxRefK) return fail(c, QF_ERR_UNSUPPORTED, "-kmatch " + std::to_string(k) + ": device k-mer index is built for k <= " + std::to_string(kMaxRefK));
+    const uint32_t nb = 1u << (2 * k);
+    const size_t bytes = (size_t)n_seqs * (nb + 1) * 4;
+    HIPCHK(c, c->d_rbucket.reserve(bytes));
+    HIPCHK(c, c->d_rcursor.reserve(bytes));
+    HIPCHK(c, c->d_rpos.reserve((c->read_total + 16) * 4));
+    HIPCHK(c, hipMemsetAsync(c->d_rbucket.p, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_rcursor.p, 0, bytes, c->stream));
+  }
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const uint32_t max_units = n_pairs * 4 + 1024;
+  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  if (sparse && c->read_index_k != cfg->kmer_len) {  // needs the token bytes prep_reads just wrote
+    launch_ref_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len,
+                     1u << (2 * cfg->kmer_len), c->d_rbucket.as<uint32_t>(), c->d_rcursor.as<uint32_t>(),
+                     c->d_rpos.as<uint32_t>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    c->read_index_k = cfg->kmer_len;
+  }
+  HIPCHK(c, c->d_ctxc.reserve((c->read_total + 2 * kCtxPad) * 4));
+  HIPCHK(c, c->d_ins_sum.reserve((size_t)n_seqs * 8));
+  HIPCHK(c, c->d_ins_sum_c.reserve((size_t)n_seqs * 8));
+  HIPCHK(c, c->d_nll_c.reserve((size_t)n_seqs * 8));
+  HIPCHK(c, hipMemsetAsync(c->d_ctxc.p, 0, (c->read_total + 2 * kCtxPad) * 4, c->stream));
+  {
+    PrepArgs pa{};
+    pa.seq = c->d_seq.as<char>();
+    pa.qual = c->reads_have_qual ? c->d_qual.as<char>() : nullptr;
+    pa.off = c->d_roff.as<uint64_t>();
+    pa.match_len = sc.match_len;
+    pa.gap_len = sc.gap_len;
+    pa.tok = c->d_tok.as<uint8_t>();
+    pa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+    pa.ctxc = c->d_ctxc.as<uint32_t>() + kCtxPad;
+    pa.eins = c->d_eins.as<double>();
+    pa.ins_sum = c->d_ins_sum.as<double>();
+    pa.ins_sum_c = c->d_ins_sum_c.as<double>();
+    pa.nll_c = c->d_nll_c.as<double>();
+    pa.has_null = c->have_null;
+    if (c->have_null) {
+      std::vector<double> lq(4 * kNQual);
+      c->null.tables(pa.null_logEmit, pa.null_log1mEmit, pa.null_logSym, lq.data());
+      pa.null_logQual = c->d_nullq.as<double>();
+    }
+    launch_prep_overlap(pa, n_seqs, c->stream);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, c->d_px.reserve((size_t)n_pairs * 4));
+  HIPCHK(c, c->d_py.reserve((size_t)n_pairs * 4));
+  HIPCHK(c, c->d_pc.reserve((size_t)n_pairs));
+  HIPCHK(c, hipMemcpyAsync(c->d_px.p, pair_x, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_py.p, pair_y, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pc.p, y_comp, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+  // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
+  const int max_nd = (int)(2 * c->read_maxlen - 1);
+  SeedArgs sa;
+  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  sa.pair_x = c->d_px.as<uint32_t>();
+  sa.pair_y = c->d_py.as<uint32_t>();
+  sa.ref_off = c->d_roff.as<uint64_t>();
+  sa.ref_bucket = c->d_rbucket.as<uint32_t>();
+  sa.ref_pos = c->d_rpos.as<uint32_t>();
+  sa.storage_mode = 2;
+  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
+    return fail(c, QF_ERR_UNSUPPORTED, "read + read length exceeds the LDS diagonal histogram");
+  launch_bin_units(sa, n_pairs, 0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  BatchCounters bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  if (bc.n_ovf && !(bc.error & 8u)) {
+    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (int rc = read_counters(c, bc)) return rc;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  if (bc.error & 2u)
+    return fail(c, QF_ERR_UNSUPPORTED, "overlap band of " + std::to_string(bc.error_detail) + " diagonals: the overlap kernels take up to 512 (no row-space overlap kernel yet)");
+  if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
+  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
+
+  // ---- fill
+  const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
+  if (tb_bytes > (200ull << 30)) return fail(c, QF_ERR_MEMORY, "traceback needs " + std::to_string(tb_bytes >> 30) + " GiB; split the pair list");
+  HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
+  HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
+  HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
+  HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));
+  OvArgs oa{};
+  oa.n_pairs = n_pairs;
+  oa.units = c->d_units.as<Unit>();
+  oa.pair_x = c->d_px.as<uint32_t>();
+  oa.pair_y = c->d_py.as<uint32_t>();
+  oa.pair_comp = c->d_pc.as<uint8_t>();
+  oa.seq_off = c->d_roff.as<uint64_t>();
+  oa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+  oa.ctxc = c->d_ctxc.as<uint32_t>() + kCtxPad;
+  oa.tb = c->d_tb.as<uint32_t>();
+  oa.mmi[0] = c->d_mmi0.as<double>();
+  oa.mmi[1] = c->d_mmi1.as<double>();
+  oa.gap[0] = c->d_gap0.as<double>();
+  oa.gap[1] = c->d_gap1.as<double>();
+  if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
+  if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
+  oa.lse = c->d_lse.as<double>();
+  oa.Km = sc.Km;
+  oa.Kg = sc.Kg;
+  oa.pair_head = c->d_pair_head.as<uint32_t>();
+  oa.ins_sum = c->d_ins_sum.as<double>();
+  oa.ins_sum_c = c->d_ins_sum_c.as<double>();
+  oa.nll = c->d_nll.as<double>();
+  oa.nll_c = c->d_nll_c.as<double>();
+  oa.pair_result = c->d_pair_result.as<double>();
+  oa.pair_score = c->d_pair_score.as<double>();
+  oa.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
+  oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
+  oa.recs = c->d_recs.as<AlignRec>();
+  oa.bc = c->d_bc.as<BatchCounters>();
+  for (int cls = 10; cls >= 1; --cls) {
+    oa.n_cls_units = bc.cls_count[cls];
+    oa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+    launch_overlap_fill(cls, oa, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  launch_overlap_finalize(oa, c->stream);
+  HIPCHK(c, hipGetLastError());
+  const BatchCounters seed_bc = bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  const uint32_t n_recs = bc.n_align;
+  HIPCHK(c, c->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
+  HIPCHK(c, c->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
+  oa.n_recs = n_recs;
+  oa.runs_tmp = c->d_runs_tmp.as<uint32_t>();
+  oa.runs_out = c->d_runs_out.as<uint32_t>();
+  launch_overlap_traceback(oa, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (int rc = read_counters(c, bc)) return rc;
+  const uint64_t total_runs = bc.total_runs_out;
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+
+  c->h_ov_result.resize(n_pairs);
+  c->h_ov_score.resize(n_pairs);
+  c->h_cells.resize(n_pairs);
+  c->h_ndiag.resize(n_pairs);
+  c->h_recs.resize(n_recs);
+  c->h_runs.resize(total_runs);
+  HIPCHK(c, hipMemcpyAsync(c->h_ov_result.data(), c->d_pair_result.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ov_score.data(), c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_cells.data(), c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data(), c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data(), c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data(), c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::sort(c->h_recs.begin(), c->h_recs.end(), [](const AlignRec& p, const AlignRec& q) { return p.read < q.read; });
+  c->h_ov_align.resize(n_recs);
+  for (uint32_t a = 0; a < n_recs; ++a) {
+    const AlignRec& r = c->h_recs[a];
+    if (!r.ok) return fail(c, QF_ERR_DEVICE, "overlap traceback did not reach the start state (pair " + std::to_string(r.read) + ")");
+    qf_overlap_alignment& o = c->h_ov_align[a];
+    o.pair = r.read;
+    o.viterbi = r.viterbi;
+    o.score = r.score;
+    o.x_start = r.x_start; o.x_end = r.x_end; o.y_start = r.y_start; o.y_end = r.y_end;
+    o.n_columns = r.n_columns;
+    o.n_runs = r.n_runs;
+    o.run_offset = r.run_off;
+  }
+  out->viterbi = c->h_ov_result.data();
+  out->score = c->h_ov_score.data();
+  out->cells = c->h_cells.data();
+  out->n_diagonals = c->h_ndiag.data();
+  out->total_cells = seed_bc.total_cells;
+  out->n_alignments = n_recs;
+  out->alignments = c->h_ov_align.data();
+  out->state_runs = c->h_runs.data();
+  out->traceback_bytes = tb_bytes;
+  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&out->ms_seed, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&out->ms_fill, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&out->ms_traceback, c->ev[3], c->ev[4]);
   (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
   return QF_OK;
 }

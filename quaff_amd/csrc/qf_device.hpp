@@ -30,6 +30,9 @@ struct Unit {
   double end_val;     // max over the last read column of mat + m2e  (-inf if none)
   uint32_t end_i;     // its 1-based reference row (largest row on ties)
   uint32_t cls;       // fill-kernel class
+  double end2_val;    // overlap only: max of mat over the band's cells in the last REFERENCE row (i == xLen)
+  uint32_t end2_j;    // its read column (largest column on ties)
+  uint32_t pad_;
 };
 
 // Fill-kernel classes: class 0 = single diagonal (one lane per unit); class c>0 = G lanes x B

@@ -183,6 +183,11 @@ __device__ __forceinline__ unsigned long long band_cells(int dlo, int dhi, int x
   return c;
 }
 
+__device__ __forceinline__ void pair_rx(const SeedArgs& a, uint32_t pair, uint32_t& r, uint32_t& x) {
+  if (a.pair_x) { x = a.pair_x[pair]; r = a.pair_y[pair]; }
+  else { r = pair / a.n_refs; x = pair % a.n_refs; }
+}
+
 // Seeding records each band of a pair in a fixed per-pair slot (an uncontended per-pair counter);
 // k_bin_units then classifies the bands and allocates unit ids, class-list slots and traceback space with
 // workgroup-aggregated atomics.  (Allocating straight from the seeding kernel put ~10^6 returning atomics
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   const uint32_t pair = a.pair_base + blockIdx.x, tid = threadIdx.x;
   if (a.pair_skip && a.pair_skip[pair]) return;
-  const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
+  uint32_t r, x;
+  pair_rx(a, pair, r, x);
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
   const int minD = 1 - yLen, maxD = xLen - 1, nd = xLen + yLen - 1;
@@ -370,7 +376,8 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   if (pidx >= n_pairs) return;
   const uint32_t pair = a.pair_base + pidx;
   if (a.pair_skip && a.pair_skip[pair]) return;
-  const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
+  uint32_t r, x;
+  pair_rx(a, pair, r, x);
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
   const int minD = 1 - yLen, maxD = xLen - 1, nd = xLen + yLen - 1;
@@ -536,20 +543,23 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
   }
   {
     if (have) {
-      const uint32_t r = pair / a.n_refs, x = pair % a.n_refs;
+      uint32_t r, x;
+  pair_rx(a, pair, r, x);
       const int xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]);
       yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
       cls = classify_width(dhi - dlo + 1);
-      if (cls == kRowClass && a.storage_mode == 1) cls = -1;  // Forward-Backward has no row-space kernel yet
+      if (cls == kRowClass && a.storage_mode >= 1) cls = -1;  // Forward-Backward / overlap: no row-space kernel yet
+      if (a.storage_mode == 2 && cls > 10) cls = -1;           // overlap kernels take up to 8 diagonals per lane
       if (cls < 0) {
         atomicOr(&a.bc->error, 2u);
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
       } else {
         act = true;
-        if (a.storage_mode == 1) cls = fb_class(cls);
+        if (a.storage_mode >= 1) cls = fb_class(cls);
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
-        tbw = a.storage_mode == 1 ? unit_fw_doubles(cls, (uint32_t)yLen)
+        tbw = a.storage_mode == 2 ? (unsigned long long)(yLen + fill_class(cls).G - 1) * fill_class(cls).G * 2
+              : a.storage_mode == 1 ? unit_fw_doubles(cls, (uint32_t)yLen)
               : cls == kRowClass  ? row_unit_words(dlo, dhi, xLen, yLen)
                                   : unit_tb_words(cls, (uint32_t)yLen);
         tbw = (tbw + 1) & ~1ull;  // keep every unit 8-byte aligned (row-space units hold doubles)
@@ -592,6 +602,9 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
   u.end_val = QF_NEG_INF;
   u.end_i = 0;
   u.cls = (uint32_t)cls;
+  u.end2_val = QF_NEG_INF;
+  u.end2_j = 0;
+  u.pad_ = 0;
   u.next = atomicExch(&a.pair_head[pair], uid);
   a.units[uid] = u;
   atomicAdd(&a.pair_cells[pair], cells);

@@ -24,11 +24,19 @@ struct PrepArgs {
   double null_logEmit, null_log1mEmit;
   double null_logSym[4];
   const double* null_logQual;  // [4][94]
+  // overlap only (qf_overlap.hip)
+  uint32_t* ctxc;          // [total] context words of the reverse-complement strand, in this sequence's orientation
+  const double* eins;      // insert-emission table
+  double* ins_sum;         // [n] sum of insert scores (xInsertScore / yInsertScore, src/qoverlap.cpp:105-113)
+  double* ins_sum_c;       // [n] same with complemented tokens
+  double* nll_c;           // [n] null log-likelihood of the reverse complement
   BatchCounters* bc;
 };
 
 struct SeedArgs {
   uint32_t pair_base, n_refs;
+  const uint32_t* pair_x;      // optional explicit pair list (overlap): x / y sequence of each pair
+  const uint32_t* pair_y;
   const uint64_t* ref_off;
   const uint64_t* read_off;
   const uint32_t* skmer;
@@ -101,11 +109,45 @@ struct CountPlanArgs {
   double* read_loglike;
 };
 
+struct AlignRec;
+struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
+  uint32_t n_cls_units, n_pairs;
+  const uint32_t* cls_list;
+  Unit* units;
+  const uint32_t* pair_x;
+  const uint32_t* pair_y;
+  const uint8_t* pair_comp;
+  const uint64_t* seq_off;
+  const uint32_t* ctx;      // plain context words
+  const uint32_t* ctxc;     // complemented-strand context words
+  uint32_t* tb;
+  const double* mmi[2];     // pair-emission tables [plain, yComplemented]
+  const double* gap[2];
+  const double* lse;
+  uint32_t Km, Kg;
+  // finalize / traceback
+  const uint32_t* pair_head;
+  const double* ins_sum;
+  const double* ins_sum_c;
+  const double* nll;
+  const double* nll_c;
+  double* pair_result;      // end + xInsertScore + yInsertScore
+  double* pair_score;       // result - null(x) - null(y)
+  uint32_t* pair_end_unit;
+  uint32_t* pair_end_ij;    // [n_pairs][2] end cell (i, j)
+  AlignRec* recs;
+  uint32_t n_recs;
+  uint32_t* runs_tmp;
+  uint32_t* runs_out;
+  BatchCounters* bc;
+};
+
 struct AlignRec {
   uint32_t read, ref, unit, ok;
   double viterbi, score;
   unsigned long long tmp_off, run_off;
   uint32_t x_start, x_end, n_columns, n_runs;
+  uint32_t y_start, y_end;
 };
 
 struct FinalArgs {
@@ -140,6 +182,10 @@ void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s);
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s);
 void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s);
 void launch_count_plan(const CountPlanArgs& a, hipStream_t s);
+void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s);
+void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);
+void launch_overlap_finalize(const OvArgs& a, hipStream_t s);
+void launch_overlap_traceback(const OvArgs& a, hipStream_t s);
 void launch_select(const FinalArgs& a, hipStream_t s);
 void launch_traceback(const FinalArgs& a, hipStream_t s);
 

@@ -386,6 +386,84 @@ const std::vector<double>& lse_table() {  // LogSumExpLookupTable ctor, src/logs
   return table;
 }
 
+static inline double lse_unary(double x) {  // log_sum_exp_unary, src/logsumexp.cpp:84-103
+  if (x >= 10 || std::isnan(x) || std::isinf(x)) return 0;
+  if (x < 0) return -x;
+  const std::vector<double>& t = lse_table();
+  const int n = (int)(x / .0001);
+  const double dx = x - (n * .0001);
+  const double f0 = t[n], f1 = t[n + 1];
+  const double df = f1 - f0;
+  return f0 + df * (dx / .0001);
+}
+double log_sum_exp(double a, double b) {  // src/logsumexp.cpp:34-50
+  double mx, diff;
+  if (a == b) { mx = a; diff = 0; }
+  else if (a < b) { mx = b; diff = b - a; }
+  else { mx = a; diff = a - b; }
+  return mx + lse_unary(diff);
+}
+
+// QuaffOverlapScores ctor, src/qoverlap.cpp:9-75: a 3-state approximation of the intersection of two quaff
+// transducers.  Built once per (parameters, strand flag) instead of once per read pair.
+void OverlapScores::build(const Params& p, const Scores& s, bool yComp) {
+  Km = s.Km;
+  Kg = s.Kg;
+  yComplemented = yComp;
+  const size_t KQ = (size_t)Km * kNQ1;
+  mmi.assign(KQ * KQ, -INFINITY);
+  gap.assign((size_t)3 * Kg * Kg + 6, 0);
+  std::vector<double> gapOpen(Kg);
+  double pGapIsInsertSum = 0, gapAdjSum = 0;
+  for (uint32_t j = 0; j < Kg; ++j) {  // :24-32
+    const double readInsertProb = p.beginInsert[j];
+    const double readDeleteProb = (1 - p.beginInsert[j]) * p.beginDelete[j];
+    gapOpen[j] = readInsertProb + readDeleteProb;
+    const double pGapIsInsert = readInsertProb / gapOpen[j];
+    const double gapAdjacentProb =
+        pGapIsInsert * readInsertProb + (1 - pGapIsInsert) * gapOpen[j] / (1 - p.extendDelete * (1 - gapOpen[j]));
+    pGapIsInsertSum += pGapIsInsert;
+    gapAdjSum += gapAdjacentProb;
+  }
+  double* m2m = gap.data();
+  double* m2i = m2m + (size_t)Kg * Kg;
+  double* m2d = m2i + (size_t)Kg * Kg;
+  double* sc = m2d + (size_t)Kg * Kg;
+  for (uint32_t i = 0; i < Kg; ++i)
+    for (uint32_t j = 0; j < Kg; ++j) {  // :34-39
+      m2m[i * Kg + j] = log(1 - gapOpen[i]) + log(1 - gapOpen[j]);
+      m2i[i * Kg + j] = log(gapOpen[i]);
+      m2d[i * Kg + j] = log(1 - gapOpen[i]) + log(gapOpen[j]);
+    }
+  const double pGapIsInsert = pGapIsInsertSum / Kg;  // accumulate(...)/size(), :41
+  const double meanGapLength = pGapIsInsert / p.extendInsert + (1 - pGapIsInsert) / p.extendDelete;
+  const double gapExtendProb = 1 / meanGapLength;
+  const double gapAdjacentProb = gapAdjSum / Kg;
+  sc[1] = sc[5] = log(gapExtendProb);                                  // i2i = d2d, :46
+  sc[2] = sc[4] = log(1 - gapExtendProb) + log(gapAdjacentProb);      // i2d = d2i
+  sc[0] = sc[3] = log(1 - gapExtendProb) + log(1 - gapAdjacentProb);  // i2m = d2m
+  auto at = [&](uint32_t ki, int qi, uint32_t kj, int qj) -> double& {
+    return mmi[((size_t)ki * kNQ1 + qi) * KQ + (size_t)kj * kNQ1 + qj];
+  };
+  for (uint32_t i = 0; i < Km; ++i)
+    for (uint32_t j = 0; j < Km; ++j) {
+      const double* xi = &s.ins[(size_t)(i & 3) * kNQ1];  // insert scores of the k-mer's last (emitted) base, :54-58
+      const double* yi = &s.ins[(size_t)(j & 3) * kNQ1];
+      for (int ik = 0; ik < kNQual; ++ik)
+        for (int jk = 0; jk < kNQual; ++jk) {
+          double mij = -INFINITY;
+          for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t yr = yComp ? 3 - r : r;
+            mij = log_sum_exp(mij, log(p.refBase[r]) + s.mat[((size_t)r * Km + i) * kNQ1 + ik] + s.mat[((size_t)yr * Km + j) * kNQ1 + jk]);
+          }
+          at(i, ik, j, jk) = mij - xi[ik] - yi[jk];
+          at(i, ik, j, kNQual) = log_sum_exp(at(i, ik, j, kNQual), mij - xi[ik] - yi[kNQual]);
+          at(i, kNQual, j, jk) = log_sum_exp(at(i, kNQual, j, jk), mij - xi[kNQual] - yi[jk]);
+          at(i, kNQual, j, kNQual) = log_sum_exp(at(i, kNQual, j, kNQual), mij - xi[kNQual] - yi[kNQual]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------ synthetic data
 static inline uint64_t splitmix64(uint64_t& x) {
   uint64_t z = (x += 0x9E3779B97F4A7C15ull);

@@ -68,6 +68,16 @@ struct NullParams {  // QuaffNullParams, src/qmodel.cpp:1806-1907
 };
 
 const std::vector<double>& lse_table();  // src/logsumexp.cpp:20-28
+double log_sum_exp(double a, double b);   // src/logsumexp.cpp:34-50,84-103 (table-interpolated)
+
+struct OverlapScores {  // QuaffOverlapScores, src/qoverlap.cpp:9-75, one strand flag
+  uint32_t Km = 4, Kg = 1;
+  bool yComplemented = false;
+  // mmi[(ki*95+qi) * (Km*95) + (kj*95+qj)]: match-minus-insert pair emission; q index 94 = that read has no quality
+  std::vector<double> mmi;
+  std::vector<double> gap;   // m2m[Kg][Kg] m2i[Kg][Kg] m2d[Kg][Kg] | i2m i2i i2d d2m d2i d2d
+  void build(const Params& p, const Scores& s, bool yComp);
+};
 
 std::string fmt6(double x);  // default ostream << double
 

@@ -1,0 +1,358 @@
+// qf_overlap.hip — read-vs-read overlap Viterbi (quaff overlap): QuaffOverlapViterbiMatrix ctor + alignment(),
+// src/qoverlap.cpp:77-290, on the same skewed G x B diagonal wavefront as the align fill.  Differences from the
+// align model: both sequences are reads (pair-emission table indexed by both reads' context k-mer and quality),
+// the gap states mix through a table log-sum-exp before the max (:145-151), both ends are free (:141,:153), the
+// traceback takes three candidates for insert and delete states (6 traceback bits per cell -> one byte), and the
+// reference's accessor swaps (src/qoverlap.h:46-50) and fill/traceback inconsistency (:148 vs :222) are reproduced
+// literally.  Bit-exact: the log-sum-exp uses the host-built table with IEEE division, as src/logsumexp.cpp does.
+#include <hip/hip_runtime.h>
+
+#include "qf_kernels.hpp"
+
+namespace qf {
+
+#define QF_NEG_INF (-__builtin_huge_val())
+
+__device__ __forceinline__ int tokc(int c) {
+  c &= ~0x20;
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
+}
+
+// log_sum_exp(a,b), src/logsumexp.cpp:34-50,84-103, bit-for-bit (exact division, no contraction)
+__device__ __forceinline__ double lse_exact(const double* __restrict__ tab, double a, double b) {
+  double mx, diff;
+  if (a == b) { mx = a; diff = 0; }
+  else if (a < b) { mx = b; diff = b - a; }
+  else { mx = a; diff = a - b; }
+  if (!(diff < 10.0)) return mx;           // x >= 10, NaN, inf -> log_sum_exp_unary returns 0
+  const int n = (int)(diff / .0001);
+  const double dx = diff - (n * .0001);
+  const double f0 = tab[n], f1 = tab[n + 1];
+  const double df = f1 - f0;
+  return mx + (f0 + df * (dx / .0001));
+}
+
+// Context words of the reverse-complement strand in this sequence's orientation (src/qoverlap.cpp:91-98: the arrays
+// of revcomp(y), reversed): complemented token, context k-mers read right-to-left, padded with revcomp's most
+// frequent token.  One wavefront per sequence.
+__global__ __launch_bounds__(64) void k_prep_overlap(PrepArgs a) {
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
+  const uint64_t b = a.off[r];
+  const uint32_t L = (uint32_t)(a.off[r + 1] - b);
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (uint32_t i = lane; i < L; i += 64) {
+    const int t = 3 - tokc((unsigned char)a.seq[b + i]);
+    c0 += t == 0; c1 += t == 1; c2 += t == 2; c3 += t == 3;
+  }
+  for (int o = 32; o; o >>= 1) {
+    c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o);
+  }
+  uint32_t padTok = 0, best = c0;
+  if (c1 > best) { best = c1; padTok = 1; }
+  if (c2 > best) { best = c2; padTok = 2; }
+  if (c3 > best) { best = c3; padTok = 3; }
+  auto ctok = [&](int64_t p) -> uint32_t {  // complemented token at position p of this sequence; beyond the end = pad
+    if (p >= (int64_t)L) return padTok;
+    return 3u - (uint32_t)tokc((unsigned char)a.seq[b + p]);
+  };
+  for (uint32_t i = lane; i < L; i += 64) {
+    uint32_t mk = 0, gk = 0;
+    for (uint32_t c = 0; c < a.match_len; ++c) mk = mk * 4 + ctok((int64_t)i + (a.match_len - 1) - c);
+    for (uint32_t c = 0; c < a.gap_len; ++c) gk = gk * 4 + ctok((int64_t)i + (a.gap_len - 1) - c);
+    uint32_t q = kNQualDev;
+    if (a.qual) {
+      const int v = (int)(signed char)a.qual[b + i] - '!';
+      q = (uint32_t)max(0, min(kNQualDev - 1, v));
+    }
+    a.ctxc[b + i] = ctx_pack(mk * (kNQualDev + 1) + q, ctok(i) * (kNQualDev + 1) + q, gk);
+  }
+}
+
+// per-sequence sequential sums: insert scores in both orientations (src/qoverlap.cpp:105-113) and the null
+// log-likelihood of the reverse complement (scoreAdjustedAlignment, :292-302).  One lane per sequence.
+__global__ __launch_bounds__(64) void k_overlap_sums(PrepArgs a, const uint32_t* __restrict__ ctx, uint32_t n) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t b = a.off[r];
+  const uint32_t L = (uint32_t)(a.off[r + 1] - b);
+  double s0 = 0, s1 = 0;
+  for (uint32_t i = 0; i < L; ++i) {
+    s0 += a.eins[(ctx[b + i] >> 15) & 0x1FFu];
+    s1 += a.eins[(a.ctxc[b + i] >> 15) & 0x1FFu];
+  }
+  a.ins_sum[r] = s0;
+  a.ins_sum_c[r] = s1;
+  double ll = 0;
+  if (a.has_null) {  // null LL of revcomp(seq): bases and qualities visited from the far end
+    ll = (double)L * a.null_logEmit + a.null_log1mEmit;
+    for (uint32_t k = 0; k < L; ++k) {
+      const uint32_t i = L - 1 - k;
+      const uint32_t t = 3u - a.tok[b + i];
+      ll += a.null_logSym[t];
+      if (a.qual) {
+        const int v = (int)(signed char)a.qual[b + i] - '!';
+        ll += a.null_logQual[t * kNQualDev + max(0, min(kNQualDev - 1, v))];
+      }
+    }
+  }
+  a.nll_c[r] = ll;
+}
+
+template <int G, int B, bool GAPCTX>
+__global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
+  constexpr int UPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int grp = lane / G, l = lane % G;
+  const uint32_t uidx = wave * UPW + grp;
+  const bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0, comp = 0;
+  int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, tb_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t x = a.pair_x[u.pair], y = a.pair_y[u.pair];
+    comp = a.pair_comp[u.pair];
+    xb = a.seq_off[x]; xLen = (int)(a.seq_off[x + 1] - xb);
+    yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
+    dlo = u.dlo; dhi = u.dhi; tb_off = u.tb_off;
+  }
+  int T = active ? yLen + G - 1 : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+  const int d0 = dlo + l * B;
+  const double* __restrict__ mmi = a.mmi[comp];
+  const double* __restrict__ gap = a.gap[comp];
+  const double* __restrict__ tab = a.lse;
+  const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
+  const double* gsc = gap + 3ull * Kg * Kg;
+  // accessor swaps of src/qoverlap.h:46-50, literally
+  const double i2mS = gsc[1], i2iS = gsc[0], i2dS = gsc[2], d2mS = gsc[4], d2iS = gsc[3], d2dS = gsc[5];
+  const double c_m2m = gap[0], c_m2i = gap[(size_t)Kg * Kg], c_m2d = gap[2ull * Kg * Kg];
+  const uint32_t* __restrict__ xc = a.ctx + xb;
+  const uint32_t* __restrict__ yc = (comp ? a.ctxc : a.ctx) + yb;
+  uint32_t* __restrict__ tb = a.tb + tb_off;
+
+  double M[B], I[B], D[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
+  double pubM = QF_NEG_INF, pubI = QF_NEG_INF, pubD = QF_NEG_INF;
+  double colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
+  uint32_t colI = 0, rowJ = 0;
+  // x-side context words of the rows this lane's slots are on; slides by one row per step
+  uint32_t xw[B + 1];  // xw[b] = word of row i-1 (1-based row i-1 -> index i-2) ... see below
+#pragma unroll
+  for (int b = 0; b <= B; ++b) xw[b] = 0;
+  uint32_t gkyPrev = 0;
+
+  for (int t = 0; t < T; ++t) {
+    const int j = t - l + 1;
+    const bool colvalid = active && j >= 1 && j <= yLen;
+    const uint32_t wy = yc[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+    const uint32_t erowY = wy & 0x7FFFu, gky = wy >> 24;
+    const uint32_t gkyP = j > 1 ? gkyPrev : 0u;   // yIndelKmer[j-1], padded with a leading 0
+    gkyPrev = gky;
+    // rows of this step: slot b is row i = d0 + b + j; xw[b] must hold the context word of row i-1 (for the padded
+    // indel k-mer of the diagonal / upper neighbour) and xw[b+1] that of row i.  Refill by direct loads: the words of
+    // rows d0+j-1 .. d0+j+B-1.
+#pragma unroll
+    for (int b = 0; b <= B; ++b) {
+      const int row = d0 + b + j - 1;  // 1-based row whose word goes to xw[b]
+      xw[b] = (row >= 1 && row <= xLen) ? xc[row - 1] : 0u;
+    }
+    double lowM = __shfl_up(pubM, 1, G), lowI = __shfl_up(pubI, 1, G), lowD = __shfl_up(pubD, 1, G);
+    if (l == 0) { lowM = QF_NEG_INF; lowI = QF_NEG_INF; lowD = QF_NEG_INF; }
+    double upM = 0, upI = 0, upD = 0;
+    double prevM = lowM, prevI = lowI, prevD = lowD;
+    uint32_t tbw0 = 0, tbw1 = 0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int d = d0 + b, i = d + j;
+      const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
+      const uint32_t wx = xw[b + 1];                       // row i
+      const uint32_t gkx = GAPCTX ? (wx >> 24) : 0u;       // xIndelKmer[i]
+      const uint32_t gkxP = GAPCTX ? (i > 1 ? (xw[b] >> 24) : 0u) : 0u;  // xIndelKmer[i-1]
+      const double e = mmi[(size_t)(wx & 0x7FFFu) * KQ + erowY];
+      double m2m, m2i, m2d;
+      if (GAPCTX) {
+        m2m = gap[gkxP * Kg + gkyP];                       // m2mScore(i-1, j-1)
+        m2i = gap[(size_t)Kg * Kg + gkx * Kg + gkyP];      // m2iScore(i,   j-1)
+        m2d = gap[2ull * Kg * Kg + gkxP * Kg + gky];       // m2dScore(i-1, j)
+      } else { m2m = c_m2m; m2i = c_m2i; m2d = c_m2d; }
+      // match state; traceback candidate order M, I, D, Start (strict >), src/qoverlap.cpp:204-209
+      const double tM = (M[b] + m2m) + e, tI = (I[b] + i2mS) + e, tD = (D[b] + d2mS) + e;
+      double nm = tM;
+      uint32_t sm = 0;
+      if (tI > nm) { nm = tI; sm = 1; }
+      if (tD > nm) { nm = tD; sm = 2; }
+      if ((j == 1 || i == 1) && e > nm) { nm = e; sm = 3; }
+      // insert state: sources at (i, j-1) = diagonal d+1, previous column
+      double sM, sI, sD;
+      if (b + 1 < B) { sM = M[b + 1]; sI = I[b + 1]; sD = D[b + 1]; } else { sM = upM; sI = upI; sD = upD; }
+      const double iM = sM + m2i, iI = sI + i2iS, iD = sD + d2iS;
+      const double lseI = lse_exact(tab, iI, iD);
+      double ni = lseI > iM ? lseI : iM;  // max(lse(...), mat + m2i): std::max returns the first unless it is smaller
+      uint32_t si = 0;                     // traceback: M, I, D on the individual terms (:215-217)
+      { double s = iM; if (iI > s) { s = iI; si = 1; } if (iD > s) { s = iD; si = 2; } }
+      // delete state: sources at (i-1, j) = diagonal d-1, this column
+      const double dM = prevM + m2d, dD = prevD + d2dS, dIfill = prevI + d2iS, dItb = prevI + i2dS;
+      const double lseD = lse_exact(tab, dD, dIfill);
+      double ndl = lseD > dM ? lseD : dM;
+      uint32_t sd = 0;                     // traceback: M, then ins + i2dScore(), then D (:221-223)
+      { double s = dM; if (dItb > s) { s = dItb; sd = 1; } if (dD > s) { s = dD; sd = 2; } }
+      if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+      M[b] = nm; I[b] = ni; D[b] = ndl;
+      prevM = nm; prevI = ni; prevD = ndl;
+      const uint32_t byte = sm | (si << 2) | (sd << 4);
+      if (b < 4) tbw0 |= byte << (8 * b); else tbw1 |= byte << (8 * (b - 4));
+      if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
+      if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+      if (b == 0) {
+        upM = __shfl_down(nm, 1, G); upI = __shfl_down(ni, 1, G); upD = __shfl_down(ndl, 1, G);
+        if (l == G - 1) { upM = QF_NEG_INF; upI = QF_NEG_INF; upD = QF_NEG_INF; }
+      }
+    }
+    pubM = prevM; pubI = prevI; pubD = prevD;
+    if (colvalid) {
+      tb[((uint64_t)t * G + l) * 2] = tbw0;
+      tb[((uint64_t)t * G + l) * 2 + 1] = tbw1;
+    }
+  }
+  for (int o = 1; o < G; o <<= 1) {
+    const double ov = __shfl_xor(colBest, o, G);
+    const uint32_t oi = __shfl_xor(colI, o, G);
+    if (ov > colBest || (ov == colBest && oi > colI)) { colBest = ov; colI = oi; }
+    const double rv = __shfl_xor(rowBest, o, G);
+    const uint32_t rj = __shfl_xor(rowJ, o, G);
+    if (rv > rowBest || (rv == rowBest && rj > rowJ)) { rowBest = rv; rowJ = rj; }
+  }
+  if (active && l == 0) {
+    Unit* u = &a.units[uid];
+    u->end_val = colBest; u->end_i = colI;
+    u->end2_val = rowBest; u->end2_j = rowJ;
+  }
+}
+
+// End cell (src/qoverlap.cpp:164-182): start from mat(xLen,yLen), scan the last read column downwards, then the last
+// reference row, replacing only on strict '>'.  result = end + xInsertScore + yInsertScore (:157); adjusted score
+// subtracts both reads' null log-likelihoods (:292-302).
+__global__ void k_overlap_finalize(OvArgs a) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n_pairs) return;
+  const uint32_t x = a.pair_x[p], y = a.pair_y[p], comp = a.pair_comp[p];
+  const uint32_t xLen = (uint32_t)(a.seq_off[x + 1] - a.seq_off[x]), yLen = (uint32_t)(a.seq_off[y + 1] - a.seq_off[y]);
+  double cb = QF_NEG_INF, rb = QF_NEG_INF;
+  uint32_t ci = 0, cu = kNoUnit, rj = 0, ru = kNoUnit;
+  for (uint32_t uid = a.pair_head[p]; uid != kNoUnit; uid = a.units[uid].next) {
+    const Unit& u = a.units[uid];
+    if (u.end_val > cb || (u.end_val == cb && u.end_val > QF_NEG_INF && u.end_i > ci)) { cb = u.end_val; ci = u.end_i; cu = uid; }
+    if (u.end2_val > rb || (u.end2_val == rb && u.end2_val > QF_NEG_INF && u.end2_j > rj)) { rb = u.end2_val; rj = u.end2_j; ru = uid; }
+  }
+  double end = cb;
+  uint32_t ei = ci, ej = yLen, eu = cu;
+  if (rb > cb) { end = rb; ei = xLen; ej = rj; eu = ru; }
+  const double yins = comp ? a.ins_sum_c[y] : a.ins_sum[y];
+  const double result = end + a.ins_sum[x] + yins;
+  a.pair_result[p] = result;
+  double score = result - a.nll[x];
+  score -= comp ? a.nll_c[y] : a.nll[y];
+  a.pair_score[p] = score;
+  a.pair_end_unit[p] = end > QF_NEG_INF ? eu : kNoUnit;
+  a.pair_end_ij[2 * p] = ei;
+  a.pair_end_ij[2 * p + 1] = ej;
+  if (end > QF_NEG_INF) {
+    const Unit& u = a.units[eu];
+    const uint32_t cap = xLen + yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
+    const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
+    AlignRec rec{};
+    rec.read = p;  // pair index
+    rec.ref = x;
+    rec.unit = eu;
+    rec.viterbi = result;
+    rec.score = score;
+    rec.tmp_off = atomicAdd(&a.bc->n_runs, (unsigned long long)cap);
+    a.recs[idx] = rec;
+  }
+}
+
+// QuaffOverlapViterbiMatrix::alignment traceback (src/qoverlap.cpp:184-268) from the per-cell bytes; raw M/I/D
+// state runs are emitted, the indel "squashing" of :231-267 is a host-side re-pairing of adjacent runs.
+__global__ void k_overlap_traceback(OvArgs a) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.n_recs) return;
+  AlignRec rec = a.recs[idx];
+  const uint32_t p = rec.read;
+  const Unit u = a.units[rec.unit];
+  const FillClass fc = fill_class((int)u.cls);
+  const uint32_t* __restrict__ tb = a.tb + u.tb_off;
+  auto cellbyte = [&](int i, int j) -> uint32_t {
+    const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
+    const uint64_t w = ((uint64_t)(j - 1 + l) * fc.G + l) * 2 + (b >> 2);
+    return (tb[w] >> (8 * (b & 3))) & 0xFFu;
+  };
+  uint32_t* tmp = a.runs_tmp + rec.tmp_off;
+  int i = (int)a.pair_end_ij[2 * p], j = (int)a.pair_end_ij[2 * p + 1];
+  const uint32_t xEnd = (uint32_t)i, yEnd = (uint32_t)j;
+  uint32_t n = 0, ncol = 0, curOp = 3, curLen = 0;
+  int state = 1;  // 0 Start, 1 Match, 2 Insert, 3 Delete
+  while (state != 0 && i >= 0 && j >= 0 && (i > 0 || j > 0)) {
+    const uint32_t byte = (i >= 1 && j >= 1) ? cellbyte(i, j) : 0u;
+    uint32_t op, s;
+    if (state == 1) { op = 0; s = byte & 3u; --i; --j; state = s == 0 ? 1 : s == 1 ? 2 : s == 2 ? 3 : 0; }
+    else if (state == 2) { op = 1; s = (byte >> 2) & 3u; --j; state = s == 0 ? 1 : s == 1 ? 2 : 3; }
+    else { op = 2; s = (byte >> 4) & 3u; --i; state = s == 0 ? 1 : s == 1 ? 2 : 3; }
+    ++ncol;
+    if (op == curOp) ++curLen;
+    else {
+      if (curLen) tmp[n++] = (curLen << 2) | curOp;
+      curOp = op; curLen = 1;
+    }
+  }
+  if (curLen) tmp[n++] = (curLen << 2) | curOp;
+  const unsigned long long off = atomicAdd(&a.bc->total_runs_out, (unsigned long long)n);
+  for (uint32_t c = 0; c < n; ++c) a.runs_out[off + c] = tmp[n - 1 - c];
+  rec.x_start = (uint32_t)(i + 1);
+  rec.x_end = xEnd;
+  rec.y_start = (uint32_t)(j + 1);
+  rec.y_end = yEnd;
+  rec.n_columns = ncol;
+  rec.n_runs = n;
+  rec.run_off = off;
+  rec.ok = state == 0;
+  a.recs[idx] = rec;
+}
+
+template <int G, int B>
+static void launch_ov_gb(const OvArgs& a, hipStream_t s) {
+  const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
+  if (a.Kg > 1) hipLaunchKernelGGL((k_overlap_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_overlap_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
+  if (!a.n_cls_units) return;
+  switch (cls) {
+    case 1: launch_ov_gb<16, 2>(a, s); break;
+    case 2: launch_ov_gb<16, 3>(a, s); break;
+    case 3: launch_ov_gb<16, 4>(a, s); break;
+    case 4: launch_ov_gb<16, 5>(a, s); break;
+    case 5: launch_ov_gb<16, 6>(a, s); break;
+    case 6: launch_ov_gb<16, 8>(a, s); break;
+    case 7: launch_ov_gb<64, 3>(a, s); break;
+    case 8: launch_ov_gb<64, 4>(a, s); break;
+    case 9: launch_ov_gb<64, 6>(a, s); break;
+    case 10: launch_ov_gb<64, 8>(a, s); break;
+  }
+}
+void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_prep_overlap, dim3(n), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_overlap_sums, dim3((n + 63) / 64), dim3(64), 0, s, a, (const uint32_t*)a.ctx, n);
+}
+void launch_overlap_finalize(const OvArgs& a, hipStream_t s) {
+  if (a.n_pairs) hipLaunchKernelGGL(k_overlap_finalize, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_overlap_traceback(const OvArgs& a, hipStream_t s) {
+  if (a.n_recs) hipLaunchKernelGGL(k_overlap_traceback, dim3((a.n_recs + 63) / 64), dim3(64), 0, s, a);
+}
+
+}  // namespace qf

@@ -1,0 +1,110 @@
+"""GPU parity for quaff overlap (read-vs-read Viterbi with log-sum-exp gap mixing): HIP path through the C ABI vs the
+oracle, bit-exact (==) on result, adjusted score, end/start coordinates and the raw traceback state string, for both
+strand flags."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import rand_seq, mutate, rand_qual
+from tests.test_gpu_align import NULL_JSON, DEFAULT_JSON, synth_params_json
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import quaff_amd as Q
+    c = Q.Context(0)
+    c.set_params_json(None)
+    c.set_null_json(NULL_JSON)
+    yield c
+    c.close()
+
+
+def overlapping_reads(rng, genome_len, n, read_len):
+    g = rand_seq(rng, genome_len)
+    reads = []
+    for k in range(n):
+        s = int(rng.integers(0, genome_len - read_len))
+        src = g[s:s + read_len]
+        if k % 3 == 2:
+            src = O.revcomp_str(src)
+        seq = mutate(rng, src, sub=0.04, ins=0.02, dele=0.02)
+        reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+    return reads
+
+
+def check_overlap(ctx, reads, params_json, cfg_kw, with_revcomps=True):
+    import quaff_amd as Q
+    p = O.Params.from_json(params_json)
+    sc = O.Scores(p)
+    null = O.NullParams.from_json(NULL_JSON)
+    osc = {False: O.OverlapScores(p, sc, False), True: O.OverlapScores(p, sc, True)}
+    n = len(reads)
+    seqs = reads + ([r.revcomp() for r in reads] if with_revcomps else [])
+    pairs = O.overlap_task_pairs(n, len(seqs))
+    ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    res = ctx.overlap_resident(pairs, Q.DPConfig(**cfg_kw))
+    ocfg = O.DPConfig(kmer_len=cfg_kw.get("kmer_len", 6), kmer_threshold=cfg_kw.get("kmer_threshold", 14),
+                      band=cfg_kw.get("band_size", 64))
+    nfinite = 0
+    for k, (nx, ny, comp) in enumerate(pairs):
+        want = O.overlap_pair(seqs[nx], seqs[ny], comp, osc[comp], sc, null, ocfg)
+        got = res["alignments"].get(k)
+        if want is None:
+            assert got is None and np.isneginf(res["viterbi"][k]), k
+            continue
+        nfinite += 1
+        assert got is not None, (k, nx, ny, comp)
+        assert res["n_diagonals"][k] == want["ndiag"] and res["cells"][k] == want["cells"], k
+        assert got["result"] == want["result"], (k, nx, ny, comp, got["result"], want["result"])
+        assert got["score"] == want["score"], (k, got["score"], want["score"])
+        assert (got["xStart"], got["xEnd"], got["yStart"], got["yEnd"]) == (want["xStart"], want["xEnd"], want["yStart"], want["yEnd"]), k
+        assert got["ops"] == want["ops"], (k, O.cigar(got["ops"]), O.cigar(want["ops"]))
+    return res, nfinite
+
+
+def test_overlap_small_genome(ctx):
+    rng = np.random.default_rng(41)
+    reads = overlapping_reads(rng, 1200, 8, 400)
+    res, nfinite = check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
+    assert nfinite == len(O.overlap_task_pairs(8, 16))        # diagonal 0 is always in the envelope: every pair has a path
+    assert (res["n_diagonals"] > 60).sum() >= 6               # real overlaps seed multi-diagonal bands
+
+
+def test_overlap_bands_and_thresholds(ctx):
+    rng = np.random.default_rng(42)
+    reads = overlapping_reads(rng, 900, 6, 350)
+    check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=8, band_size=20))
+    check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=20, band_size=100), with_revcomps=False)
+
+
+def test_overlap_order2(ctx):
+    rng = np.random.default_rng(43)
+    pj = synth_params_json(rng, 2, 1)
+    ctx.set_params_json(pj)
+    try:
+        check_overlap(ctx, overlapping_reads(rng, 800, 5, 300), pj, dict(kmer_threshold=12))
+    finally:
+        ctx.set_params_json(None)
+
+
+def test_c8f30_overlap_golden_through_gpu(ctx):
+    """Makefile:152-156 golden with the HIP path: Stockholm text byte-for-byte."""
+    import quaff_amd as Q
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    reads = O.read_fastx(os.path.join(golden, "c8f30.fastq.gz"))
+    cp = O.FastSeq(reads[0].name.replace("channel", "copy", 1), reads[0].seq, reads[0].qual)
+    seqs = [reads[0], cp]
+    null = O.NullParams.fit(seqs)
+    ctx.set_null_json(null.to_json())
+    try:
+        ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+        res = ctx.overlap_resident([(0, 1, False)], Q.DPConfig(kmer_threshold=-1, max_size=10 << 20))
+        a = res["alignments"][0]
+        al = dict(a, score=a["result"] - null.loglike(seqs[0]) - null.loglike(seqs[1]))   # null went through 6-s.f. JSON
+        assert O.overlap_stockholm(seqs[0], seqs[1], al) == open(os.path.join(golden, "c8f30-self-overlap.json")).read()
+    finally:
+        ctx.set_null_json(NULL_JSON)
