@@ -123,6 +123,13 @@ int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
  * decimal algorithm as the reference's gason, src/gason.cpp:73-117), build the log-space
  * score tables and upload them.  text == NULL selects the built-in defaults. */
 int qf_set_params_json(qf_ctx *ctx, const char *text);
+/* Same from in-memory values (EM iterations keep full doubles; quaff's JSON writer prints 6 significant figures):
+ *   begin_insert/begin_delete[4^gap_len]; insert_pqr[4][3], match_pqr[4][4^match_len][3] = (p, q, r) of each SymQualDist,
+ *   match indexed [reference base][read context k-mer]; ref_base[4] (only the overlap model reads it). */
+int qf_set_params_raw(qf_ctx *ctx, uint32_t match_len, uint32_t gap_len, const double *ref_base,
+                      const double *begin_insert, const double *begin_delete, double extend_insert, double extend_delete,
+                      const double *insert_pqr, const double *match_pqr);
+int qf_set_null_raw(qf_ctx *ctx, double null_emit, const double *null_pqr /* [4][3] */);
 /* Score tables as built (for inspection / parity tests).  Any pointer may be NULL.
  *   ins[4][95], mat[4][Km][95] (index 94 = quality-marginalised), trans[4*Kg+4] =
  *   m2m[Kg] m2i[Kg] m2d[Kg] m2e[Kg] d2d d2m i2i i2m. */

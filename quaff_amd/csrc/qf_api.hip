@@ -167,14 +167,39 @@ int qf_device_name(const qf_ctx* c, char* buf, size_t cap) {
 }
 
 // ---------------------------------------------------------------------------------- model
+static int install_params(qf_ctx* c, const Params& p);
+
 int qf_set_params_json(qf_ctx* c, const char* text) {
   if (!c) return QF_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
   Json j;
   std::string err;
   if (!parse_json(text ? text : kDefaultParamsJson, j, err)) return fail(c, QF_ERR_PARSE, err);
   Params p;
   if (!p.read_json(j, err)) return fail(c, QF_ERR_PARSE, err);
+  return install_params(c, p);
+}
+
+int qf_set_params_raw(qf_ctx* c, uint32_t match_len, uint32_t gap_len, const double* ref_base, const double* begin_insert,
+                      const double* begin_delete, double extend_insert, double extend_delete, const double* insert_pqr,
+                      const double* match_pqr) {
+  if (!c) return QF_ERR_ARG;
+  if (!begin_insert || !begin_delete || !insert_pqr || !match_pqr) return fail(c, QF_ERR_ARG, "null parameter array");
+  if (match_len < 1 || match_len > 4 || gap_len > 4) return fail(c, QF_ERR_UNSUPPORTED, "unsupported matchOrder/gapOrder (need 1..4 / 0..4)");
+  Params p;
+  p.match_len = match_len;
+  p.gap_len = gap_len;
+  p.resize();
+  if (ref_base) for (int i = 0; i < 4; ++i) p.refBase[i] = ref_base[i];
+  for (uint32_t g = 0; g < p.Kg(); ++g) { p.beginInsert[g] = begin_insert[g]; p.beginDelete[g] = begin_delete[g]; }
+  p.extendInsert = extend_insert;
+  p.extendDelete = extend_delete;
+  for (int i = 0; i < 4; ++i) p.insert[i] = SymQualDist{insert_pqr[i * 3], insert_pqr[i * 3 + 1], insert_pqr[i * 3 + 2]};
+  for (size_t m = 0; m < (size_t)4 * p.Km(); ++m) p.match[m] = SymQualDist{match_pqr[m * 3], match_pqr[m * 3 + 1], match_pqr[m * 3 + 2]};
+  return install_params(c, p);
+}
+
+static int install_params(qf_ctx* c, const Params& p) {
+  HIPCHK(c, hipSetDevice(c->device));
   c->params = p;
   c->scores.build(p);
   const Scores& s = c->scores;
@@ -234,18 +259,32 @@ const char* qf_fill_class_name(uint32_t cls) {
   return names[cls].c_str();
 }
 
+static int install_null(qf_ctx* c, const NullParams& n);
+
 int qf_set_null_json(qf_ctx* c, const char* text) {
   if (!c) return QF_ERR_ARG;
   if (!text) {
     c->have_null = false;
     return QF_OK;
   }
-  HIPCHK(c, hipSetDevice(c->device));
   Json j;
   std::string err;
   if (!parse_json(text, j, err)) return fail(c, QF_ERR_PARSE, err);
   NullParams n;
   if (!n.read_json(j, err)) return fail(c, QF_ERR_PARSE, err);
+  return install_null(c, n);
+}
+
+int qf_set_null_raw(qf_ctx* c, double null_emit, const double* pqr) {
+  if (!c || !pqr) return QF_ERR_ARG;
+  NullParams n;
+  n.nullEmit = null_emit;
+  for (int i = 0; i < 4; ++i) n.null[i] = SymQualDist{pqr[i * 3], pqr[i * 3 + 1], pqr[i * 3 + 2]};
+  return install_null(c, n);
+}
+
+static int install_null(qf_ctx* c, const NullParams& n) {
+  HIPCHK(c, hipSetDevice(c->device));
   c->null = n;
   double le, l1, ls[4];
   std::vector<double> lq(4 * kNQual);

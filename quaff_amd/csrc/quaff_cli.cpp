@@ -1,0 +1,719 @@
+// quaff_cli.cpp — `quaff {align,count,train,overlap}` command-line shell over libquaffhip.
+// Keeps the reference's commands, the DP-relevant flags (t/quaff.cpp:122-236, src/qmodel.cpp:747-833,1916-1993,
+// 2485-2529), its input formats (FASTA/FASTQ, optionally gzipped; params / null / counts JSON) and its output
+// formats (Stockholm, gapped FASTA, SAM, refseq; params / counts JSON), so that it is a drop-in for the hot path.
+// All DP runs on the GPU through the C ABI (include/quaff_hip.h); this file is host plumbing only.  Not provided:
+// remote/ssh/EC2/qsub execution, logging levels (-v* are accepted and ignored), -threads (accepted, ignored).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/quaff_hip.h"
+#include "qf_em.hpp"
+#include "qf_model.hpp"
+
+using namespace std;
+using namespace qf;
+
+[[noreturn]] static void Fail(const string& msg) {  // Fail(), src/util.cpp:89-98
+  cerr << msg << endl;
+  exit(EXIT_FAILURE);
+}
+#define Require(cond, msg) do { if (!(cond)) Fail(msg); } while (0)
+
+// ------------------------------------------------------------------------------------------ sequences
+struct Coords {  // SeqIntervalCoords, src/fastseq.h:29-39
+  string name;
+  unsigned start = 0, end = 0;
+  bool rev = false;
+  bool isNull() const { return name.empty(); }
+  Coords compose(const Coords& src) const {  // src/fastseq.cpp:51-65
+    if (src.isNull()) return *this;
+    Coords c;
+    c.name = src.name;
+    c.rev = rev != src.rev;
+    if (src.rev) { c.start = src.end - end + 1; c.end = src.end - start + 1; }
+    else { c.start = start + src.start - 1; c.end = end + src.start - 1; }
+    return c;
+  }
+};
+struct FastSeq {
+  string name, comment, seq, qual;
+  Coords source;
+  bool hasQual() const { return qual.size() == seq.size(); }
+};
+static char complementChar(char c) {  // dnaComplementChar, src/fastseq.cpp:22-25
+  switch (toupper(c)) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; }
+  return c;
+}
+static FastSeq revcomp(const FastSeq& s) {  // FastSeq::revcomp, src/fastseq.cpp:218-230
+  FastSeq r;
+  r.name = "revcomp(" + s.name + ")";
+  r.comment = s.comment;
+  r.seq.resize(s.seq.size());
+  for (size_t i = 0; i < s.seq.size(); ++i) r.seq[s.seq.size() - 1 - i] = complementChar(s.seq[i]);
+  r.qual = string(s.qual.rbegin(), s.qual.rend());
+  Coords c;
+  c.name = s.name; c.start = 1; c.end = (unsigned)s.seq.size(); c.rev = true;
+  r.source = c.compose(s.source);
+  return r;
+}
+static void writeFasta(ostream& out, const FastSeq& s) {
+  out << '>' << s.name;
+  if (s.comment.size()) out << ' ' << s.comment;
+  out << endl << s.seq << endl;
+}
+
+// FASTA / FASTQ reader with kseq's conventions (kseq/kseq.h, src/fastseq.cpp:133-171): name up to the first blank,
+// rest of the header line is the comment, multi-line sequence, quality kept only when as long as the sequence.
+static vector<FastSeq> readFastSeqs(const string& filename) {
+  gzFile fp = gzopen(filename.c_str(), "r");
+  Require(fp != Z_NULL, "Couldn't open " + filename);
+  string data;
+  char buf[1 << 16];
+  int n;
+  while ((n = gzread(fp, buf, sizeof buf)) > 0) data.append(buf, n);
+  gzclose(fp);
+  vector<FastSeq> seqs;
+  size_t p = 0;
+  auto line = [&](string& out) -> bool {
+    if (p >= data.size()) return false;
+    size_t e = data.find('\n', p);
+    if (e == string::npos) e = data.size();
+    out.assign(data, p, e - p);
+    if (!out.empty() && out.back() == '\r') out.pop_back();
+    p = e + 1;
+    return true;
+  };
+  string l;
+  bool have = line(l);
+  while (have) {
+    if (l.empty() || (l[0] != '>' && l[0] != '@')) { have = line(l); continue; }
+    FastSeq s;
+    const size_t sp = l.find_first_of(" \t");
+    s.name = l.substr(1, sp == string::npos ? string::npos : sp - 1);
+    if (sp != string::npos) s.comment = l.substr(sp + 1);
+    have = line(l);
+    while (have && !(l.size() && (l[0] == '>' || l[0] == '@' || l[0] == '+'))) {
+      for (char c : l) if (!isspace((unsigned char)c)) s.seq += c;
+      have = line(l);
+    }
+    if (have && l.size() && l[0] == '+') {
+      have = line(l);
+      while (have && s.qual.size() < s.seq.size()) { s.qual += l; have = line(l); }
+      if (s.qual.size() != s.seq.size()) s.qual.clear();
+    }
+    seqs.push_back(s);
+  }
+  if (seqs.empty()) cerr << "Warning: Couldn't read any sequences from " << filename << endl;
+  return seqs;
+}
+
+// ------------------------------------------------------------------------------------------ alignments
+struct Alignment {  // src/qmodel.h:235-254
+  FastSeq row[2];
+  double score = -INFINITY;
+  size_t columns() const { return row[0].seq.size(); }
+};
+static bool isGap(char c) { return c == '-' || c == '.'; }
+
+static string cigarString(const Alignment& a) {  // src/qmodel.cpp:625-653 (letter before count)
+  string cigar;
+  char last = 0;
+  size_t count = 0;
+  for (size_t col = 0; col < a.columns(); ++col) {
+    const bool g0 = isGap(a.row[0].seq[col]), g1 = isGap(a.row[1].seq[col]);
+    const char c = (!g0 && !g1) ? 'M' : (!g0 && g1) ? 'D' : (g0 && !g1) ? 'I' : 0;
+    if (!c) continue;
+    if (c == last) ++count;
+    else { if (count) cigar += last + to_string(count); last = c; count = 1; }
+  }
+  if (count) cigar += last + to_string(count);
+  return cigar;
+}
+
+static void writeStockholm(ostream& out, const Alignment& a) {  // src/qmodel.cpp:553-606
+  vector<string> rowName, rowData;
+  vector<size_t> rowIndex;
+  for (const auto& s : a.row) {
+    rowIndex.push_back(rowName.size());
+    rowName.push_back(s.name);
+    rowData.push_back(s.seq);
+    if (s.hasQual()) { rowName.push_back("#=GR " + s.name + " QS"); rowData.push_back(s.qual); }
+  }
+  string cons;
+  for (size_t pos = 0; pos < a.columns(); ++pos) {
+    const char c0 = toupper(a.row[0].seq[pos]), c1 = toupper(a.row[1].seq[pos]);
+    cons.push_back((isGap(c0) || isGap(c1)) ? '-' : (c0 == c1 ? c0 : ':'));
+  }
+  rowName.insert(rowName.begin() + rowIndex[1], "#=GC id");
+  rowData.insert(rowData.begin() + rowIndex[1], cons);
+  if (a.row[0].hasQual()) { swap(rowName[0], rowName[1]); swap(rowData[0], rowData[1]); }
+  size_t nameWidth = 0;
+  for (const auto& s : rowName) nameWidth = max(s.size(), nameWidth);
+  const size_t dataWidth = max(nameWidth, 79 - nameWidth);
+  out << "# STOCKHOLM 1.0" << endl;
+  out << "#=GF Score " << fmt6(a.score) << endl;
+  for (const auto& s : a.row) if (s.comment.size()) out << "#=GS CC " << s.name << ' ' << s.comment << endl;
+  for (size_t col = 0; col < a.columns(); col += dataWidth) {
+    if (col > 0) out << endl;
+    for (size_t r = 0; r < rowName.size(); ++r) {
+      string nm = rowName[r];
+      nm.resize(max(nm.size(), nameWidth), ' ');
+      out << nm << ' ' << rowData[r].substr(col, dataWidth) << endl;
+    }
+  }
+  out << "//" << endl;
+}
+
+static Alignment revcompAlignment(const Alignment& a) {  // Alignment::revcomp, src/qmodel.cpp:655-660
+  Alignment r = a;
+  for (int k = 0; k < 2; ++k) r.row[k] = revcomp(a.row[k]);
+  return r;
+}
+static void writeSam(ostream& out, const Alignment& a) {  // src/qmodel.cpp:608-616
+  if (a.row[0].source.rev) { writeSam(out, revcompAlignment(a)); return; }
+  const int flag = a.row[1].source.rev ? 16 : 0;
+  out << a.row[1].source.name << '\t' << flag << '\t' << a.row[0].source.name << '\t' << a.row[0].source.start << "\t0\t"
+      << cigarString(a) << "\t*\t0\t0\t*\t*\tAS:i:" << ((int)round(a.score)) << endl;
+}
+static FastSeq getUngapped(const Alignment& a, int r) {  // src/qmodel.cpp:662-676
+  const FastSeq& g = a.row[r];
+  FastSeq s = g;
+  s.seq.clear();
+  s.qual.clear();
+  for (size_t i = 0; i < g.seq.size(); ++i)
+    if (!isGap(g.seq[i])) { s.seq.push_back(g.seq[i]); if (g.hasQual()) s.qual.push_back(g.qual[i]); }
+  return s;
+}
+
+struct Printer {  // QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600
+  enum Format { Stockholm, Fasta, Sam, Refseq } format = Stockholm;
+  double threshold = 0;
+  string alignFilename;
+  ofstream alignFile;
+  ostream& stream(ostream& out) { return alignFilename.size() ? (ostream&)alignFile : out; }
+  bool parse(deque<string>& av) {
+    if (av.empty()) return false;
+    const string arg = av[0];
+    if (arg == "-format") {
+      Require(av.size() > 1, arg + " must have an argument");
+      const string f = av[1];
+      if (f == "fasta") format = Fasta; else if (f == "stockholm") format = Stockholm; else if (f == "sam") format = Sam;
+      else if (f == "refseq") format = Refseq; else Fail("Unknown format: " + f);
+      av.pop_front(); av.pop_front();
+      return true;
+    }
+    if (arg == "-threshold") { Require(av.size() > 1, arg + " must have an argument"); threshold = atof(av[1].c_str()); av.pop_front(); av.pop_front(); return true; }
+    if (arg == "-nothreshold") { threshold = -INFINITY; av.pop_front(); return true; }
+    if (arg == "-savealign") { Require(av.size() > 1, arg + " must have an argument"); alignFilename = av[1]; av.pop_front(); av.pop_front(); return true; }
+    return false;
+  }
+  void header(ostream& out, const vector<FastSeq>& refs, bool groupByQuery) {  // writeAlignmentHeader :2559-2564
+    if (alignFilename.size()) alignFile.open(alignFilename);
+    if (format == Sam) {
+      ostream& o = stream(out);
+      o << "@HD\tVN:1.0\t" << (groupByQuery ? "GO:query" : "SO:unknown") << endl;
+      for (const auto& s : refs) if (s.source.isNull()) o << "@SQ\tSN:" << s.name << "\tLN:" << s.seq.size() << endl;
+    }
+  }
+  void write(ostream& out, const Alignment& a) {  // writeAlignment :2566-2600
+    if (!(a.score >= threshold)) return;
+    ostream& o = stream(out);
+    switch (format) {
+      case Fasta: writeFasta(o, a.row[0]); writeFasta(o, a.row[1]); out << endl; break;
+      case Stockholm: writeStockholm(o, a); break;
+      case Sam: writeSam(o, a); break;
+      case Refseq: {
+        FastSeq ref = getUngapped(a, 0);
+        ref.comment = "matches(" + a.row[1].name + ") " + ref.comment;
+        writeFasta(o, ref);
+        break;
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------ options
+struct Opts {
+  deque<string> av;
+  deque<string> implicit;
+  qf_dp_config cfg{1, 1, 6, 14, 64, 0, 0};
+  bool autoMem = false;
+  vector<string> refFiles, readFiles;
+  bool fwdstrand = false, noquals = false;
+  string paramsFile, nullFile, saveNull;
+  bool parseConfig(bool refseq) {  // parseRefSeqConfigArgs / parseGeneralConfigArgs, src/qmodel.cpp:747-833
+    if (av.empty()) return false;
+    const string arg = av[0];
+    auto val = [&]() { Require(av.size() > 1, arg + " must have an argument"); const string v = av[1]; av.pop_front(); av.pop_front(); return v; };
+    if (refseq && arg == "-global") { cfg.local = 0; av.pop_front(); return true; }
+    if (arg == "-kmatchband") { cfg.band_size = atoi(val().c_str()); return true; }
+    if (arg == "-kmatch") {
+      cfg.kmer_len = atoi(val().c_str());
+      Require(cfg.kmer_len >= 5 && cfg.kmer_len <= 32, arg + " out of range (" + to_string(cfg.kmer_len) + "). Try 5 to 32");
+      return true;
+    }
+    if (arg == "-kmatchn") { cfg.kmer_threshold = atoi(val().c_str()); return true; }
+    if (arg == "-kmatchmb") {
+      cfg.max_size = (uint64_t)atoi(val().c_str()) << 20;
+      Require(cfg.max_size > 0, "-kmatchmb needs a size (the GPU build does not size by system RAM)");
+      cfg.kmer_threshold = -1;
+      return true;
+    }
+    if (arg == "-kmatchmax") Fail("-kmatchmax (size by system RAM) is not supported by the GPU build; use -kmatchmb <M>");
+    if (arg == "-kmatchoff") { cfg.sparse = 0; av.pop_front(); return true; }
+    if (arg == "-threads") { val(); return true; }           // accepted, ignored: the GPU batches instead
+    if (arg == "-maxthreads") { av.pop_front(); return true; }
+    return false;
+  }
+  bool parseLog() {  // Logger::parseLogArgs, src/logger.cpp:48-83: accepted and ignored
+    if (av.empty()) return false;
+    const string& arg = av[0];
+    if (arg == "-log") { Require(av.size() > 1, "-log must have an argument"); av.pop_front(); av.pop_front(); return true; }
+    if (arg == "-verbose" || arg == "-nocolor" || (arg.size() >= 2 && arg[0] == '-' && arg[1] == 'v' &&
+        arg.find_first_not_of("v0123456789", 1) == string::npos)) { av.pop_front(); return true; }
+    return false;
+  }
+  bool parseFiles(bool wantRefs) {
+    if (av.empty()) return false;
+    const string arg = av[0];
+    auto val = [&]() { Require(av.size() > 1, arg + " needs an argument"); const string v = av[1]; av.pop_front(); av.pop_front(); return v; };
+    if (arg == "-params") { paramsFile = val(); return true; }
+    if (arg == "-null") { nullFile = val(); return true; }
+    if (arg == "-savenull") { saveNull = val(); return true; }
+    if (wantRefs && arg == "-ref") { refFiles.push_back(val()); return true; }
+    if (arg == "-read") { readFiles.push_back(val()); return true; }
+    if (arg == "-fwdstrand") { fwdstrand = true; av.pop_front(); return true; }
+    return false;
+  }
+  bool parseUnknown() {  // OptParser::parseUnknown, src/optparser.cpp:30-53
+    if (av.empty()) return false;
+    const string arg = av[0];
+    if (arg[0] == '-' || implicit.empty()) Fail("Unknown option: " + arg + "\nError parsing command-line options");
+    av.push_front(implicit.front());
+    if (implicit.size() > 1) implicit.pop_front();
+    return true;
+  }
+};
+
+static string slurp(const string& fn) {
+  ifstream in(fn);
+  Require(!in.fail(), "Couldn't open " + fn);
+  stringstream ss;
+  ss << in.rdbuf();
+  return ss.str();
+}
+
+struct SeqSet {  // SeqList::loadSequences, t/quaff.cpp:610-636
+  vector<FastSeq> seqs;
+  size_t nOriginals = 0;
+  void load(const vector<string>& files, const string& type, const string& tag, bool wantQual, bool wantRevcomps, bool requireUnique) {
+    Require(!files.empty(), "Please specify at least one " + type + " file using " + tag);
+    for (const auto& f : files)
+      for (auto& fs : readFastSeqs(f)) {
+        if (wantQual) Require(fs.hasQual(), "Sequence " + fs.name + " in file " + f + " does not have quality scores");
+        else fs.qual.clear();
+        if (fs.seq.size()) seqs.push_back(fs);
+      }
+    nOriginals = seqs.size();
+    if (wantRevcomps) for (size_t n = 0; n < nOriginals; ++n) seqs.push_back(revcomp(seqs[n]));
+    Require(!seqs.empty(), "Please specify a valid " + type + " file using " + tag);
+    if (requireUnique) {
+      set<string> names, dups;
+      for (const auto& s : seqs) { if (names.count(s.name)) dups.insert(s.name); names.insert(s.name); }
+      if (!dups.empty()) {
+        cerr << "Duplicate names:";
+        for (const auto& d : dups) cerr << ' ' << d;
+        cerr << endl;
+        Fail("All " + type + " sequence names are required to be unique");
+      }
+    }
+  }
+};
+
+#define QF(ctx, call) do { if ((call) != QF_OK) Fail(string("libquaffhip: ") + qf_last_error(ctx)); } while (0)
+
+static void packSeqs(const vector<FastSeq>& v, size_t lo, size_t hi, string& seq, string& qual, vector<uint64_t>& off, bool& allQual) {
+  seq.clear(); qual.clear(); off.assign(1, 0);
+  allQual = true;
+  for (size_t n = lo; n < hi; ++n) allQual = allQual && v[n].hasQual() && !v[n].qual.empty();
+  for (size_t n = lo; n < hi; ++n) {
+    seq += v[n].seq;
+    if (allQual) qual += v[n].qual;
+    off.push_back(seq.size());
+  }
+}
+
+struct Session {
+  qf_ctx* ctx = nullptr;
+  Params params;
+  NullParams null;
+  Session() { if (qf_ctx_create(0, &ctx) != QF_OK) Fail(string("libquaffhip: ") + qf_last_error(nullptr)); }
+  ~Session() { qf_ctx_destroy(ctx); }
+  void loadParams(const Opts& o) {  // requireParamsOrUseDefaults, t/quaff.cpp:362-368
+    const string text = o.paramsFile.size() ? slurp(o.paramsFile) : string(kDefaultParamsJson);
+    Json j;
+    string err;
+    if (!parse_json(text, j, err) || !params.read_json(j, err)) Fail("Couldn't read parameters: " + err);
+    QF(ctx, qf_set_params_json(ctx, text.c_str()));
+  }
+  void setParams(const Params& p) {
+    params = p;
+    vector<double> ipqr(12), mpqr((size_t)4 * p.Km() * 3);
+    for (int i = 0; i < 4; ++i) { ipqr[i * 3] = p.insert[i].p; ipqr[i * 3 + 1] = p.insert[i].q; ipqr[i * 3 + 2] = p.insert[i].r; }
+    for (size_t m = 0; m < p.match.size(); ++m) { mpqr[m * 3] = p.match[m].p; mpqr[m * 3 + 1] = p.match[m].q; mpqr[m * 3 + 2] = p.match[m].r; }
+    QF(ctx, qf_set_params_raw(ctx, p.match_len, p.gap_len, p.refBase, p.beginInsert.data(), p.beginDelete.data(), p.extendInsert,
+                              p.extendDelete, ipqr.data(), mpqr.data()));
+  }
+  void loadNull(const Opts& o, const vector<FastSeq>& reads) {  // requireNullModelOrFit, t/quaff.cpp:419-429
+    if (o.nullFile.size()) {
+      const string text = slurp(o.nullFile);
+      Json j;
+      string err;
+      if (!parse_json(text, j, err) || !null.read_json(j, err)) Fail("Couldn't read null model parameters: " + err);
+      QF(ctx, qf_set_null_json(ctx, text.c_str()));
+    } else {
+      vector<string> s, q;
+      for (const auto& r : reads) { s.push_back(r.seq); q.push_back(r.qual); }
+      null = fit_null(s, q);
+      double pqr[12];
+      for (int i = 0; i < 4; ++i) { pqr[i * 3] = null.null[i].p; pqr[i * 3 + 1] = null.null[i].q; pqr[i * 3 + 2] = null.null[i].r; }
+      QF(ctx, qf_set_null_raw(ctx, null.nullEmit, pqr));
+    }
+    if (o.saveNull.size()) { ofstream out(o.saveNull); out << null.write_json(); }
+  }
+  void setRefs(const vector<FastSeq>& x) {
+    string s;
+    vector<uint64_t> off(1, 0);
+    for (const auto& fs : x) { s += fs.seq; off.push_back(s.size()); }
+    QF(ctx, qf_set_refs(ctx, s.data(), off.data(), (uint32_t)x.size()));
+  }
+};
+
+// gapped rows of a read-to-reference alignment from its CIGAR runs (QuaffViterbiMatrix::alignment, src/qmodel.cpp:1577-1645)
+static Alignment makeAlignment(const FastSeq& x, const FastSeq& y, const qf_alignment& al, const uint32_t* runs, bool local) {
+  Alignment a;
+  string &xr = a.row[0].seq, &yr = a.row[1].seq, &yq = a.row[1].qual;
+  size_t i = al.x_start - 1, j = 0;
+  const bool hq = y.hasQual();
+  for (uint32_t r = 0; r < al.n_runs; ++r) {
+    const uint32_t op = runs[r] & 3u, len = runs[r] >> 2;
+    for (uint32_t c = 0; c < len; ++c) {
+      if (op == 0) { xr += x.seq[i++]; yr += y.seq[j]; if (hq) yq += y.qual[j]; ++j; }
+      else if (op == 1) { xr += '-'; yr += y.seq[j]; if (hq) yq += y.qual[j]; ++j; }
+      else { xr += x.seq[i++]; yr += '-'; if (hq) yq += '~'; }
+    }
+  }
+  a.row[0].name = "Ref";
+  a.row[0].comment = local ? "substr(" + x.name + "," + to_string(al.x_start) + ".." + to_string(al.x_end) + ")" : x.name;
+  a.row[1].name = "Read";
+  a.row[1].comment = y.name;
+  Coords cx, cy;
+  cx.name = x.name; cx.start = al.x_start; cx.end = al.x_end;
+  cy.name = y.name; cy.start = 1; cy.end = (unsigned)y.seq.size();
+  a.row[0].source = cx.compose(x.source);
+  a.row[1].source = cy.compose(y.source);
+  a.score = al.score;
+  return a;
+}
+
+static int cmdAlign(Opts& o) {
+  Printer pr;
+  bool printAll = false;
+  o.implicit = {"-ref", "-read"};
+  o.cfg.kmer_threshold = 20;  // DEFAULT_REFSEQ_KMER_THRESHOLD, t/quaff.cpp:128
+  while (o.parseLog() || [&] { if (!o.av.empty() && o.av[0] == "-printall") { printAll = true; o.av.pop_front(); return true; } return false; }() ||
+         pr.parse(o.av) || o.parseConfig(true) || o.parseFiles(true) ||
+         [&] { if (!o.av.empty() && o.av[0] == "-noquals") { o.noquals = true; o.av.pop_front(); return true; } return false; }() ||
+         o.parseUnknown()) {}
+  SeqSet reads, refs;
+  reads.load(o.readFiles, "read", "-read", !o.noquals, false, true);
+  refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, true);
+  Session s;
+  s.loadParams(o);
+  s.loadNull(o, reads.seqs);
+  s.setRefs(refs.seqs);
+  pr.header(cout, refs.seqs, false);
+  const size_t batch = 65536;
+  for (size_t lo = 0; lo < reads.seqs.size(); lo += batch) {
+    const size_t hi = min(reads.seqs.size(), lo + batch);
+    string seq, qual;
+    vector<uint64_t> off;
+    bool allQual;
+    packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
+    qf_align_result res;
+    QF(s.ctx, qf_align_batch(s.ctx, &o.cfg, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo),
+                             printAll ? QF_ALIGN_ALL : QF_ALIGN_BEST, &res));
+    for (uint32_t a = 0; a < res.n_alignments; ++a) {
+      const qf_alignment& al = res.alignments[a];
+      pr.write(cout, makeAlignment(refs.seqs[al.ref], reads.seqs[lo + al.read], al, res.cigar_runs + al.run_offset, o.cfg.local));
+    }
+  }
+  return EXIT_SUCCESS;
+}
+
+// One E-step over all reads (QuaffTrainer::getCounts, src/qmodel.cpp:2005-2032), batched; counts summed in read order.
+static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_refs, bool useNull, vector<vector<uint32_t>>& sortOrder, double& logLike) {
+  ParamCounts total(s.params.match_len, s.params.gap_len);
+  logLike = 0;
+  const size_t batch = 16384;
+  for (size_t lo = 0; lo < reads.seqs.size(); lo += batch) {
+    const size_t hi = min(reads.seqs.size(), lo + batch);
+    string seq, qual;
+    vector<uint64_t> off;
+    bool allQual;
+    packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
+    QF(s.ctx, qf_upload_reads(s.ctx, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo)));
+    vector<uint32_t> sin, snin;
+    if (!sortOrder.empty()) {
+      for (size_t r = lo; r < hi; ++r) {
+        vector<uint32_t> row = sortOrder[r];
+        snin.push_back((uint32_t)row.size());
+        row.resize(n_refs, 0);
+        sin.insert(sin.end(), row.begin(), row.end());
+      }
+    }
+    qf_count_result res;
+    QF(s.ctx, qf_count_resident(s.ctx, &o.cfg, useNull ? 0 : QF_COUNT_FORCE, sin.empty() ? nullptr : sin.data(),
+                                snin.empty() ? nullptr : snin.data(), &res));
+    for (uint32_t c = 0; c < res.counts_size; ++c) total.v[c] += res.counts[c];
+    logLike += res.loglike;
+    if (sortOrder.empty()) { sortOrder.assign(reads.seqs.size(), vector<uint32_t>()); }
+    for (size_t r = lo; r < hi; ++r) {
+      vector<uint32_t>& so = sortOrder[r];
+      so.clear();
+      for (uint32_t k = 0; k < res.sort_count[r - lo]; ++k) so.push_back(res.sort_order[(r - lo) * res.n_refs + k]);
+    }
+  }
+  return total;
+}
+
+static bool parseTrainArgs(Opts& o, bool training, int& maxIter, double& minInc, long& maxReadBases, bool& allowNull,
+                           string& rawCounts, string& countsWithPrior, string& saveParams) {  // src/qmodel.cpp:1916-1993
+  if (o.av.empty()) return false;
+  const string arg = o.av[0];
+  auto val = [&]() { Require(o.av.size() > 1, arg + " must have an argument"); const string v = o.av[1]; o.av.pop_front(); o.av.pop_front(); return v; };
+  if (training && arg == "-maxiter") { maxIter = atoi(val().c_str()); return true; }
+  if (training && arg == "-mininc") { minInc = atof(val().c_str()); return true; }
+  if (training && arg == "-maxreadmb") { maxReadBases = atol(val().c_str()) << 20; return true; }
+  if (arg == "-force") { allowNull = false; o.av.pop_front(); return true; }
+  if (arg == "-savecounts") { rawCounts = val(); return true; }
+  if (training && arg == "-savecountswithprior") { countsWithPrior = val(); return true; }
+  if (training && arg == "-saveparams") { saveParams = val(); return true; }
+  return false;
+}
+
+static void fitRefSeqs(Params& qp, const vector<FastSeq>& refs) {  // src/qmodel.cpp:284-294; the reference reads an
+  long total = 0;                                                   // uninitialised totalLen there
+  long cnt[4] = {0, 0, 0, 0};
+  for (const auto& fs : refs) { total += fs.seq.size(); for (char c : fs.seq) { const int u = toupper(c); ++cnt[u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : 3]; } }
+  for (int i = 0; i < 4; ++i) qp.refBase[i] = cnt[i] / (double)total;
+}
+
+static int cmdTrainOrCount(Opts& o, bool training) {
+  int maxIter = 100;  // QuaffMaxEMIterations
+  double minInc = .01;
+  long maxReadBases = 0;
+  bool allowNull = true;
+  string rawCounts, countsWithPriorFile, saveParams, priorFile, savePrior;
+  int order = -1, suborder = -1, gaporder = -1;
+  o.implicit = {"-ref", "-read"};
+  o.cfg.kmer_threshold = 20;
+  auto parsePrior = [&]() {  // QuaffPriorIn::parsePriorArgs, t/quaff.cpp:431-480
+    if (!training || o.av.empty()) return false;
+    const string arg = o.av[0];
+    auto val = [&]() { Require(o.av.size() > 1, arg + " needs an argument"); const string v = o.av[1]; o.av.pop_front(); o.av.pop_front(); return v; };
+    if (arg == "-prior") { priorFile = val(); return true; }
+    if (arg == "-order") { order = atoi(val().c_str()); return true; }
+    if (arg == "-suborder") { suborder = atoi(val().c_str()); return true; }
+    if (arg == "-gaporder") { gaporder = atoi(val().c_str()); return true; }
+    if (arg == "-saveprior") { savePrior = val(); return true; }
+    return false;
+  };
+  while (o.parseLog() || parseTrainArgs(o, training, maxIter, minInc, maxReadBases, allowNull, rawCounts, countsWithPriorFile, saveParams) ||
+         o.parseConfig(true) || o.parseFiles(true) || parsePrior() || o.parseUnknown()) {}
+  SeqSet reads, refs;
+  reads.load(o.readFiles, "read", "-read", true, false, false);
+  refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, false);
+  Session s;
+  s.loadNull(o, reads.seqs);
+  if (!training) {
+    s.loadParams(o);
+    s.setRefs(refs.seqs);
+    vector<vector<uint32_t>> so;
+    double ll;
+    ParamCounts counts = eStep(s, o, reads, (uint32_t)refs.seqs.size(), true, so, ll);
+    if (rawCounts.size()) { ofstream out(rawCounts); out << counts.write_json() << endl; }
+    else cout << counts.write_json();
+    return EXIT_SUCCESS;
+  }
+  // prior: file, or auto from the null model (requirePriorOrUseNullModel, t/quaff.cpp:490-515)
+  unsigned ml = 1, gl = 0;
+  bool lenSpecified = false;
+  if (order >= 0) { gl = order; ml = 1 + order; lenSpecified = true; }
+  if (suborder >= 0) { ml = 1 + suborder; lenSpecified = true; }
+  if (gaporder >= 0) { gl = gaporder; lenSpecified = true; }
+  Params seed;
+  const bool haveParams = o.paramsFile.size() > 0;
+  if (haveParams) { s.loadParams(o); seed = s.params; }
+  ParamCounts prior(ml, gl);
+  if (priorFile.size()) {
+    Json j;
+    string err;
+    if (!parse_json(slurp(priorFile), j, err) || !prior.read_json(j, err)) Fail("Couldn't read counts: " + err);
+    if (haveParams) Require(prior.match_len == seed.match_len && prior.gap_len == seed.gap_len, "Order of dependence in prior file does not match order in parameter file");
+  } else {
+    if (haveParams) {
+      if (lenSpecified) Require(ml == seed.match_len && gl == seed.gap_len, "Order of dependence specified on command line does not match order in parameter file");
+      else prior.resize(seed.match_len, seed.gap_len);
+    }
+    prior.init_counts(9, 9, 5, 1, &s.null);
+  }
+  if (savePrior.size()) { ofstream out(savePrior); out << prior.write_json(); }
+  if (!haveParams) seed = prior.fit();  // requireParamsOrUsePrior, t/quaff.cpp:370-376
+  // QuaffTrainer::fit / fitUnlimited, src/qmodel.cpp:2169-2231
+  SeqSet used = reads;
+  if (maxReadBases > 0) {
+    used.seqs.clear();
+    long bases = 0;
+    for (const auto& y : reads.seqs) { used.seqs.push_back(y); bases += y.seq.size(); if (bases >= maxReadBases) break; }
+  }
+  Params qp = seed;
+  s.setRefs(refs.seqs);
+  vector<vector<uint32_t>> sortOrder;
+  double prevLL = -INFINITY;
+  for (int iter = 0; iter < maxIter; ++iter) {
+    s.setParams(qp);
+    double logLike = 0;
+    ParamCounts counts = eStep(s, o, used, (uint32_t)refs.seqs.size(), allowNull, sortOrder, logLike);
+    if (rawCounts.size()) { ofstream out(rawCounts); out << counts.write_json() << endl; }
+    const double logPrior = prior.log_prior(qp);
+    const double llp = logLike + logPrior;
+    cerr << "EM iteration " << (iter + 1) << ": log-likelihood (" << fmt6(logLike) << ") + log-prior (" << fmt6(logPrior) << ") = " << fmt6(llp) << endl;
+    if (iter > 0 && llp < prevLL + fabs(prevLL) * minInc) break;
+    prevLL = llp;
+    ParamCounts withPrior = counts;
+    withPrior.add_weighted(prior, 1.);
+    if (countsWithPriorFile.size()) { ofstream out(countsWithPriorFile); out << withPrior.write_json() << endl; }
+    qp = withPrior.fit();
+    fitRefSeqs(qp, refs.seqs);
+    if (saveParams.size()) { ofstream out(saveParams); out << qp.write_json() << endl; }
+  }
+  if (saveParams.empty()) cout << qp.write_json();
+  return EXIT_SUCCESS;
+}
+
+// gapped rows of an overlap alignment with the reference's indel squashing (src/qoverlap.cpp:231-289)
+static Alignment makeOverlapAlignment(const FastSeq& x, const FastSeq& y, const qf_overlap_alignment& al, const uint32_t* runs) {
+  Alignment a;
+  string &xr = a.row[0].seq, &yr = a.row[1].seq, &xq = a.row[0].qual, &yq = a.row[1].qual;
+  const bool hx = x.hasQual(), hy = y.hasQual();
+  size_t i = al.x_start - 1, j = al.y_start - 1;
+  uint32_t r = 0;
+  while (r < al.n_runs) {
+    if ((runs[r] & 3u) == 0) {
+      for (uint32_t c = 0; c < (runs[r] >> 2); ++c) { xr += x.seq[i]; yr += y.seq[j]; if (hx) xq += x.qual[i]; if (hy) yq += y.qual[j]; ++i; ++j; }
+      ++r;
+      continue;
+    }
+    size_t nins = 0, ndel = 0;
+    while (r < al.n_runs && (runs[r] & 3u) != 0) { ((runs[r] & 3u) == 1 ? nins : ndel) += runs[r] >> 2; ++r; }
+    const size_t shared = min(nins, ndel);
+    xr += x.seq.substr(i, ndel) + string(nins - shared, '-');
+    yr += y.seq.substr(j, shared) + string(ndel - shared, '-') + y.seq.substr(j + shared, nins - shared);
+    if (hx) xq += x.qual.substr(i, ndel) + string(nins - shared, '~');
+    if (hy) yq += y.qual.substr(j, shared) + string(ndel - shared, '~') + y.qual.substr(j + shared, nins - shared);
+    i += ndel; j += nins;
+  }
+  a.row[0].name = "read_x";
+  a.row[0].comment = "substr(" + x.name + "," + to_string(al.x_start) + ".." + to_string(al.x_end) + ")";
+  a.row[1].name = "read_y";
+  a.row[1].comment = "substr(" + y.name + "," + to_string(al.y_start) + ".." + to_string(al.y_end) + ")";
+  Coords cx, cy;
+  cx.name = x.name; cx.start = al.x_start; cx.end = al.x_end;
+  cy.name = y.name; cy.start = al.y_start; cy.end = al.y_end;
+  a.row[0].source = cx.compose(x.source);
+  a.row[1].source = cy.compose(y.source);
+  a.score = al.score;
+  return a;
+}
+
+static int cmdOverlap(Opts& o) {
+  Printer pr;
+  o.implicit = {"-read"};
+  while (o.parseLog() || pr.parse(o.av) || o.parseConfig(false) || o.parseFiles(false) ||
+         [&] { if (!o.av.empty() && o.av[0] == "-noquals") { o.noquals = true; o.av.pop_front(); return true; } return false; }() ||
+         o.parseUnknown()) {}
+  SeqSet reads;
+  reads.load(o.readFiles, "read", "-read", !o.noquals, !o.fwdstrand, true);
+  Session s;
+  s.loadParams(o);
+  s.loadNull(o, reads.seqs);
+  pr.header(cout, reads.seqs, true);
+  string seq, qual;
+  vector<uint64_t> off;
+  bool allQual;
+  packSeqs(reads.seqs, 0, reads.seqs.size(), seq, qual, off, allQual);
+  QF(s.ctx, qf_upload_reads(s.ctx, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
+  // pair order of QuaffOverlapScheduler, src/qoverlap.cpp:475-480,528-547
+  vector<uint32_t> px, py;
+  vector<uint8_t> pc;
+  const size_t N = reads.nOriginals, total = reads.seqs.size(), chunk = 1 << 18;
+  auto flush = [&]() {
+    if (px.empty()) return;
+    qf_overlap_result res;
+    QF(s.ctx, qf_overlap_resident(s.ctx, &o.cfg, px.data(), py.data(), pc.data(), (uint32_t)px.size(), &res));
+    for (uint32_t a = 0; a < res.n_alignments; ++a) {
+      const qf_overlap_alignment& al = res.alignments[a];
+      pr.write(cout, makeOverlapAlignment(reads.seqs[px[al.pair]], reads.seqs[py[al.pair]], al, res.state_runs + al.run_offset));
+    }
+    px.clear(); py.clear(); pc.clear();
+  };
+  for (size_t nx = 0; nx + 1 < N; ++nx)
+    for (size_t ny = nx + 1; ny < total; ++ny) {
+      px.push_back((uint32_t)nx); py.push_back((uint32_t)ny); pc.push_back(ny >= N);
+      if (px.size() >= chunk) flush();
+    }
+  flush();
+  return EXIT_SUCCESS;
+}
+
+int main(int argc, char** argv) {
+  Opts o;
+  for (int n = 1; n < argc; ++n) o.av.push_back(argv[n]);
+  if (o.av.empty()) { cerr << "Usage: quaff {help,train,align,overlap} [options]" << endl; return EXIT_FAILURE; }
+  const string command = o.av[0];
+  o.av.pop_front();
+  if (command == "align") return cmdAlign(o);
+  if (command == "count") return cmdTrainOrCount(o, false);
+  if (command == "train") return cmdTrainOrCount(o, true);
+  if (command == "overlap") return cmdOverlap(o);
+  if (command == "help" || command == "-h" || command == "--help" || command == "-help") {
+    cout << "Usage: quaff {help,train,align,overlap} [options]\n\n"
+            " quaff train refs.fasta reads.fastq >params.json   (-maxiter -mininc -maxreadmb -force -order/-suborder/-gaporder\n"
+            "                                                    -prior -saveprior -saveparams -savecounts -savecountswithprior)\n"
+            " quaff align refs.fasta reads.fastq                (-printall)\n"
+            " quaff overlap reads.fastq\n"
+            " quaff count refs.fasta reads.fastq                (one E-step; -savecounts)\n\n"
+            "Alignment options: -threshold <n> -nothreshold -noquals -savealign <file> -format {fasta,stockholm,sam,refseq}\n"
+            "General: -params <file> -ref <file> -read <file> -fwdstrand -global -null <file> -savenull <file>\n"
+            "         -kmatch <k> -kmatchn <n> -kmatchband <n> -kmatchmb <M> -kmatchoff\n"
+            "All dynamic programming runs on GPU 0 through libquaffhip (include/quaff_hip.h).\n";
+    return EXIT_SUCCESS;
+  }
+  if (command == "version" || command == "-V" || command == "--version") { cout << "quaff (hip) 0.1" << endl; return EXIT_SUCCESS; }
+  cerr << "Usage: quaff {help,train,align,overlap} [options]\nUnrecognized command: " << command << endl;
+  return EXIT_FAILURE;
+}

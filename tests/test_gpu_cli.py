@@ -1,0 +1,81 @@
+"""The `quaff` command-line shell (quaff_amd/bin/quaff, C++ over the C ABI) against the reference's own integration
+goldens (Makefile:146-156) — the same commands `make test` runs — and against the oracle for SAM output."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import rand_seq, make_reads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUAFF = os.path.join(ROOT, "quaff_amd", "bin", "quaff")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+C8 = os.path.join(GOLDEN, "c8f30.fastq.gz")
+
+
+def run(*args):
+    out = subprocess.run([QUAFF] + list(args), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_align_self_golden():
+    assert run("align", C8, C8, "-kmatchmb", "10", "-fwdstrand") == open(os.path.join(GOLDEN, "c8f30-self-align.json")).read()
+
+
+def test_count_self_golden():
+    got = run("count", C8, C8, "-kmatchmb", "10", "-fwdstrand")
+    want = open(os.path.join(GOLDEN, "c8f30-self-counts.json")).read()
+    if got != want:       # 1e-4 tolerance on Forward-Backward counts: allow last-digit differences of the 6 s.f. text
+        import re
+        g, w = (list(map(float, re.findall(r"-?\d+\.?\d*(?:e[-+]?\d+)?", t))) for t in (got, want))
+        assert len(g) == len(w)
+        np.testing.assert_allclose(g, w, rtol=1e-4, atol=1e-6)
+
+
+def test_overlap_self_golden(tmp_path):
+    copy = tmp_path / "copy-of-c8f30.fastq"
+    copy.write_text(gzip.open(C8, "rt").read().replace("channel", "copy", 1))
+    assert run("overlap", C8, str(copy), "-kmatchmb", "10", "-fwdstrand") == open(os.path.join(GOLDEN, "c8f30-self-overlap.json")).read()
+
+
+def test_align_sam_both_strands(tmp_path):
+    """SAM output incl. the reverse-strand POS/CIGAR quirk, explicit -params/-null files."""
+    rng = np.random.default_rng(51)
+    ref = rand_seq(rng, 2500)
+    reads = make_reads(rng, ref, 10, 300)
+    (tmp_path / "ref.fa").write_text(">chr1 test\n" + "\n".join(ref[i:i + 70] for i in range(0, len(ref), 70)) + "\n")
+    (tmp_path / "reads.fq").write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    nullf = os.path.join(GOLDEN, "testquaffnullparams.json")
+    got = run("align", str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq"), "-null", nullf, "-format", "sam",
+              "-params", os.path.join(GOLDEN, "defaultparams.json"))
+    sc = O.Scores(O.Params.from_json(open(os.path.join(GOLDEN, "defaultparams.json")).read()))
+    null = O.NullParams.from_json(open(nullf).read())
+    x = O.FastSeq("chr1", ref, "", "test")
+    refs = [x, x.revcomp()]
+    want = "@HD\tVN:1.0\tSO:unknown\n@SQ\tSN:chr1\tLN:2500\n"
+    for r in reads:
+        al = O.align_read(refs, r, sc, null, O.DPConfig())[0]
+        if al["score"] >= 0:
+            want += O.sam_line(refs[al["ref"]], r, al)
+    assert got == want
+    assert "\t16\t" in got and "\t0\tchr1" in got
+
+
+def test_train_runs_and_improves(tmp_path):
+    rng = np.random.default_rng(52)
+    ref = rand_seq(rng, 3000)
+    reads = make_reads(rng, ref, 40, 250)
+    (tmp_path / "ref.fa").write_text(">ref\n" + ref + "\n")
+    (tmp_path / "reads.fq").write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    out = subprocess.run([QUAFF, "train", str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq"), "-maxiter", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lls = [float(l.split("log-likelihood (")[1].split(")")[0]) for l in out.stderr.splitlines() if "EM iteration" in l]
+    assert len(lls) >= 2 and lls[1] > lls[0]
+    p = O.Params.from_json(out.stdout)          # parses as a quaff params file
+    assert 0 < p.extendInsert < 1 and abs(p.match[0, 0, 0] + p.match[0, 1, 0] + p.match[0, 2, 0] + p.match[0, 3, 0] - 1) < 1e-5
