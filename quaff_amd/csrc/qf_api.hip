@@ -359,7 +359,7 @@ static int ensure_ref_index(qf_ctx* c, int k) {
   const size_t bytes = (size_t)c->n_refs * (nb + 1) * 4;
   HIPCHK(c, c->d_bucket.reserve(bytes));
   HIPCHK(c, c->d_cursor.reserve(bytes));
-  HIPCHK(c, c->d_pos.reserve(c->ref_total * 4));
+  HIPCHK(c, c->d_pos.reserve((c->ref_total + 16) * 4));  // + slack: the seeding kernel reads bucket entries four at a time
   HIPCHK(c, hipMemsetAsync(c->d_bucket.p, 0, bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_cursor.p, 0, bytes, c->stream));
   launch_ref_index(c->d_ref_tok.as<uint8_t>(), c->d_ref_off.as<uint64_t>(), c->n_refs, c->ref_maxlen, (uint32_t)k, nb,

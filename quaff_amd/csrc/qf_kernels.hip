@@ -407,35 +407,37 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   const uint32_t* __restrict__ pos = a.ref_pos + xb;
   const uint32_t* __restrict__ sk = a.skmer + yb;
   const int nk = yLen - k + 1;  // read k-mers (>= 1 here)
-  const uint32_t lastQuad = (uint32_t)max(xLen - 4, 0);
   // visit(bin) for every (i, j) with equal k-mers, bin = i - j + yLen - 1 (diagenv.cpp:33-40).
   // R read positions per lane per round; the three dependent loads are issued as batches.
   auto walk = [&](auto&& visit) {
     constexpr int R = 4;
     for (int j0 = 0; j0 < nk; j0 += 64 * R) {
       uint32_t km[R], s[R], e[R];
-#pragma unroll
+#pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
         const int j = j0 + c * 64 + (int)lane;
         km[c] = j < nk ? sk[j] : 0xFFFFFFFFu;
       }
-#pragma unroll
+#pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
         s[c] = km[c] != 0xFFFFFFFFu ? starts[km[c]] : 0u;
         e[c] = km[c] != 0xFFFFFFFFu ? starts[km[c] + 1] : 0u;
       }
-      U32x4u p4[R];
-#pragma unroll
-      for (int c = 0; c < R; ++c) p4[c] = *(const U32x4u*)(pos + min(s[c], lastQuad));
-#pragma unroll
+      uint32_t pa[R], pb[R], pc[R], pd[R];  // the first four entries of each bucket (the index has 4 words of slack)
+#pragma clang loop unroll(full)
+      for (int c = 0; c < R; ++c) {
+        const uint32_t* q4 = pos + s[c];
+        pa[c] = q4[0]; pb[c] = q4[1]; pc[c] = q4[2]; pd[c] = q4[3];
+      }
+#pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
         const int j = j0 + c * 64 + (int)lane;
         const uint32_t n = e[c] - s[c];
-        const uint32_t shift = s[c] - min(s[c], lastQuad);  // bucket entry q sits at p4.v[q + shift]
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if ((uint32_t)q < n && q + shift < 4) visit((int)p4[c].v[q + shift] - j + yLen - 1);
-        for (uint32_t q = 4 - shift; q < n; ++q) visit((int)pos[s[c] + q] - j + yLen - 1);  // long buckets
+        if (n > 0) visit((int)pa[c] - j + yLen - 1);
+        if (n > 1) visit((int)pb[c] - j + yLen - 1);
+        if (n > 2) visit((int)pc[c] - j + yLen - 1);
+        if (n > 3) visit((int)pd[c] - j + yLen - 1);
+        for (uint32_t q = 4; q < n; ++q) visit((int)pos[s[c] + q] - j + yLen - 1);  // long buckets
       }
     }
   };
