@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--band", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (rehearse the N>1 path on a one-GPU box)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = this process's CPU share (at most 16)")
@@ -103,7 +104,7 @@ def main():
     ctx.set_refs([ref, api.revcomp(ref)])
     seq, qual, off = api.synth_reads(2 + rank, ref, a.reads, a.read_len)
     ctx.upload_reads_packed(seq, qual, off)          # resident in HBM before the timed region
-    cfg = Q.DPConfig(band_size=a.band)
+    cfg = Q.DPConfig(band_size=a.band, debug_flags=2 if a.reference_kernel else 0)
 
     def sync_all():
         if world > 1:

@@ -556,6 +556,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   fa.dp.i2m = sc.trans[4 * sc.Kg + 3];
   fa.dp.Kg = sc.Kg;
   fa.dp.local = cfg->local;
+  fa.reference_kernel = (cfg->reserved >> 1) & 1;
   // widest classes first: they run longest
   for (int cls = kNumClasses - 1; cls >= 0; --cls) {
     HIPCHK(c, hipEventRecord(c->cls_ev[cls + 1], c->stream));

@@ -793,6 +793,211 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_viterbi_fill2: the same wavefront and the same bits as k_viterbi_fill, with a trimmed instruction stream.
+//  * Every step is classified wave-uniformly.  A FAST step has no lane on its first or last read column and no lane
+//    whose band pokes above reference row 1; it needs no start candidate, no end tracking and no row/column validity
+//    masking (cells before a lane's first column are -inf by construction, cells below the last reference row or
+//    after the last column are never read by a valid cell).  Everything else takes the general SLOW step.  For a
+//    1 kb read ~95 % of the steps are FAST.
+//  * Values come from v_max_f64; the traceback flags from compares of the same candidates (first maximum in the
+//    reference's M, I, D order) instead of value/flag select chains.
+//  * Lane exchange by DPP row/wave shifts (a -inf "old" value fills the group's edge lane) instead of ds_bpermute.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf in the group's lane 0
+  constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int G>
+__device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf in the group's last lane
+  constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int G, int B, bool GAPCTX>
+__global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
+  constexpr int UPW = 64 / G;
+  constexpr int WPL = B > 8 ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int grp = lane / G, l = lane % G;
+  const uint32_t uidx = wave * UPW + grp;
+  const bool active = uidx < a.n_cls_units;
+
+  uint32_t uid = 0;
+  int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, xw = 0, tb_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb); xw = a.ref_woff[x];
+    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
+    dlo = u.dlo; dhi = u.dhi; tb_off = u.tb_off;
+  }
+  int T = active ? yLen + G - 1 : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+
+  const int d0 = dlo + l * B;
+  const int bmax = active ? dhi - d0 : -1;  // slots b > bmax are outside the band
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg], c_m2e = trans[3 * Kg];
+
+  double M[B], I[B], D[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
+  double pubM = QF_NEG_INF, pubD = QF_NEG_INF;
+  double bestEnd = QF_NEG_INF;
+  uint32_t bestI = 0;
+
+  const uint32_t* __restrict__ xp = a.ref_packed + xw;
+  const int nxw = (xLen + 15) / 16 + 2;
+  const int rtop0 = d0 - l + B - 1;
+  const int q0 = rtop0 >> 4, sh0 = 2 * (rtop0 & 15);
+  auto xword = [&](int q) -> uint32_t { return xp[min(max(q, 0), nxw - 1)]; };
+  uint32_t xlo, xhi = xword(q0), xnx = xword(q0 + 1);
+  uint32_t win = 0;
+  {
+    const uint8_t* xt = a.ref_tok + xb;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int row = d0 - l - 1 + b;
+      const uint32_t t = (row >= 0 && row < xLen) ? xt[row] : 0u;
+      win |= t << (2 * b);
+    }
+  }
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  U32x4 cwn = *(const U32x4*)(ctx + (0 - l));
+  uint32_t gkPrev = 0;
+  uint32_t* __restrict__ tb = a.tb + tb_off;
+
+  int chunk = 0;
+  for (int t0 = 0; t0 < T; t0 += 16, ++chunk) {
+    xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
+    const unsigned long long xpair = ((unsigned long long)xhi << 32) | xlo;
+    for (int s4 = 0; s4 < 16; s4 += 4) {
+      const U32x4 cw = cwn;
+      cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = t0 + s4 + s;
+        const int j = t - l + 1;
+        const bool colvalid = active && j >= 1 && j <= yLen;
+        const uint32_t w = cw.v[s];
+        const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
+        double m2m, m2i, m2d;
+        if (GAPCTX) {
+          const uint32_t gp = j <= 1 ? 0u : gkPrev;
+          m2m = trans[gp]; m2i = trans[Kg + gp]; m2d = trans[2 * Kg + gk];
+          gkPrev = gk;
+        } else {
+          m2m = c_m2m; m2i = c_m2i; m2d = c_m2d;
+        }
+        const double insE = eins[insrow];
+        const uint32_t newTok = (uint32_t)(xpair >> (sh0 + 2 * (s4 + s))) & 3u;
+        win = (win >> 2) | (newTok << (2 * (B - 1)));
+        const double lowM = dpp_from_below<G>(pubM), lowD = dpp_from_below<G>(pubD);
+        double e[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) e[b] = ematch[erow4 + ((win >> (2 * b)) & 3u)];
+
+        // a lane needs the general step on its first / last column and while its lowest row is above row 1
+        const bool needSlow = active && (j == 1 || j == yLen || (j > 1 && j < yLen && d0 + j < 1));
+        uint32_t tbw0 = 0, tbw1 = 0;
+        double upM = 0, upI = 0;
+        double prevM = lowM, prevD = lowD;
+        if (!__builtin_amdgcn_ballot_w64(needSlow)) {
+          // ---------------- FAST step
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            const double tM = (M[b] + m2m) + e[b], tI = (I[b] + i2m) + e[b], tD = (D[b] + d2m) + e[b];
+            const double m1 = fmax(tM, tI);
+            const double nm = fmax(m1, tD);
+            uint32_t sm = tI > tM ? 1u : 0u;     // first maximum in the order M, I, D (strict >)
+            sm = tD > m1 ? 2u : sm;
+            double srcM, srcI;
+            if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
+            const double cM = (srcM + m2i) + insE, cI = (srcI + i2i) + insE;
+            const double ni = fmax(cM, cI);
+            const uint32_t si = cI > cM ? 4u : 0u;
+            const double gM = prevM + m2d, gD = prevD + d2d;
+            double ndl = fmax(gM, gD);
+            const uint32_t sd = gD > gM ? 8u : 0u;
+            if (b > bmax) ndl = QF_NEG_INF;      // the slot just outside the band must not pick up del from inside it
+            M[b] = nm; I[b] = ni; D[b] = ndl;
+            prevM = nm; prevD = ndl;
+            const uint32_t nib = sm | si | sd;
+            if (b < 8) tbw0 |= nib << (4 * (b & 7)); else tbw1 |= nib << (4 * (b & 7));
+            if (b == 0) { upM = dpp_from_above<G>(nm); upI = dpp_from_above<G>(ni); }
+          }
+        } else {
+          // ---------------- general step (start candidate, end tracking, full validity masking)
+          const bool startCol = j == 1, endCol = j == yLen;
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            const int d = d0 + b, i = d + j;
+            const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
+            const double tM = (M[b] + m2m) + e[b], tI = (I[b] + i2m) + e[b], tD = (D[b] + d2m) + e[b];
+            double nm = tM;
+            uint32_t sm = 0;
+            if (tI > nm) { nm = tI; sm = 1; }
+            if (tD > nm) { nm = tD; sm = 2; }
+            if (startCol && (i == 1 || local) && e[b] > nm) { nm = e[b]; sm = 3; }
+            double srcM, srcI;
+            if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
+            const double cM = (srcM + m2i) + insE, cI = (srcI + i2i) + insE;
+            double ni = cM;
+            uint32_t si = 0;
+            if (cI > ni) { ni = cI; si = 1; }
+            const double gM = prevM + m2d, gD = prevD + d2d;
+            double ndl = gM;
+            uint32_t sd = 0;
+            if (gD > ndl) { ndl = gD; sd = 1; }
+            // idle lanes (before their first column) stay -inf by themselves; cells below the last reference row or
+            // past the last column may hold anything (never read by a valid cell) but are forced to -inf here too
+            if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+            M[b] = nm; I[b] = ni; D[b] = ndl;
+            prevM = nm; prevD = ndl;
+            const uint32_t nib = sm | (si << 2) | (sd << 3);
+            if (b < 8) tbw0 |= nib << (4 * (b & 7)); else tbw1 |= nib << (4 * (b & 7));
+            if (endCol && valid && (local || i == xLen)) {
+              const double ev = nm + (GAPCTX ? trans[3 * Kg + gk] : c_m2e);
+              if (ev >= bestEnd) { bestEnd = ev; bestI = (uint32_t)i; }
+            }
+            if (b == 0) { upM = dpp_from_above<G>(nm); upI = dpp_from_above<G>(ni); }
+          }
+        }
+        pubM = prevM; pubD = prevD;
+        if (colvalid) {
+          if (WPL == 1) tb[(uint64_t)t * G + l] = tbw0;
+          else { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
+        }
+      }
+    }
+  }
+  for (int o = 1; o < G; o <<= 1) {
+    const double ov = __shfl_xor(bestEnd, o, G);
+    const uint32_t oi = __shfl_xor(bestI, o, G);
+    if (ov > bestEnd || (ov == bestEnd && oi > bestI)) { bestEnd = ov; bestI = oi; }
+  }
+  if (active && l == 0) {
+    a.units[uid].end_val = bestEnd;
+    a.units[uid].end_i = bestI;
+  }
+}
+
 // Single-diagonal units (the lone diagonal 0, wrong-strand pairs): no neighbours, so ins = del = -inf and
 // the match state is a serial chain.  One lane per unit, 8 traceback nibbles per word.
 __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
@@ -1119,8 +1324,13 @@ __global__ void k_traceback(FinalArgs a) {
 template <int G, int B>
 static void launch_fill_gb(const FillArgs& a, bool gapctx, hipStream_t s) {
   const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
-  if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_viterbi_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+  if (a.reference_kernel) {  // the first-generation kernel, kept for A/B and as a cross-check (same results)
+    if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_viterbi_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+  } else {
+    if (gapctx) hipLaunchKernelGGL((k_viterbi_fill2<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_viterbi_fill2<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+  }
 }
 
 void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s) {

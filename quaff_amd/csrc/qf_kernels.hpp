@@ -75,6 +75,7 @@ struct FillArgs {
   const uint32_t* ctx;         // offset past the front pad
   uint32_t* tb;
   DpParams dp;
+  int reference_kernel;        // 1: launch the first-generation fill kernel (debug / A-B)
 };
 
 struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
