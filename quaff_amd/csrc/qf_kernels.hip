@@ -10,6 +10,9 @@ namespace qf {
 
 #define QF_NEG_INF (-__builtin_huge_val())
 
+struct __attribute__((packed, aligned(4))) U32x4 { uint32_t v[4]; };   // 16-byte load from a 4-byte aligned address
+struct __attribute__((packed, aligned(1))) U8x16 { uint32_t v[4]; };   // 16-byte load from any address
+
 // ------------------------------------------------------------------------------------------------
 // Sequence preparation
 // ------------------------------------------------------------------------------------------------
@@ -159,13 +162,29 @@ __global__ __launch_bounds__(64) void k_null_ll(PrepArgs a, uint32_t n_reads) {
     const uint64_t b = a.off[r];
     const uint32_t L = (uint32_t)(a.off[r + 1] - b);
     ll = (double)L * a.null_logEmit + a.null_log1mEmit;
-    for (uint32_t i = 0; i < L; ++i) {
-      const uint32_t t = a.tok[b + i];
-      ll += a.null_logSym[t];
-      if (a.qual) {
-        const int v = (int)(signed char)a.qual[b + i] - '!';
-        ll += a.null_logQual[t * kNQualDev + max(0, min(kNQualDev - 1, v))];
+    // 16 bases per round: token / quality bytes and the table values are independent loads, only the adds are serial
+    // (buffers are allocated with 16 bytes of slack, so the last round may read past the read)
+    for (uint32_t i0 = 0; i0 < L; i0 += 16) {
+      const U8x16 tw = *(const U8x16*)(a.tok + b + i0);
+      U8x16 qw{};
+      if (a.qual) qw = *(const U8x16*)(a.qual + b + i0);
+      double ls[16], lq[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t t = (tw.v[c >> 2] >> (8 * (c & 3))) & 3u;
+        ls[c] = a.null_logSym[t];
+        lq[c] = 0;
+        if (a.qual) {
+          const int v = (int)(signed char)((qw.v[c >> 2] >> (8 * (c & 3))) & 0xFFu) - '!';
+          lq[c] = a.null_logQual[t * kNQualDev + max(0, min(kNQualDev - 1, v))];
+        }
       }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (i0 + c < L) {
+          ll += ls[c];
+          if (a.qual) ll += lq[c];
+        }
     }
   }
   a.nll[r] = ll;
@@ -626,7 +645,6 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
 // so a group advances all its lanes every step.  Each cell records 4 traceback bits chosen exactly as
 // QuaffViterbiMatrix::alignment's updateMax sequence would choose them (src/qmodel.cpp:1590-1616).
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) U32x4 { uint32_t v[4]; };
 
 template <int G, int B, bool GAPCTX>
 __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
@@ -804,6 +822,9 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
 //    reference's M, I, D order) instead of value/flag select chains.
 //  * Lane exchange by DPP row/wave shifts (a -inf "old" value fills the group's edge lane) instead of ds_bpermute.
 // ------------------------------------------------------------------------------------------------
+#ifndef QF_STEP_UNROLL
+#define QF_STEP_UNROLL 4
+#endif
 template <int G>
 __device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf in the group's lane 0
   constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
@@ -888,14 +909,15 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
     xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
     const unsigned long long xpair = ((unsigned long long)xhi << 32) | xlo;
     for (int s4 = 0; s4 < 16; s4 += 4) {
-      const U32x4 cw = cwn;
+      U32x4 cw = cwn;
       cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
-#pragma unroll
+#pragma unroll QF_STEP_UNROLL
       for (int s = 0; s < 4; ++s) {
         const int t = t0 + s4 + s;
         const int j = t - l + 1;
         const bool colvalid = active && j >= 1 && j <= yLen;
-        const uint32_t w = cw.v[s];
+        const uint32_t w = cw.v[0];
+        cw.v[0] = cw.v[1]; cw.v[1] = cw.v[2]; cw.v[2] = cw.v[3];
         const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
         double m2m, m2i, m2d;
         if (GAPCTX) {
@@ -1020,28 +1042,54 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
   const double* __restrict__ trans = a.dp.trans;
   const uint32_t Kg = a.dp.Kg;
   const bool local = a.dp.local != 0;
-  const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
   uint32_t* __restrict__ tb = a.tb + tb_off;
   double M = QF_NEG_INF, bestEnd = QF_NEG_INF;
-  uint32_t bestI = 0, word = 0, gkPrev = 0;
-  for (int j = 1; j <= T; ++j) {
-    const int i = d + j;
-    const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
-    const uint32_t w = ctx[j - 1];
-    const uint32_t gk = w >> 24;
-    const uint32_t tok = valid ? xt[i - 1] : 0u;
-    const double e = ematch[(w & 0x7FFFu) * 4u + tok];
-    const double tM = (M + trans[j <= 1 ? 0u : gkPrev]) + e;
-    gkPrev = gk;
-    double nm = tM;
-    uint32_t sm = 0;
-    if (j == 1 && (i == 1 || local) && e > nm) { nm = e; sm = 3; }
-    if (!valid) nm = QF_NEG_INF;
-    M = nm;
-    word |= sm << (4 * ((j - 1) & 7));
-    if (((j & 7) == 0 || j == yLen) && active && j <= yLen) { tb[(j - 1) >> 3] = word; word = 0; }
-    if (j == yLen && valid && (local || i == xLen)) { bestEnd = nm + trans[3 * Kg + gk]; bestI = (uint32_t)i; }
+  uint32_t bestI = 0, gkPrev = 0;
+  // Eight columns per round: the context words, reference tokens (2-bit packed) and emission scores of a round do not
+  // depend on the DP chain, so they are fetched as batches of independent loads one round ahead of the serial adds.
+  const uint32_t* __restrict__ xp = a.ref_packed + (active ? a.ref_woff[a.units[uid].pair % a.n_refs] : 0);
+  const int nxw = (xLen + 15) / 16 + 2;
+  auto xword = [&](int q) -> uint32_t { return xp[min(max(q, 0), nxw - 1)]; };
+  auto loadCtx = [&](int j0, U32x4& lo, U32x4& hi) {
+    const int base = min(j0 - 1, yLen);  // ctx is padded: indices up to yLen + kCtxPad are readable
+    lo = *(const U32x4*)(ctx + base);
+    hi = *(const U32x4*)(ctx + base + 4);
+  };
+  U32x4 cA, cB, nA, nB;
+  loadCtx(1, nA, nB);
+  int r0n = d;  // 0-based reference index of row i-1 at column j0 = 1
+  uint32_t nx0 = xword(r0n >> 4), nx1 = xword((r0n >> 4) + 1);
+  for (int j0 = 1; j0 <= T; j0 += 8) {
+    cA = nA; cB = nB;
+    const unsigned long long xpair = (((unsigned long long)nx1 << 32) | nx0) >> (2 * (r0n & 15));
+    loadCtx(j0 + 8, nA, nB);
+    r0n = d + j0 + 8 - 1;
+    nx0 = xword(r0n >> 4); nx1 = xword((r0n >> 4) + 1);
+    uint32_t w[8];
+    double e[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      w[c] = c < 4 ? cA.v[c] : cB.v[c - 4];
+      e[c] = ematch[(w[c] & 0x7FFFu) * 4u + ((uint32_t)(xpair >> (2 * c)) & 3u)];
+    }
+    uint32_t word = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int j = j0 + c, i = d + j;
+      const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
+      const uint32_t gk = w[c] >> 24;
+      const double tM = (M + trans[j <= 1 ? 0u : gkPrev]) + e[c];
+      gkPrev = gk;
+      double nm = tM;
+      uint32_t sm = 0;
+      if (j == 1 && (i == 1 || local) && e[c] > nm) { nm = e[c]; sm = 3; }
+      if (!valid) nm = QF_NEG_INF;
+      M = nm;
+      word |= sm << (4 * c);
+      if (j == yLen && valid && (local || i == xLen)) { bestEnd = nm + trans[3 * Kg + gk]; bestI = (uint32_t)i; }
+    }
+    if (active && j0 <= yLen) tb[(j0 - 1) >> 3] = word;
   }
   if (active) {
     a.units[uid].end_val = bestEnd;
@@ -1262,6 +1310,8 @@ __global__ void k_traceback(FinalArgs a) {
   const uint32_t xR = rec.ref;
   const int xLenR = (int)(a.ref_off[xR + 1] - a.ref_off[xR]);
   const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, (int)yLen) : RowGeom{0, 0, 0};
+  int cl = -1, ct = -1;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
   auto nibble = [&](int i, int j) -> uint32_t {
     if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0xFu;
     if (u.cls == (uint32_t)kRowClass) {
@@ -1273,9 +1323,21 @@ __global__ void k_traceback(FinalArgs a) {
       return (words[so[s] + (unsigned long long)(j - jlo + li) * 64 + li] >> (4 * b)) & 0xFu;
     }
     const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
-    const uint64_t t = (uint64_t)(j - 1 + l);
-    const uint64_t w = fc.B > 8 ? (t * fc.G + l) * 2 + (b >> 3) : t * fc.G + l;
-    return (tb[w] >> (4 * (b & 7))) & 0xFu;
+    const int t = j - 1 + l;
+    if (fc.B > 8) return (tb[((uint64_t)t * fc.G + l) * 2 + (b >> 3)] >> (4 * (b & 7))) & 0xFu;
+    // A path mostly stays inside one lane's diagonals, where consecutive moves read the words of steps t, t-1, ...
+    // of the same lane: keep eight of them (fetched as independent loads) instead of one dependent load per move.
+    if (l != cl || t > ct || t < ct - 7) {
+      cl = l; ct = t;
+      c0 = tb[(uint64_t)t * fc.G + l];
+      c1 = tb[(uint64_t)max(t - 1, 0) * fc.G + l]; c2 = tb[(uint64_t)max(t - 2, 0) * fc.G + l];
+      c3 = tb[(uint64_t)max(t - 3, 0) * fc.G + l]; c4 = tb[(uint64_t)max(t - 4, 0) * fc.G + l];
+      c5 = tb[(uint64_t)max(t - 5, 0) * fc.G + l]; c6 = tb[(uint64_t)max(t - 6, 0) * fc.G + l];
+      c7 = tb[(uint64_t)max(t - 7, 0) * fc.G + l];
+    }
+    const int k = ct - t;
+    const uint32_t wv = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : k == 3 ? c3 : k == 4 ? c4 : k == 5 ? c5 : k == 6 ? c6 : c7;
+    return (wv >> (4 * (b & 7))) & 0xFu;
   };
   uint32_t* tmp = a.runs_tmp + rec.tmp_off;
   int i = (int)u.end_i, j = (int)yLen;
