@@ -1299,8 +1299,12 @@ __global__ void k_select(FinalArgs a) {
 
 // QuaffViterbiMatrix::alignment, src/qmodel.cpp:1576-1622, replayed from the packed traceback bits.
 // One thread per alignment; CIGAR runs are produced end-to-start, then written start-to-end.
+// Few alignments per wavefront (kTbLanes of the 64 lanes): every memory stall of one path stalls its whole wavefront,
+// so narrow wavefronts, many of them, hide the dependent traceback loads far better than full ones.
+constexpr uint32_t kTbLanes = 64;
 __global__ void k_traceback(FinalArgs a) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x >= kTbLanes) return;
+  const uint32_t idx = blockIdx.x * kTbLanes + threadIdx.x;
   if (idx >= a.n_recs) return;
   AlignRec rec = a.recs[idx];
   const Unit u = a.units[rec.unit];
@@ -1327,14 +1331,7 @@ __global__ void k_traceback(FinalArgs a) {
     if (fc.B > 8) return (tb[((uint64_t)t * fc.G + l) * 2 + (b >> 3)] >> (4 * (b & 7))) & 0xFu;
     // A path mostly stays inside one lane's diagonals, where consecutive moves read the words of steps t, t-1, ...
     // of the same lane: keep eight of them (fetched as independent loads) instead of one dependent load per move.
-    if (l != cl || t > ct || t < ct - 7) {
-      cl = l; ct = t;
-      c0 = tb[(uint64_t)t * fc.G + l];
-      c1 = tb[(uint64_t)max(t - 1, 0) * fc.G + l]; c2 = tb[(uint64_t)max(t - 2, 0) * fc.G + l];
-      c3 = tb[(uint64_t)max(t - 3, 0) * fc.G + l]; c4 = tb[(uint64_t)max(t - 4, 0) * fc.G + l];
-      c5 = tb[(uint64_t)max(t - 5, 0) * fc.G + l]; c6 = tb[(uint64_t)max(t - 6, 0) * fc.G + l];
-      c7 = tb[(uint64_t)max(t - 7, 0) * fc.G + l];
-    }
+    if (l != cl || t > ct || t < ct - 7) return (tb[(uint64_t)t * fc.G + l] >> (4 * (b & 7))) & 0xFu;  // left the cached run
     const int k = ct - t;
     const uint32_t wv = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : k == 3 ? c3 : k == 4 ? c4 : k == 5 ? c5 : k == 6 ? c6 : c7;
     return (wv >> (4 * (b & 7))) & 0xFu;
@@ -1344,7 +1341,20 @@ __global__ void k_traceback(FinalArgs a) {
   const uint32_t xEnd = u.end_i;
   uint32_t n = 0, ncol = 0, curOp = 3, curLen = 0;
   int state = 1;  // 0 Start, 1 Match, 2 Insert, 3 Delete
+  const bool cached = u.cls != 0 && u.cls != (uint32_t)kRowClass && fc.B <= 8;
+  uint32_t it = 0;
   while (state != 0 && i >= 0 && j >= 0 && (i > 0 || j > 0)) {
+    if (cached && (it++ & 7) == 0 && i >= 1 && j >= 1) {
+      // every 8 moves ALL lanes of the wavefront refill together (one round trip for eight independent loads per lane)
+      // instead of each lane stalling the wavefront whenever its own run is exhausted
+      const int dd = (i - j) - u.dlo, l = dd / fc.B, t = j - 1 + l;
+      cl = l; ct = t;
+      c0 = tb[(uint64_t)t * fc.G + l];
+      c1 = tb[(uint64_t)max(t - 1, 0) * fc.G + l]; c2 = tb[(uint64_t)max(t - 2, 0) * fc.G + l];
+      c3 = tb[(uint64_t)max(t - 3, 0) * fc.G + l]; c4 = tb[(uint64_t)max(t - 4, 0) * fc.G + l];
+      c5 = tb[(uint64_t)max(t - 5, 0) * fc.G + l]; c6 = tb[(uint64_t)max(t - 6, 0) * fc.G + l];
+      c7 = tb[(uint64_t)max(t - 7, 0) * fc.G + l];
+    }
     const uint32_t nib = (i >= 1 && j >= 1) ? nibble(i, j) : 0u;
     uint32_t op;
     if (state == 1) {
@@ -1477,7 +1487,7 @@ void launch_select(const FinalArgs& a, hipStream_t s) {
   if (a.n_reads) hipLaunchKernelGGL(k_select, dim3((a.n_reads + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_traceback(const FinalArgs& a, hipStream_t s) {
-  if (a.n_recs) hipLaunchKernelGGL(k_traceback, dim3((a.n_recs + 63) / 64), dim3(64), 0, s, a);
+  if (a.n_recs) hipLaunchKernelGGL(k_traceback, dim3((a.n_recs + kTbLanes - 1) / kTbLanes), dim3(64), 0, s, a);
 }
 
 }  // namespace qf
