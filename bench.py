@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--band", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="align", choices=["align", "train", "overlap", "fulldp"],
+                    help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = scaled "
+                         "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
     ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (rehearse the N>1 path on a one-GPU box)")
@@ -82,6 +85,132 @@ def cpu_baseline(ref, seq, qual, off, n_sample, threads, band, gpu_res):
             "seconds": round(dt, 3), "gpu_parity_mismatches": mismatches}
 
 
+def order2_params_json():
+    """-order 2 shaped parameters (matchOrder 3, gapOrder 2) made by repeating the built-in order-0/1 values for every
+    context, as `quaff train -order 2` would start from a context-free prior."""
+    import re
+    base = open(os.path.join(ROOT, "tests", "golden", "defaultparams.json")).read()
+    bi = re.search(r'"beginInsert": \{ "": ([0-9.e-]+)', base).group(1)
+    bd = re.search(r'"beginDelete": \{ "": ([0-9.e-]+)', base).group(1)
+    block = base[base.index('"match": {') + len('"match": {'):]
+    block = block[block.index('{', 1) + 1:block.rindex('} } }')]           # the four reference-base rows of the "" context
+    ctxs = [a + b2 for a in "ACGT" for b2 in "ACGT"]
+    gaps = ",".join(' "%s": %s' % (c, bi) for c in ctxs), ",".join(' "%s": %s' % (c, bd) for c in ctxs)
+    head = base[:base.index('"beginInsert"')]
+    mid = base[base.index('"extendInsert"'):base.index('"match": {')]
+    match = ",\n".join('   "%s": {%s }' % (c, block.rstrip().rstrip("}").rstrip() + " }") for c in ctxs)
+    return ('{\n  "matchOrder": 3,\n  "gapOrder": 2,\n' + head[head.index('"refBase"') - 2:] + '"beginInsert": {%s },\n  "beginDelete": {%s },\n  '
+            % gaps + mid + '"match": {\n' + match + " } }\n")
+
+
+def extra_workload(a, rank, world, local_rank):
+    """Supplementary workloads (scaled configs 3, 4, 5).  One JSON line, same keys as the headline line."""
+    import numpy as np
+    import quaff_amd as Q
+    from quaff_amd import api, dist
+    ctx = Q.Context(local_rank)
+    null_json = open(os.path.join(ROOT, "tests", "golden", "testquaffnullparams.json")).read()
+    ctx.set_null_json(null_json)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+
+    if a.workload == "train":
+        ctx.set_params_json(order2_params_json())
+        ref = api.synth_ref(1, a.ref_len)
+        ctx.set_refs([ref, api.revcomp(ref)])
+        n = a.reads if a.reads != 100000 else 20000
+        seq, qual, off = api.synth_reads(2 + rank, ref, n, a.read_len)
+        ctx.upload_reads_packed(seq, qual, off)
+        cfg = Q.DPConfig(band_size=a.band)
+        order = None
+        for _ in range(a.warmup):
+            order = ctx.count_resident(cfg)["sort_order"]      # later EM iterations run on the pruned reference order
+        sync_all()
+        t0 = time.perf_counter()
+        cells = 0
+        ph = {}
+        for _ in range(a.steps):
+            res = ctx.count_resident(cfg, sort_order=order)
+            if world > 1:
+                dist.estep_allreduce(res["counts"], res["loglike"])   # the E-step's only exchange (RCCL all-reduce)
+            cells += res["total_cells"] + res["backward_cells"]
+            for k, v in res["ms"].items():
+                ph[k] = ph.get(k, 0.0) + v
+        sync_all()
+        dt = time.perf_counter() - t0
+        desc = "config 4 shape: quaff train E-step, -order 2, %d bp ref (+revcomp) x %d x %d bp reads per GPU, band %d" % (a.ref_len, n, a.read_len, a.band)
+        metric = "DP cells/sec (Forward + Backward E-step)"
+        extra = {"forward_bytes": res["forward_bytes"], "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
+    elif a.workload == "overlap":
+        ctx.set_params_json(None)
+        n = a.reads if a.reads != 100000 else 1500
+        genome = api.synth_ref(3, max(a.ref_len, 20 * n))
+        seq, qual, off = api.synth_reads(4 + rank, genome, n, 2000)
+        # SeqList::loadSequences: originals followed by their reverse complements
+        seqs = [seq[int(off[k]):int(off[k + 1])] for k in range(n)]
+        quals = [qual[int(off[k]):int(off[k + 1])] for k in range(n)]
+        seqs += [api.revcomp(s) for s in seqs]
+        quals += [q[::-1] for q in quals]
+        ctx.upload_reads(seqs, quals)
+        xs, ys = np.triu_indices(2 * n, 1)       # QuaffOverlapScheduler order: nx < ny, nx an original
+        keep = xs < n - 1
+        pairs = (xs[keep].astype(np.uint32), ys[keep].astype(np.uint32), (ys[keep] >= n).astype(np.uint8))
+        cfg = Q.DPConfig(kmer_threshold=14, band_size=a.band)
+        for _ in range(a.warmup):
+            ctx.overlap_resident(pairs, cfg, raw=True)
+        sync_all()
+        t0 = time.perf_counter()
+        cells = 0
+        ph = {}
+        for _ in range(a.steps):
+            res = ctx.overlap_resident(pairs, cfg, raw=True)
+            cells += int(res.total_cells)
+            for k in ("prep", "seed", "fill", "traceback", "total"):
+                ph[k] = ph.get(k, 0.0) + getattr(res, "ms_" + k)
+        sync_all()
+        dt = time.perf_counter() - t0
+        desc = "config 3 shape: quaff overlap, %d x 2 kb reads from a %d bp genome, all-vs-all both strands (%d pairs) per GPU" % (n, len(genome), len(pairs[0]))
+        metric = "DP cells/sec (overlap Viterbi)"
+        extra = {"pairs": len(pairs[0]), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
+    else:
+        ctx.set_params_json(None)
+        ref_len = a.ref_len if a.ref_len != 10000 else 100000
+        ref = api.synth_ref(1, ref_len)
+        ctx.set_refs([ref, api.revcomp(ref)])
+        n = a.reads if a.reads != 100000 else 256
+        seq, qual, off = api.synth_reads(2 + rank, ref, n, 5000)
+        ctx.upload_reads_packed(seq, qual, off)
+        cfg = Q.DPConfig(sparse=False)
+        for _ in range(a.warmup):
+            ctx.align_resident(cfg, 0, raw=True)
+        sync_all()
+        t0 = time.perf_counter()
+        cells = 0
+        ph = {}
+        for _ in range(a.steps):
+            res = ctx.align_resident(cfg, 0, raw=True)
+            cells += int(res.total_cells)
+            for k in ("prep", "seed", "fill", "traceback", "total"):
+                ph[k] = ph.get(k, 0.0) + getattr(res, "ms_" + k)
+        sync_all()
+        dt = time.perf_counter() - t0
+        desc = "config 5 shape: -kmatchoff full DP, %d bp ref (+revcomp) x %d x 5 kb reads per GPU" % (ref_len, n)
+        metric = "DP cells/sec (unbanded Viterbi)"
+        extra = {"traceback_bytes": int(res.traceback_bytes), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
+    if world > 1:
+        dt = dist.allreduce_max(dt)
+        cells = int(dist.allreduce_sum(np.array([float(cells)]))[0])
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": cells / dt, "unit": "DP cells/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": dict({"workload": desc}, **extra)}))
+    ctx.close()
+    dist.finalize()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -97,6 +226,8 @@ def main():
         # nccl == RCCL on ROCm, one process per GPU (RCCL refuses two ranks on one GPU, so the rehearsal uses gloo)
         dist.init("gloo" if a.single_device else "nccl")
 
+    if a.workload != "align":
+        return extra_workload(a, rank, world, local_rank)
     ctx = Q.Context(local_rank)
     ctx.set_params_json(None)
     ctx.set_null_json(open(os.path.join(ROOT, "tests", "golden", "testquaffnullparams.json")).read())

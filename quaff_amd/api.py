@@ -306,16 +306,23 @@ class Context:
                 "backward_cells": int(res.backward_cells), "forward_bytes": int(res.forward_bytes),
                 "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "forward", "plan", "backward", "total")}}
 
-    def overlap_resident(self, pairs, cfg=None):
-        """pairs: list of (x index, y index, y_complemented) over the resident sequences.  quaff overlap's defaults are
-        kmer_threshold=14 (DEFAULT_KMER_THRESHOLD, src/diagenv.h:15)."""
+    def overlap_resident(self, pairs, cfg=None, raw=False):
+        """pairs: list of (x index, y index, y_complemented) over the resident sequences, or a tuple of three numpy arrays
+        (uint32 x, uint32 y, uint8 flag).  quaff overlap's defaults are kmer_threshold=14 (DEFAULT_KMER_THRESHOLD,
+        src/diagenv.h:15).  raw=True returns the ctypes result struct without unpacking the alignments."""
         cfg = cfg or DPConfig(kmer_threshold=14)
-        px = np.array([q[0] for q in pairs], np.uint32)
-        py = np.array([q[1] for q in pairs], np.uint32)
-        pc = np.array([1 if q[2] else 0 for q in pairs], np.uint8)
+        if isinstance(pairs, tuple):
+            px, py, pc = (np.ascontiguousarray(pairs[0], np.uint32), np.ascontiguousarray(pairs[1], np.uint32),
+                          np.ascontiguousarray(pairs[2], np.uint8))
+        else:
+            px = np.array([q[0] for q in pairs], np.uint32)
+            py = np.array([q[1] for q in pairs], np.uint32)
+            pc = np.array([1 if q[2] else 0 for q in pairs], np.uint8)
         res = _OverlapResult()
-        self._chk(self.L.qf_overlap_resident(self.h, C.byref(cfg), px.ctypes.data, py.ctypes.data, pc.ctypes.data, len(pairs),
+        self._chk(self.L.qf_overlap_resident(self.h, C.byref(cfg), px.ctypes.data, py.ctypes.data, pc.ctypes.data, len(px),
                                              C.byref(res)))
+        if raw:
+            return res
         n = res.n_pairs
         arr = lambda ptr, dt=None: np.ctypeslib.as_array(ptr, (n,)).copy() if n else np.zeros(0)
         out = {"viterbi": arr(res.viterbi), "score": arr(res.score), "cells": arr(res.cells), "n_diagonals": arr(res.n_diagonals),

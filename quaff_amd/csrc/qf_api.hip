@@ -1072,7 +1072,7 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
   oa.recs = c->d_recs.as<AlignRec>();
   oa.bc = c->d_bc.as<BatchCounters>();
-  for (int cls = 10; cls >= 1; --cls) {
+  for (int cls = 10; cls >= 0; --cls) {
     oa.n_cls_units = bc.cls_count[cls];
     oa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
     launch_overlap_fill(cls, oa, c->stream);

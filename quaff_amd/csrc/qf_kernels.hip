@@ -576,10 +576,11 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
       } else {
         act = true;
-        if (a.storage_mode >= 1) cls = fb_class(cls);
+        if (a.storage_mode == 1) cls = fb_class(cls);
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
-        tbw = a.storage_mode == 2 ? (unsigned long long)(yLen + fill_class(cls).G - 1) * fill_class(cls).G * 2
+        tbw = a.storage_mode == 2 ? (cls == 0 ? (unsigned long long)(yLen + 7) / 8
+                                               : (unsigned long long)(yLen + fill_class(cls).G - 1) * fill_class(cls).G * 2)
               : a.storage_mode == 1 ? unit_fw_doubles(cls, (uint32_t)yLen)
               : cls == kRowClass  ? row_unit_words(dlo, dhi, xLen, yLen)
                                   : unit_tb_words(cls, (uint32_t)yLen);

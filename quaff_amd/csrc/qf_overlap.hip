@@ -233,6 +233,74 @@ __global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
   }
 }
 
+// Single-diagonal bands (most read pairs do not overlap: only diagonal 0 is in the envelope): with no neighbouring
+// diagonal the gap states stay -inf and the match state is a serial chain.  One lane per band, eight columns per round
+// with the context words and emissions fetched ahead of the chain; 2 traceback bits used per cell (one nibble).
+__global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
+  struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
+  const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0, comp = 0;
+  int d = 0, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, tb_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t x = a.pair_x[u.pair], y = a.pair_y[u.pair];
+    comp = a.pair_comp[u.pair];
+    xb = a.seq_off[x]; xLen = (int)(a.seq_off[x + 1] - xb);
+    yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
+    d = u.dlo; tb_off = u.tb_off;
+  }
+  int T = active ? yLen : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+  const double* __restrict__ mmi = a.mmi[comp];
+  const double* __restrict__ gap = a.gap[comp];
+  const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
+  const uint32_t* __restrict__ xc = a.ctx + xb;
+  const uint32_t* __restrict__ yc = (comp ? a.ctxc : a.ctx) + yb;
+  uint32_t* __restrict__ tb = a.tb + tb_off;
+  double M = QF_NEG_INF, colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
+  uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0;
+  for (int j0 = 1; j0 <= T; j0 += 8) {
+    const int yi = min(j0 - 1, yLen);                       // both context arrays are padded by kCtxPad words
+    const int xi = min(max(d + j0 - 1, -kCtxPad + 8), xLen);
+    const W4 ya = *(const W4*)(yc + yi), yb4 = *(const W4*)(yc + yi + 4);
+    const W4 xa = *(const W4*)(xc + xi), xb4 = *(const W4*)(xc + xi + 4);
+    uint32_t wy[8], wx[8];
+    double e[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      wy[c] = c < 4 ? ya.v[c] : yb4.v[c - 4];
+      wx[c] = c < 4 ? xa.v[c] : xb4.v[c - 4];
+      e[c] = mmi[(size_t)(wx[c] & 0x7FFFu) * KQ + (wy[c] & 0x7FFFu)];
+    }
+    uint32_t word = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int j = j0 + c, i = d + j;
+      const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
+      const uint32_t gxP = i > 1 ? gxPrev : 0u, gyP = j > 1 ? gyPrev : 0u;  // xIndelKmer[i-1], yIndelKmer[j-1] (padded 0)
+      gxPrev = wx[c] >> 24; gyPrev = wy[c] >> 24;
+      const double tM = (M + gap[gxP * Kg + gyP]) + e[c];
+      double nm = tM;
+      uint32_t sm = 0;
+      if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; sm = 3; }
+      if (!valid) nm = QF_NEG_INF;
+      M = nm;
+      word |= sm << (4 * c);
+      if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
+      if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+    }
+    if (active && j0 <= yLen) tb[(j0 - 1) >> 3] = word;
+  }
+  if (active) {
+    Unit* u = &a.units[uid];
+    u->end_val = colBest; u->end_i = colI;
+    u->end2_val = rowBest; u->end2_j = rowJ;
+  }
+}
+
 // End cell (src/qoverlap.cpp:164-182): start from mat(xLen,yLen), scan the last read column downwards, then the last
 // reference row, replacing only on strict '>'.  result = end + xInsertScore + yInsertScore (:157); adjusted score
 // subtracts both reads' null log-likelihoods (:292-302).
@@ -286,6 +354,7 @@ __global__ void k_overlap_traceback(OvArgs a) {
   const FillClass fc = fill_class((int)u.cls);
   const uint32_t* __restrict__ tb = a.tb + u.tb_off;
   auto cellbyte = [&](int i, int j) -> uint32_t {
+    if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0x3u;  // single diagonal: match flags only
     const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
     const uint64_t w = ((uint64_t)(j - 1 + l) * fc.G + l) * 2 + (b >> 2);
     return (tb[w] >> (8 * (b & 3))) & 0xFFu;
@@ -331,6 +400,7 @@ static void launch_ov_gb(const OvArgs& a, hipStream_t s) {
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
   switch (cls) {
+    case 0: hipLaunchKernelGGL(k_overlap_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a); break;
     case 1: launch_ov_gb<16, 2>(a, s); break;
     case 2: launch_ov_gb<16, 3>(a, s); break;
     case 3: launch_ov_gb<16, 4>(a, s); break;
