@@ -427,6 +427,14 @@ def viterbi(xtok, rc, sc, diags, local=True, want_tb=True, dump=False):
     return out
 
 
+def rescore_path(xtok, rc, sc, x_start, ops, local=True):
+    """Log-probability of one alignment path in the Viterbi recurrence's own association (qo_rescore_path)."""
+    lib().qo_rescore_path.restype = C.c_double
+    return lib().qo_rescore_path(len(xtok), len(rc.tok), sc.Km, sc.Kg, int(local), _vp(xtok), _vp(rc.tok), _vp(rc.qual),
+                                 _vp(rc.mk), _vp(rc.gk), _vp(sc.ins), _vp(sc.mat), _vp(sc.trans), int(x_start),
+                                 ops.encode(), len(ops))
+
+
 def counts_size(Km, Kg):
     return (4 + 4 * Km) * NQUAL + 4 * Kg + 4
 

@@ -776,3 +776,45 @@ double qo_overlap_viterbi(int xLen, int yLen, int Km, int Kg,
     mx_free(&m);
     return end;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Path re-scoring: the log-probability of ONE given alignment path, accumulated in the same association as the Viterbi
+ * recurrence (src/qmodel.cpp:1532-1552): O(path) instead of O(cells), so it checks alignments of full-size runs.  For the
+ * Viterbi path it reproduces QuaffViterbiMatrix::result bit-for-bit; for any other path it is <= result. */
+double qo_rescore_path(int xLen, int yLen, int Km, int Kg, int local,
+                       const uint8_t *xtok, const uint8_t *ytok, const uint8_t *yqual,
+                       const uint32_t *ymk, const uint32_t *ygk,
+                       const double *ins, const double *mat, const double *trans,
+                       int xStart, const char *ops, int n_ops)
+{
+    qo_pair p = { xLen, yLen, Km, Kg, local, xtok, ytok, yqual, ymk, ygk, ins, mat, trans };
+    int i = xStart - 1, j = 0;            /* cell before the first column */
+    double sc = 0;                        /* start */
+    char prev = 'S';
+    if (!local && xStart != 1) return NEG_INF;
+    for (int a = 0; a < n_ops; ++a) {
+        const char op = ops[a];
+        if (op == 'M') {
+            ++i; ++j;
+            if (i > xLen || j > yLen) return NEG_INF;
+            double t;
+            if (prev == 'S') { if (j != 1) return NEG_INF; t = 0; }
+            else if (prev == 'M') t = sc + p_m2m(&p, j - 1);
+            else if (prev == 'I') t = sc + p_i2m(&p);
+            else t = sc + p_d2m(&p);
+            sc = t + p_memit(&p, i, j);
+        } else if (op == 'I') {
+            ++j;
+            if (j > yLen || prev == 'S' || prev == 'D') return NEG_INF;
+            sc = p_iemit(&p, j) + (prev == 'I' ? sc + p_i2i(&p) : sc + p_m2i(&p, j - 1));
+        } else {
+            ++i;
+            if (i > xLen || prev == 'S' || prev == 'I') return NEG_INF;
+            sc = prev == 'D' ? sc + p_d2d(&p) : sc + p_m2d(&p, j);
+        }
+        prev = op;
+    }
+    if (j != yLen || prev != 'M') return NEG_INF;
+    if (!local && i != xLen) return NEG_INF;
+    return sc + p_m2e(&p, yLen);
+}
