@@ -74,7 +74,10 @@ struct qf_ctx {
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
       d_recs, d_runs_tmp, d_runs_out, d_cover, d_lse, d_fw, d_weight, d_fwd_out, d_counts, d_order_in, d_order_n_in,
       d_order_out, d_order_n_out, d_rll, d_skip, d_ctxc, d_ins_sum, d_ins_sum_c, d_nll_c, d_rbucket, d_rcursor, d_rpos,
-      d_px, d_py, d_pc, d_mmi0, d_mmi1, d_gap0, d_gap1, d_pair_result, d_pair_ij;
+      d_px, d_py, d_pc, d_mmi0, d_mmi1, d_gap0, d_gap1, d_pair_result, d_pair_ij, d_skmer64, d_skeys, d_keys_tmp, d_vals_tmp,
+      d_off32, d_rskeys, d_roff32;
+  void* sort_temp = nullptr;
+  size_t sort_temp_cap = 0;
   // host results
   std::vector<double> h_viterbi, h_nll;
   std::vector<uint64_t> h_cells;
@@ -150,8 +153,10 @@ void qf_ctx_destroy(qf_ctx* c) {
                     &c->d_weight, &c->d_fwd_out, &c->d_counts, &c->d_order_in, &c->d_order_n_in, &c->d_order_out,
                     &c->d_order_n_out, &c->d_rll, &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
-                    &c->d_gap0, &c->d_gap1, &c->d_pair_result, &c->d_pair_ij})
+                    &c->d_gap0, &c->d_gap1, &c->d_pair_result, &c->d_pair_ij, &c->d_skmer64, &c->d_skeys, &c->d_keys_tmp,
+                    &c->d_vals_tmp, &c->d_off32, &c->d_rskeys, &c->d_roff32})
     b->release();
+  if (c->sort_temp) (void)hipFree(c->sort_temp);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->cls_ev) if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -351,10 +356,38 @@ int qf_set_refs(qf_ctx* c, const char* seq, const uint64_t* offsets, uint32_t n_
   return QF_OK;
 }
 
+// sorted (k-mer, position) index of a sequence set, for k > kMaxRefK
+static int build_sorted_index(qf_ctx* c, const uint8_t* d_tok, const uint64_t* d_off, const std::vector<uint64_t>& off,
+                              uint64_t max_len, int k, DevBuf& d_off32, DevBuf& d_keys_out, DevBuf& d_pos_out) {
+  const uint32_t n = (uint32_t)off.size() - 1;
+  const uint64_t total = off[n];
+  if (total > 0x7FFFFFF0ull) return fail(c, QF_ERR_UNSUPPORTED, "sorted k-mer index: more than 2^31 bases in one sequence set");
+  std::vector<int> off32(off.begin(), off.end());
+  HIPCHK(c, d_off32.reserve((size_t)(n + 1) * 4));
+  HIPCHK(c, hipMemcpyAsync(d_off32.p, off32.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, c->d_keys_tmp.reserve((total + 16) * 8));
+  HIPCHK(c, c->d_vals_tmp.reserve((total + 16) * 4));
+  HIPCHK(c, d_keys_out.reserve((total + 16) * 8));
+  HIPCHK(c, d_pos_out.reserve((total + 16) * 4));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // off32 is a stack-lifetime host buffer
+  const int rc = sort_kmer_index(d_tok, d_off, d_off32.as<int>(), n, total, max_len, (uint32_t)k, c->d_keys_tmp.as<unsigned long long>(),
+                                 c->d_vals_tmp.as<uint32_t>(), d_keys_out.as<unsigned long long>(), d_pos_out.as<uint32_t>(),
+                                 &c->sort_temp, &c->sort_temp_cap, c->stream);
+  if (rc != 0) return fail(c, QF_ERR_DEVICE, std::string("k-mer index sort: ") + hipGetErrorString((hipError_t)rc));
+  HIPCHK(c, hipGetLastError());
+  return QF_OK;
+}
+
 static int ensure_ref_index(qf_ctx* c, int k) {
   if (c->index_k == k) return QF_OK;
-  if (k < 1 || k > kMaxRefK)
-    return fail(c, QF_ERR_UNSUPPORTED, "-kmatch " + std::to_string(k) + ": device k-mer index is built for k <= " + std::to_string(kMaxRefK));
+  if (k < 1 || k > 32) return fail(c, QF_ERR_ARG, "kmer_len out of range");
+  if (k > kMaxRefK) {
+    if (int rc = build_sorted_index(c, c->d_ref_tok.as<uint8_t>(), c->d_ref_off.as<uint64_t>(), c->ref_off, c->ref_maxlen, k,
+                                    c->d_off32, c->d_skeys, c->d_pos))
+      return rc;
+    c->index_k = k;
+    return QF_OK;
+  }
   const uint32_t nb = 1u << (2 * k);
   const size_t bytes = (size_t)c->n_refs * (nb + 1) * 4;
   HIPCHK(c, c->d_bucket.reserve(bytes));
@@ -414,6 +447,11 @@ static int prep_reads(qf_ctx* c, int seed_k) {
   a.tok = c->d_tok.as<uint8_t>();
   a.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
   a.skmer = c->d_skmer.as<uint32_t>();
+  a.skmer64 = nullptr;
+  if (seed_k > kMaxRefK) {
+    HIPCHK(c, c->d_skmer64.reserve((c->read_total + 16) * 8));
+    a.skmer64 = c->d_skmer64.as<unsigned long long>();
+  }
   a.nll = c->d_nll.as<double>();
   a.has_null = c->have_null;
   if (c->have_null) {
@@ -443,9 +481,12 @@ static void fill_seed_args(qf_ctx* c, const qf_dp_config* cfg, SeedArgs& s, uint
   s.ref_off = c->d_ref_off.as<uint64_t>();
   s.read_off = c->d_roff.as<uint64_t>();
   s.skmer = c->d_skmer.as<uint32_t>();
+  const bool sorted = cfg->sparse && cfg->kmer_len > kMaxRefK;
+  s.skmer64 = sorted ? c->d_skmer64.as<unsigned long long>() : nullptr;
+  s.ref_skeys = sorted ? c->d_skeys.as<unsigned long long>() : nullptr;
   s.ref_bucket = c->d_bucket.as<uint32_t>();
   s.ref_pos = c->d_pos.as<uint32_t>();
-  s.nbuckets = cfg->sparse ? 1u << (2 * cfg->kmer_len) : 0;
+  s.nbuckets = (cfg->sparse && !sorted) ? 1u << (2 * cfg->kmer_len) : 0;
   s.sparse = cfg->sparse;
   s.kmer_len = cfg->kmer_len;
   s.threshold = cfg->kmer_threshold;
@@ -949,9 +990,8 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     c->ov_scores[v] = true;
   }
   // k-mer index over the resident sequences themselves (every sequence can be an x)
-  if (sparse && c->read_index_k != cfg->kmer_len) {
+  if (sparse && c->read_index_k != cfg->kmer_len && cfg->kmer_len <= kMaxRefK) {
     const int k = cfg->kmer_len;
-    if (k > kMaxRefK) return fail(c, QF_ERR_UNSUPPORTED, "-kmatch " + std::to_string(k) + ": device k-mer index is built for k <= " + std::to_string(kMaxRefK));
     const uint32_t nb = 1u << (2 * k);
     const size_t bytes = (size_t)n_seqs * (nb + 1) * 4;
     HIPCHK(c, c->d_rbucket.reserve(bytes));
@@ -964,6 +1004,12 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   const uint32_t max_units = n_pairs * 4 + 1024;
   if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
   if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  if (sparse && c->read_index_k != cfg->kmer_len && cfg->kmer_len > kMaxRefK) {
+    if (int rc = build_sorted_index(c, c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), c->read_off, c->read_maxlen, cfg->kmer_len,
+                                    c->d_roff32, c->d_rskeys, c->d_rpos))
+      return rc;
+    c->read_index_k = cfg->kmer_len;
+  }
   if (sparse && c->read_index_k != cfg->kmer_len) {  // needs the token bytes prep_reads just wrote
     launch_ref_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len,
                      1u << (2 * cfg->kmer_len), c->d_rbucket.as<uint32_t>(), c->d_rcursor.as<uint32_t>(),
@@ -1016,6 +1062,7 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   sa.ref_off = c->d_roff.as<uint64_t>();
   sa.ref_bucket = c->d_rbucket.as<uint32_t>();
   sa.ref_pos = c->d_rpos.as<uint32_t>();
+  sa.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
   sa.storage_mode = 2;
   if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
     return fail(c, QF_ERR_UNSUPPORTED, "read + read length exceeds the LDS diagonal histogram");

@@ -145,9 +145,9 @@ __global__ __launch_bounds__(64) void k_prep_reads(PrepArgs a) {
     const uint32_t t = tokAt(i);
     a.ctx[b + i] = ctx_pack(mk * (kNQualDev + 1) + q, t * (kNQualDev + 1) + q, gk);
     if (a.seed_k && i + a.seed_k <= L) {
-      uint32_t sk = 0;
+      unsigned long long sk = 0;
       for (uint32_t c = 0; c < a.seed_k; ++c) sk = sk * 4 + tokAt(i + c);
-      a.skmer[b + i] = sk;
+      if (a.skmer64) a.skmer64[b + i] = sk; else a.skmer[b + i] = (uint32_t)sk;
     }
   }
 }
@@ -205,6 +205,27 @@ __device__ __forceinline__ unsigned long long band_cells(int dlo, int dhi, int x
 __device__ __forceinline__ void pair_rx(const SeedArgs& a, uint32_t pair, uint32_t& r, uint32_t& x) {
   if (a.pair_x) { x = a.pair_x[pair]; r = a.pair_y[pair]; }
   else { r = pair / a.n_refs; x = pair % a.n_refs; }
+}
+
+// Index lookup: positions of x-sequence `x` whose k-mer equals km are pos[s..e).  Direct-addressed buckets (k <= 8) or
+// binary search in the sorted k-mer array (k > 8).
+__device__ __forceinline__ void bucket_range(const SeedArgs& a, uint32_t x, uint64_t xb, int xLen, unsigned long long km,
+                                             uint32_t& s, uint32_t& e) {
+  if (!a.ref_skeys) {
+    const uint32_t* st = a.ref_bucket + (uint64_t)x * (a.nbuckets + 1);
+    s = st[km]; e = st[km + 1];
+    return;
+  }
+  const unsigned long long* __restrict__ keys = a.ref_skeys + xb;
+  const int n = xLen - a.kmer_len + 1;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < km) lo = mid + 1; else hi = mid;
+  }
+  int up = lo;
+  while (up < n && keys[up] == km) ++up;
+  s = (uint32_t)lo; e = (uint32_t)up;
 }
 
 // Seeding records each band of a pair in a fixed per-pair slot (an uncontended per-pair counter);
@@ -271,11 +292,11 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
   // histogram of matching k-mer pairs per diagonal (diagenv.cpp:33-40), reads' k-mers against the
   // reference's k-mer index
   if (xLen >= k && yLen >= k) {
-    const uint32_t* starts = a.ref_bucket + (uint64_t)x * (a.nbuckets + 1);
     const uint32_t* pos = a.ref_pos + xb;
     for (int j = tid; j <= yLen - k; j += 256) {
-      const uint32_t km = a.skmer[yb + j];
-      const uint32_t s = starts[km], e = starts[km + 1];
+      const unsigned long long km = a.skmer64 ? a.skmer64[yb + j] : (unsigned long long)a.skmer[yb + j];
+      uint32_t s, e;
+      bucket_range(a, x, xb, xLen, km, s, e);
       for (uint32_t p = s; p < e; ++p) {
         const int bin = (int)pos[p] - j + yLen - 1;
         atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
@@ -422,25 +443,27 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   if (lane == 0) misc[0] = 0;
   wave_lds_sync();
 
-  const uint32_t* __restrict__ starts = a.ref_bucket + (uint64_t)x * (a.nbuckets + 1);
   const uint32_t* __restrict__ pos = a.ref_pos + xb;
   const uint32_t* __restrict__ sk = a.skmer + yb;
+  const unsigned long long* __restrict__ sk64 = a.skmer64 ? a.skmer64 + yb : nullptr;
   const int nk = yLen - k + 1;  // read k-mers (>= 1 here)
   // visit(bin) for every (i, j) with equal k-mers, bin = i - j + yLen - 1 (diagenv.cpp:33-40).
   // R read positions per lane per round; the three dependent loads are issued as batches.
   auto walk = [&](auto&& visit) {
     constexpr int R = 4;
     for (int j0 = 0; j0 < nk; j0 += 64 * R) {
-      uint32_t km[R], s[R], e[R];
+      unsigned long long km[R];
+      uint32_t s[R], e[R];
 #pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
         const int j = j0 + c * 64 + (int)lane;
-        km[c] = j < nk ? sk[j] : 0xFFFFFFFFu;
+        km[c] = j < nk ? (sk64 ? sk64[j] : (unsigned long long)sk[j]) : 0ull;
       }
 #pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
-        s[c] = km[c] != 0xFFFFFFFFu ? starts[km[c]] : 0u;
-        e[c] = km[c] != 0xFFFFFFFFu ? starts[km[c] + 1] : 0u;
+        const int j = j0 + c * 64 + (int)lane;
+        s[c] = e[c] = 0;
+        if (j < nk) bucket_range(a, x, xb, xLen, km[c], s[c], e[c]);
       }
       uint32_t pa[R], pb[R], pc[R], pd[R];  // the first four entries of each bucket (the index has 4 words of slack)
 #pragma clang loop unroll(full)

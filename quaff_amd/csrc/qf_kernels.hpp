@@ -18,7 +18,8 @@ struct PrepArgs {
   uint32_t match_len, gap_len, seed_k;
   uint8_t* tok;            // [total]
   uint32_t* ctx;           // [total] (already offset past the front pad)
-  uint32_t* skmer;         // [total] seeding k-mer starting at each base
+  uint32_t* skmer;         // [total] seeding k-mer starting at each base (k <= 16)
+  unsigned long long* skmer64;  // same as 64-bit values, filled instead of skmer when the sorted index is used (k > 8)
   double* nll;             // [n_reads]
   int has_null;
   double null_logEmit, null_log1mEmit;
@@ -40,6 +41,8 @@ struct SeedArgs {
   const uint64_t* ref_off;
   const uint64_t* read_off;
   const uint32_t* skmer;
+  const unsigned long long* skmer64;   // non-NULL: sorted-index mode (k > 8)
+  const unsigned long long* ref_skeys; // sorted k-mers of every x-sequence, aligned with ref_off
   const uint32_t* ref_bucket;  // [n_refs][nbuckets+1] exclusive starts
   const uint32_t* ref_pos;     // [total ref bases] positions grouped by k-mer
   uint32_t nbuckets;
@@ -183,6 +186,9 @@ void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s);
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s);
 void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s);
 void launch_count_plan(const CountPlanArgs& a, hipStream_t s);
+int sort_kmer_index(const uint8_t* tok, const uint64_t* d_off, const int* d_off32, uint32_t n_seqs, uint64_t total,
+                    uint64_t max_len, uint32_t k, unsigned long long* keys_tmp, uint32_t* vals_tmp,
+                    unsigned long long* keys_out, uint32_t* pos_out, void** temp, size_t* temp_cap, hipStream_t s);
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s);
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s);

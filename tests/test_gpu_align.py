@@ -112,6 +112,27 @@ def test_envelopes_match_oracle(ctx):
                     assert np.array_equal(got, want), (kw, dbg, r, x, len(got), len(want))
 
 
+def test_long_kmers_sorted_index(ctx):
+    """-kmatch 9 .. 32 (reference range 5..32, src/qmodel.cpp:773-779): sorted k-mer index + binary search."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(12)
+    ref = rand_seq(rng, 2500)
+    sc, null = oracle_model()
+    reads = make_reads(rng, ref, 6, 400, sub=0.02, ins=0.01, dele=0.01)
+    refs = both_strands(ref)
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    for k, thr in ((9, 10), (12, 6), (16, 4), (17, 3), (32, 1)):
+        ocfg = O.DPConfig(kmer_len=k, kmer_threshold=thr)
+        for r, read in enumerate(reads):
+            for x, rf in enumerate(refs):
+                got = ctx.envelope(r, x, Q.DPConfig(kmer_len=k, kmer_threshold=thr))
+                want = O.envelope(O.tokens(rf.seq), O.tokens(read.seq), ocfg, 24)
+                assert np.array_equal(got, want), (k, thr, r, x, len(got), len(want))
+    check_against_oracle(ctx, refs, reads, dict(kmer_len=12, kmer_threshold=6), sc, null)
+    check_against_oracle(ctx, refs, reads, dict(kmer_len=20, kmer_threshold=-1, max_size=80 * 400 * 24), sc, null)
+
+
 def test_align_small_both_strands(ctx):
     rng = np.random.default_rng(21)
     ref = rand_seq(rng, 2000)

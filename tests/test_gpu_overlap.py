@@ -81,6 +81,11 @@ def test_overlap_bands_and_thresholds(ctx):
     check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=20, band_size=100), with_revcomps=False)
 
 
+def test_overlap_long_kmers(ctx):
+    rng = np.random.default_rng(44)
+    check_overlap(ctx, overlapping_reads(rng, 700, 5, 300), DEFAULT_JSON, dict(kmer_len=11, kmer_threshold=5))
+
+
 def test_overlap_order2(ctx):
     rng = np.random.default_rng(43)
     pj = synth_params_json(rng, 2, 1)
