@@ -117,6 +117,9 @@ int qf_ctx_create(int device_id, qf_ctx **ctx);
 void qf_ctx_destroy(qf_ctx *ctx);
 const char *qf_last_error(const qf_ctx *ctx);   /* ctx may be NULL: last creation error */
 int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
+/* Device bytes one internal chunk may use for traceback / Forward storage (default 160 GiB; 0 restores it).  Larger
+ * batches are processed in halves transparently. */
+int qf_set_memory_budget(qf_ctx *ctx, uint64_t bytes);
 
 /* ---- model ------------------------------------------------------------------------ */
 /* Parse a quaff params JSON document (numbers go through the same non-correctly-rounded

@@ -87,6 +87,7 @@ struct qf_ctx {
   std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
+  uint64_t tb_budget = 160ull << 30;   // per-chunk device storage budget (traceback / Forward matrices)
   bool ov_scores[2] = {false, false};
   int read_index_k = 0;
   std::vector<double> h_ov_result, h_ov_score;
@@ -527,32 +528,27 @@ static int reserve_pair_buffers(qf_ctx* c, uint64_t n_pairs, uint32_t max_units)
   return QF_OK;
 }
 
-int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_align_result* out) {
-  if (int rc = check_cfg(c, cfg)) return rc;
-  if (!out) return fail(c, QF_ERR_ARG, "null result");
-  HIPCHK(c, hipSetDevice(c->device));
-  memset(out, 0, sizeof *out);
-  const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
-  const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
-  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
-  const uint32_t n_pairs = (uint32_t)n_pairs64;
-  out->n_reads = n_reads;
-  out->n_refs = n_refs;
-  if (!n_pairs) return QF_OK;
+// Reads [lo, hi) of the resident set against every reference.  Results go to the context's host arrays at the chunk's
+// offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
+// *too_big is set (the caller splits the range).
+static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi, qf_align_result* out,
+                       bool* too_big) {
+  *too_big = false;
+  const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
+  const uint32_t n_pairs = n_reads * n_refs;
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
-  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
-
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const uint32_t max_units = n_pairs * 4 + 1024;
   if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
-  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  const uint64_t* d_roff = c->d_roff.as<uint64_t>() + lo;   // the chunk's reads: offsets stay absolute, indices local
+  const double* d_nll = c->d_nll.as<double>() + lo;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
   // ---- seeding
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
   fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  sa.read_off = d_roff;
   if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
     return fail(c, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
                                            " exceeds the LDS diagonal histogram (global-memory histogram not built yet)");
@@ -575,7 +571,11 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
 
   // ---- fill
   const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
-  if (tb_bytes > (200ull << 30)) return fail(c, QF_ERR_MEMORY, "traceback needs " + std::to_string(tb_bytes >> 30) + " GiB; split the batch");
+  if (tb_bytes > c->tb_budget) {
+    if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "one read needs " + std::to_string(tb_bytes >> 20) + " MiB of traceback, over the memory budget");
+    *too_big = true;
+    return QF_OK;
+  }
   HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
   FillArgs fa{};
   fa.n_refs = n_refs;
@@ -584,7 +584,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   fa.ref_woff = c->d_ref_woff.as<uint64_t>();
   fa.ref_tok = c->d_ref_tok.as<uint8_t>();
   fa.ref_packed = c->d_ref_packed.as<uint32_t>();
-  fa.read_off = c->d_roff.as<uint64_t>();
+  fa.read_off = d_roff;
   fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
   fa.tb = c->d_tb.as<uint32_t>();
   const Scores& sc = c->scores;
@@ -620,8 +620,8 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   fin.pair_head = c->d_pair_head.as<uint32_t>();
   fin.pair_score = c->d_pair_score.as<double>();
   fin.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
-  fin.nll = c->d_nll.as<double>();
-  fin.read_off = c->d_roff.as<uint64_t>();
+  fin.nll = d_nll;
+  fin.read_off = d_roff;
   fin.ref_off = c->d_ref_off.as<uint64_t>();
   fin.tb = c->d_tb.as<uint32_t>();
   fin.bc = c->d_bc.as<BatchCounters>();
@@ -648,22 +648,89 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
 
-  // ---- results to the host
+  // ---- results to the host, at the chunk's offsets
+  const size_t p0 = (size_t)lo * n_refs, recs0 = c->h_recs.size(), runs0 = c->h_runs.size();
+  c->h_recs.resize(recs0 + n_recs);
+  c->h_runs.resize(runs0 + total_runs);
+  HIPCHK(c, hipMemcpyAsync(c->h_viterbi.data() + p0, c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + p0, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data() + p0, c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data() + recs0, c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data() + runs0, c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t a = recs0; a < recs0 + n_recs; ++a) {
+    c->h_recs[a].read += lo;
+    c->h_recs[a].run_off += runs0;
+  }
+  out->total_cells += seed_bc.total_cells;
+  out->n_units += seed_bc.n_units;
+  out->traceback_bytes += tb_bytes;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); out->ms_seed += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); out->ms_fill += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_traceback += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    // class cls ran between cls_ev[cls+1] and the next lower class's start (cls_ev[cls]); cls 0 ends at cls_ev[0]
+    ms = 0;
+    if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&ms, c->cls_ev[cls + 1], c->cls_ev[cls]);
+    out->ms_fill_class[cls] += ms;
+    out->cells_class[cls] += seed_bc.cls_cells[cls];
+    out->units_class[cls] += seed_bc.cls_count[cls];
+  }
+  return QF_OK;
+}
+
+
+int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_align_result* out) {
+  if (int rc = check_cfg(c, cfg)) return rc;
+  if (!out) return fail(c, QF_ERR_ARG, "null result");
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
+  const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
+  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
+  const uint32_t n_pairs = (uint32_t)n_pairs64;
+  out->n_reads = n_reads;
+  out->n_refs = n_refs;
+  if (!n_pairs) return QF_OK;
+  const bool sparse = cfg->sparse != 0;
+  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
+  HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->h_viterbi.resize(n_pairs);
   c->h_cells.resize(n_pairs);
   c->h_ndiag.resize(n_pairs);
   c->h_nll.resize(n_reads);
-  c->h_recs.resize(n_recs);
-  c->h_runs.resize(total_runs);
-  HIPCHK(c, hipMemcpyAsync(c->h_viterbi.data(), c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_cells.data(), c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data(), c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  c->h_recs.clear();
+  c->h_runs.clear();
   HIPCHK(c, hipMemcpyAsync(c->h_nll.data(), c->d_nll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
-  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data(), c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
-  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data(), c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-
+  {
+    BatchCounters pb;
+    if (int rc = read_counters(c, pb)) return rc;
+    if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
+  }
+  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
+  out->ms_total = out->ms_prep;
+  // the whole batch at once when its traceback fits the memory budget, else halves (recursively)
+  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n_reads}};
+  while (!todo.empty()) {
+    const auto [lo, hi] = todo.back();
+    todo.pop_back();
+    bool too_big = false;
+    if (int rc = align_chunk(c, cfg, flags, lo, hi, out, &too_big)) return rc;
+    if (too_big) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      todo.push_back({mid, hi});
+      todo.push_back({lo, mid});
+    }
+  }
+  const uint32_t n_recs = (uint32_t)c->h_recs.size();
   // order: by read; within a read by descending score, earlier reference first on ties (multiset order,
   // src/qmodel.cpp:2773-2775)
   std::vector<uint32_t> order(n_recs);
@@ -693,25 +760,16 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   out->cells = c->h_cells.data();
   out->n_diagonals = c->h_ndiag.data();
   out->null_loglike = c->h_nll.data();
-  out->total_cells = bc.total_cells;
   out->n_alignments = n_recs;
   out->alignments = c->h_align.data();
   out->cigar_runs = c->h_runs.data();
-  out->n_units = bc.n_units;
-  out->traceback_bytes = tb_bytes;
-  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&out->ms_seed, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&out->ms_fill, c->ev[2], c->ev[3]);
-  (void)hipEventElapsedTime(&out->ms_traceback, c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
   out->n_fill_classes = kNumClasses;
-  for (int cls = 0; cls < kNumClasses; ++cls) {
-    // class cls ran between cls_ev[cls+1] and the next lower class's start (cls_ev[cls]); cls 0 ends at cls_ev[0]
-    out->ms_fill_class[cls] = 0;
-    if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&out->ms_fill_class[cls], c->cls_ev[cls + 1], c->cls_ev[cls]);
-    out->cells_class[cls] = seed_bc.cls_cells[cls];
-    out->units_class[cls] = seed_bc.cls_count[cls];
-  }
+  return QF_OK;
+}
+
+int qf_set_memory_budget(qf_ctx* c, uint64_t bytes) {
+  if (!c) return QF_ERR_ARG;
+  c->tb_budget = bytes ? bytes : (160ull << 30);
   return QF_OK;
 }
 
@@ -727,69 +785,28 @@ uint32_t qf_counts_size(const qf_ctx* c) {
   return (uint32_t)((4 + 4 * c->scores.Km) * kNQual + 4 * c->scores.Kg + 4);
 }
 
-int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const uint32_t* sort_in,
-                      const uint32_t* sort_n_in, qf_count_result* out) {
-  if (int rc = check_cfg(c, cfg)) return rc;
-  if (!out) return fail(c, QF_ERR_ARG, "null result");
-  if ((sort_in == nullptr) != (sort_n_in == nullptr)) return fail(c, QF_ERR_ARG, "sort_in and sort_n_in go together");
-  HIPCHK(c, hipSetDevice(c->device));
-  memset(out, 0, sizeof *out);
-  const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
-  const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
-  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
-  const uint32_t n_pairs = (uint32_t)n_pairs64;
-  out->n_reads = n_reads;
-  out->n_refs = n_refs;
-  const uint32_t csize = qf_counts_size(c);
-  out->counts_size = csize;
-  c->h_pcounts.assign(csize, 0.0);
-  out->counts = c->h_pcounts.data();
-  if (!n_pairs) return QF_OK;
-  if (!c->reads_have_qual)  // QuaffBackwardMatrix ctor, src/qmodel.cpp:1398
-    return fail(c, QF_ERR_ARG, "Forward-Backward algorithm requires quality scores to fit model");
-  const bool use_null = !(flags & QF_COUNT_FORCE);
-  if (use_null && !c->have_null) return fail(c, QF_ERR_STATE, "no null model set (qf_set_null_json) and QF_COUNT_FORCE not given");
+// Forward-Backward over reads [lo, hi) of the resident set; counts accumulate in d_counts, per-read / per-pair results go to
+// the host arrays at the chunk's offsets.  Sets *too_big (and does nothing) when the Forward matrices exceed the budget.
+static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
+                       qf_count_result* out, bool* too_big) {
+  *too_big = false;
+  const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
+  const uint32_t n_pairs = n_reads * n_refs;
+  const size_t p0 = (size_t)lo * n_refs;
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
-  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
-  if (!c->lse_uploaded) {
-    const std::vector<double>& t = lse_table();
-    HIPCHK(c, c->d_lse.reserve(t.size() * 8));
-    HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
-    c->lse_uploaded = true;
-  }
-
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const uint32_t max_units = n_pairs * 4 + 1024;
+  const uint32_t csize = qf_counts_size(c);
   if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
-  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
-  // pairs outside the read's reference order are not even seeded (their LL stays -inf, qmodel.cpp:2245)
-  HIPCHK(c, c->d_order_in.reserve((size_t)n_pairs * 4));
-  HIPCHK(c, c->d_order_n_in.reserve((size_t)n_reads * 4));
-  const uint8_t* d_skip = nullptr;
-  if (sort_in) {
-    std::vector<uint8_t> skip(n_pairs, 1);
-    for (uint32_t r = 0; r < n_reads; ++r) {
-      if (sort_n_in[r] > n_refs) return fail(c, QF_ERR_ARG, "sort_n_in out of range");
-      for (uint32_t k = 0; k < sort_n_in[r]; ++k) {
-        const uint32_t x = sort_in[(size_t)r * n_refs + k];
-        if (x >= n_refs) return fail(c, QF_ERR_ARG, "sort_in out of range");
-        skip[(size_t)r * n_refs + x] = 0;
-      }
-    }
-    HIPCHK(c, c->d_skip.reserve(n_pairs));
-    HIPCHK(c, hipMemcpyAsync(c->d_skip.p, skip.data(), n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_order_in.p, sort_in, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_order_n_in.p, sort_n_in, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // `skip` is a stack-lifetime host buffer
-    d_skip = c->d_skip.as<uint8_t>();
-  }
+  const uint64_t* d_roff = c->d_roff.as<uint64_t>() + lo;
+  const uint8_t* d_skip = have_sort ? c->d_skip.as<uint8_t>() + p0 : nullptr;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
   // ---- seeding (cellSize = 2 * 24 for counting, qmodel.cpp:2249; only matters in memory mode)
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
   fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  sa.read_off = d_roff;
   sa.cell_size = 48;
   sa.storage_mode = 1;
   sa.pair_skip = d_skip;
@@ -813,23 +830,24 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
 
   // ---- Forward
   const uint64_t fw_bytes = (uint64_t)bc.tb_words * 8;
-  if (fw_bytes > (220ull << 30))
-    return fail(c, QF_ERR_MEMORY, "Forward matrices need " + std::to_string(fw_bytes >> 30) + " GiB; upload fewer reads per batch");
+  if (fw_bytes > c->tb_budget) {
+    if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "one read needs " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices, over the memory budget");
+    *too_big = true;
+    return QF_OK;
+  }
   HIPCHK(c, c->d_fw.reserve(fw_bytes + 64));
   HIPCHK(c, c->d_weight.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_fwd_out.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_counts.reserve((size_t)csize * 8));
   HIPCHK(c, c->d_order_out.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_order_n_out.reserve((size_t)n_reads * 4));
   HIPCHK(c, c->d_rll.reserve((size_t)n_reads * 8));
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)csize * 8, c->stream));
   const Scores& sc = c->scores;
   FbArgs fa{};
   fa.n_refs = n_refs;
   fa.units = c->d_units.as<Unit>();
   fa.ref_off = c->d_ref_off.as<uint64_t>();
   fa.ref_tok = c->d_ref_tok.as<uint8_t>();
-  fa.read_off = c->d_roff.as<uint64_t>();
+  fa.read_off = d_roff;
   fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
   fa.fw = c->d_fw.as<double>();
   fa.lse = c->d_lse.as<double>();
@@ -867,13 +885,13 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   pa.n_reads = n_reads;
   pa.n_refs = n_refs;
   pa.use_null = use_null;
-  pa.nll = c->d_nll.as<double>();
+  pa.nll = c->d_nll.as<double>() + lo;
   pa.lse = c->d_lse.as<double>();
   pa.pair_fwd = c->d_pair_score.as<double>();
   pa.pair_fwd_out = c->d_fwd_out.as<double>();
   pa.weight = c->d_weight.as<double>();
-  pa.order_in = sort_in ? c->d_order_in.as<uint32_t>() : nullptr;
-  pa.order_n_in = sort_in ? c->d_order_n_in.as<uint32_t>() : nullptr;
+  pa.order_in = have_sort ? c->d_order_in.as<uint32_t>() + p0 : nullptr;
+  pa.order_n_in = have_sort ? c->d_order_n_in.as<uint32_t>() + lo : nullptr;
   pa.order_out = c->d_order_out.as<uint32_t>();
   pa.order_n_out = c->d_order_n_out.as<uint32_t>();
   pa.read_loglike = c->d_rll.as<double>();
@@ -890,6 +908,88 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
 
+  HIPCHK(c, hipMemcpyAsync(c->h_fwd.data() + p0, c->d_fwd_out.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_weight.data() + p0, c->d_weight.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_rll.data() + lo, c->d_rll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_order.data() + p0, c->d_order_out.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_order_n.data() + lo, c->d_order_n_out.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + p0, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out->total_cells += bc.total_cells;
+  out->forward_bytes += fw_bytes;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); out->ms_seed += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); out->ms_forward += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_plan += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); out->ms_backward += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
+  (void)csize;
+  return QF_OK;
+}
+
+int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const uint32_t* sort_in,
+                      const uint32_t* sort_n_in, qf_count_result* out) {
+  if (int rc = check_cfg(c, cfg)) return rc;
+  if (!out) return fail(c, QF_ERR_ARG, "null result");
+  if ((sort_in == nullptr) != (sort_n_in == nullptr)) return fail(c, QF_ERR_ARG, "sort_in and sort_n_in go together");
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
+  const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
+  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
+  const uint32_t n_pairs = (uint32_t)n_pairs64;
+  out->n_reads = n_reads;
+  out->n_refs = n_refs;
+  const uint32_t csize = qf_counts_size(c);
+  out->counts_size = csize;
+  c->h_pcounts.assign(csize, 0.0);
+  out->counts = c->h_pcounts.data();
+  if (!n_pairs) return QF_OK;
+  if (!c->reads_have_qual)  // QuaffBackwardMatrix ctor, src/qmodel.cpp:1398
+    return fail(c, QF_ERR_ARG, "Forward-Backward algorithm requires quality scores to fit model");
+  const bool use_null = !(flags & QF_COUNT_FORCE);
+  if (use_null && !c->have_null) return fail(c, QF_ERR_STATE, "no null model set (qf_set_null_json) and QF_COUNT_FORCE not given");
+  const bool sparse = cfg->sparse != 0;
+  if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
+  if (!c->lse_uploaded) {
+    const std::vector<double>& t = lse_table();
+    HIPCHK(c, c->d_lse.reserve(t.size() * 8));
+    HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    c->lse_uploaded = true;
+  }
+
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
+  HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  // pairs outside the read's reference order are not even seeded (their LL stays -inf, qmodel.cpp:2245)
+  HIPCHK(c, c->d_order_in.reserve((size_t)n_pairs * 4));
+  HIPCHK(c, c->d_order_n_in.reserve((size_t)n_reads * 4));
+  if (sort_in) {
+    std::vector<uint8_t> skip(n_pairs, 1);
+    for (uint32_t r = 0; r < n_reads; ++r) {
+      if (sort_n_in[r] > n_refs) return fail(c, QF_ERR_ARG, "sort_n_in out of range");
+      for (uint32_t k = 0; k < sort_n_in[r]; ++k) {
+        const uint32_t x = sort_in[(size_t)r * n_refs + k];
+        if (x >= n_refs) return fail(c, QF_ERR_ARG, "sort_in out of range");
+        skip[(size_t)r * n_refs + x] = 0;
+      }
+    }
+    HIPCHK(c, c->d_skip.reserve(n_pairs));
+    HIPCHK(c, hipMemcpyAsync(c->d_skip.p, skip.data(), n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_order_in.p, sort_in, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_order_n_in.p, sort_n_in, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // `skip` is a stack-lifetime host buffer
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+  {
+    BatchCounters pb;
+    if (int rc = read_counters(c, pb)) return rc;
+    if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
+  }
+  HIPCHK(c, c->d_counts.reserve((size_t)csize * 8));
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)csize * 8, c->stream));
   c->h_fwd.resize(n_pairs);
   c->h_weight.resize(n_pairs);
   c->h_rll.resize(n_reads);
@@ -897,14 +997,22 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   c->h_order.resize(n_pairs);
   c->h_order_n.resize(n_reads);
   c->h_cells.resize(n_pairs);
-  HIPCHK(c, hipMemcpyAsync(c->h_fwd.data(), c->d_fwd_out.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_weight.data(), c->d_weight.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_rll.data(), c->d_rll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_order.data(), c->d_order_out.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_order_n.data(), c->d_order_n_out.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_cells.data(), c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
+  out->ms_total = out->ms_prep;
+  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n_reads}};
+  while (!todo.empty()) {
+    const auto [lo, hi] = todo.back();
+    todo.pop_back();
+    bool too_big = false;
+    if (int rc = count_chunk(c, cfg, use_null, sort_in != nullptr, lo, hi, out, &too_big)) return rc;
+    if (too_big) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      todo.push_back({mid, hi});
+      todo.push_back({lo, mid});
+    }
+  }
+  HIPCHK(c, hipMemcpy(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost));
+  const Scores& sc = c->scores;
 
   // QuaffParamCounts(const QuaffCounts&), src/qmodel.cpp:407-417 (linear, so it commutes with the weighted sum)
   const size_t ne = (size_t)(4 + 4 * sc.Km) * kNQual, Kg = sc.Kg;
@@ -932,15 +1040,7 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   out->sort_order = c->h_order.data();
   out->sort_count = c->h_order_n.data();
   out->loglike = ll;
-  out->total_cells = bc.total_cells;
   out->backward_cells = bcells;
-  out->forward_bytes = fw_bytes;
-  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&out->ms_seed, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&out->ms_forward, c->ev[2], c->ev[3]);
-  (void)hipEventElapsedTime(&out->ms_plan, c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&out->ms_backward, c->ev[4], c->ev[5]);
-  (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
   return QF_OK;
 }
 

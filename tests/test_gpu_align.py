@@ -275,3 +275,34 @@ def test_bad_symbol_and_errors(ctx):
     assert e.value.code == -4
     with pytest.raises(Q.QuaffHipError):
         ctx.set_refs(["ACGTXX"])
+
+
+def test_internal_chunking_matches_single_pass(ctx):
+    """A batch whose traceback exceeds the device budget is processed in halves; results must not change."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(29)
+    ref = rand_seq(rng, 2500)
+    reads = make_reads(rng, ref, 37, 300)
+    refs = both_strands(ref)
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    whole = ctx.align_resident(Q.DPConfig(), 1)
+    try:
+        ctx.set_memory_budget(whole["traceback_bytes"] // 7)
+        parts = ctx.align_resident(Q.DPConfig(), 1)
+    finally:
+        ctx.set_memory_budget(0)
+    for key in ("viterbi", "cells", "n_diagonals", "null_loglike"):
+        assert np.array_equal(whole[key], parts[key]), key
+    assert whole["total_cells"] == parts["total_cells"] and whole["traceback_bytes"] == parts["traceback_bytes"]
+    assert len(whole["alignments"]) == len(parts["alignments"]) == 74
+    for a, b in zip(whole["alignments"], parts["alignments"]):
+        assert (a["read"], a["ref"], a["score"], a["xStart"], a["xEnd"], a["ops"]) == \
+               (b["read"], b["ref"], b["score"], b["xStart"], b["xEnd"], b["ops"])
+    # a budget below a single read's traceback is an error, not a silent truncation
+    try:
+        ctx.set_memory_budget(1024)
+        with pytest.raises(Exception, match="over the memory budget"):
+            ctx.align_resident(Q.DPConfig(), 0)
+    finally:
+        ctx.set_memory_budget(0)

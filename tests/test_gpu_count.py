@@ -124,3 +124,27 @@ def test_c8f30_counts_golden_through_gpu(ctx):
             np.testing.assert_allclose(g, w, rtol=RTOL, atol=1e-6)
     finally:
         ctx.set_null_json(NULL_JSON)
+
+
+def test_count_internal_chunking(ctx):
+    """Forward matrices over the device budget: the E-step runs in halves, same per-read results, counts to 1e-9."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(35)
+    ref = rand_seq(rng, 1200)
+    reads = make_reads(rng, ref, 13, 260)
+    refs = both_strands(ref)
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    whole = ctx.count_resident(Q.DPConfig())
+    try:
+        ctx.set_memory_budget(whole["forward_bytes"] // 5)
+        parts = ctx.count_resident(Q.DPConfig())
+        parts2 = ctx.count_resident(Q.DPConfig(), sort_order=whole["sort_order"])
+    finally:
+        ctx.set_memory_budget(0)
+    whole2 = ctx.count_resident(Q.DPConfig(), sort_order=whole["sort_order"])
+    for w, p in ((whole, parts), (whole2, parts2)):
+        assert np.array_equal(w["forward"], p["forward"]) and np.array_equal(w["read_loglike"], p["read_loglike"])
+        assert w["sort_order"] == p["sort_order"] and w["loglike"] == p["loglike"]
+        assert w["total_cells"] == p["total_cells"] and w["forward_bytes"] == p["forward_bytes"]
+        np.testing.assert_allclose(p["counts"], w["counts"], rtol=1e-9, atol=1e-12)
