@@ -1054,6 +1054,137 @@ static int ensure_lse(qf_ctx* c) {
   return QF_OK;
 }
 
+// Pairs [lo, hi) of the uploaded pair list.  Results go to the host arrays at the chunk's offsets; *too_big (nothing done)
+// when the chunk's traceback exceeds the memory budget.
+static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t lo, uint32_t hi,
+                         qf_overlap_result* out, bool* too_big) {
+  *too_big = false;
+  const uint32_t n_pairs = hi - lo;
+  const bool sparse = cfg->sparse != 0;
+  const bool mem = sparse && cfg->kmer_threshold < 0;
+  const Scores& sc = c->scores;
+  const uint32_t max_units = n_pairs * 4 + 1024;
+  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+  // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
+  const int max_nd = (int)(2 * c->read_maxlen - 1);
+  SeedArgs sa;
+  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  sa.pair_x = c->d_px.as<uint32_t>() + lo;
+  sa.pair_y = c->d_py.as<uint32_t>() + lo;
+  sa.ref_off = c->d_roff.as<uint64_t>();
+  sa.ref_bucket = c->d_rbucket.as<uint32_t>();
+  sa.ref_pos = c->d_rpos.as<uint32_t>();
+  sa.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
+  sa.storage_mode = 2;
+  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
+    return fail(c, QF_ERR_UNSUPPORTED, "read + read length exceeds the LDS diagonal histogram");
+  launch_bin_units(sa, n_pairs, 0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  BatchCounters bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  if (bc.n_ovf && !(bc.error & 8u)) {
+    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (int rc = read_counters(c, bc)) return rc;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  if (bc.error & 2u)
+    return fail(c, QF_ERR_UNSUPPORTED, "overlap band of " + std::to_string(bc.error_detail) + " diagonals: the overlap kernels take up to 512 (no row-space overlap kernel yet)");
+  if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
+  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
+
+  // ---- fill
+  const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
+  if (tb_bytes > c->tb_budget) {
+    if (n_pairs == 1) return fail(c, QF_ERR_MEMORY, "one pair needs " + std::to_string(tb_bytes >> 20) + " MiB of traceback, over the memory budget");
+    *too_big = true;
+    return QF_OK;
+  }
+  HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
+  HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
+  HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
+  HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));
+  OvArgs oa{};
+  oa.n_pairs = n_pairs;
+  oa.units = c->d_units.as<Unit>();
+  oa.pair_x = c->d_px.as<uint32_t>() + lo;
+  oa.pair_y = c->d_py.as<uint32_t>() + lo;
+  oa.pair_comp = c->d_pc.as<uint8_t>() + lo;
+  oa.seq_off = c->d_roff.as<uint64_t>();
+  oa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+  oa.ctxc = c->d_ctxc.as<uint32_t>() + kCtxPad;
+  oa.tb = c->d_tb.as<uint32_t>();
+  oa.mmi[0] = c->d_mmi0.as<double>();
+  oa.mmi[1] = c->d_mmi1.as<double>();
+  oa.gap[0] = c->d_gap0.as<double>();
+  oa.gap[1] = c->d_gap1.as<double>();
+  if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
+  if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
+  oa.lse = c->d_lse.as<double>();
+  oa.Km = sc.Km;
+  oa.Kg = sc.Kg;
+  oa.pair_head = c->d_pair_head.as<uint32_t>();
+  oa.ins_sum = c->d_ins_sum.as<double>();
+  oa.ins_sum_c = c->d_ins_sum_c.as<double>();
+  oa.nll = c->d_nll.as<double>();
+  oa.nll_c = c->d_nll_c.as<double>();
+  oa.pair_result = c->d_pair_result.as<double>();
+  oa.pair_score = c->d_pair_score.as<double>();
+  oa.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
+  oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
+  oa.recs = c->d_recs.as<AlignRec>();
+  oa.bc = c->d_bc.as<BatchCounters>();
+  for (int cls = 10; cls >= 0; --cls) {
+    oa.n_cls_units = bc.cls_count[cls];
+    oa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+    launch_overlap_fill(cls, oa, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  launch_overlap_finalize(oa, c->stream);
+  HIPCHK(c, hipGetLastError());
+  const BatchCounters seed_bc = bc;
+  if (int rc = read_counters(c, bc)) return rc;
+  const uint32_t n_recs = bc.n_align;
+  HIPCHK(c, c->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
+  HIPCHK(c, c->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
+  oa.n_recs = n_recs;
+  oa.runs_tmp = c->d_runs_tmp.as<uint32_t>();
+  oa.runs_out = c->d_runs_out.as<uint32_t>();
+  launch_overlap_traceback(oa, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (int rc = read_counters(c, bc)) return rc;
+  const uint64_t total_runs = bc.total_runs_out;
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+
+  const size_t recs0 = c->h_recs.size(), runs0 = c->h_runs.size();
+  c->h_recs.resize(recs0 + n_recs);
+  c->h_runs.resize(runs0 + total_runs);
+  HIPCHK(c, hipMemcpyAsync(c->h_ov_result.data() + lo, c->d_pair_result.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ov_score.data() + lo, c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + lo, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data() + lo, c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data() + recs0, c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data() + runs0, c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t a = recs0; a < recs0 + n_recs; ++a) {
+    c->h_recs[a].read += lo;
+    c->h_recs[a].run_off += runs0;
+  }
+  out->total_cells += seed_bc.total_cells;
+  out->traceback_bytes += tb_bytes;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); out->ms_seed += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); out->ms_fill += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_traceback += ms;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
+  return QF_OK;
+}
+
 int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair_x, const uint32_t* pair_y,
                         const uint8_t* y_comp, uint32_t n_pairs, qf_overlap_result* out) {
   if (!c) return QF_ERR_ARG;
@@ -1073,7 +1204,6 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     need[y_comp[p] ? 1 : 0] = true;
   }
   const bool sparse = cfg->sparse != 0;
-  const bool mem = sparse && cfg->kmer_threshold < 0;
   if (int rc = ensure_lse(c)) return rc;
   const Scores& sc = c->scores;
   // pair-emission tables: once per (parameters, strand flag), not once per pair (src/qoverlap.cpp:79)
@@ -1101,8 +1231,8 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     HIPCHK(c, hipMemsetAsync(c->d_rcursor.p, 0, bytes, c->stream));
   }
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  const uint32_t max_units = n_pairs * 4 + 1024;
-  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
+  HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
   if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
   if (sparse && c->read_index_k != cfg->kmer_len && cfg->kmer_len > kMaxRefK) {
     if (int rc = build_sorted_index(c, c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), c->read_off, c->read_maxlen, cfg->kmer_len,
@@ -1153,109 +1283,32 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   HIPCHK(c, hipMemcpyAsync(c->d_pc.p, y_comp, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
-  // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
-  const int max_nd = (int)(2 * c->read_maxlen - 1);
-  SeedArgs sa;
-  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
-  sa.pair_x = c->d_px.as<uint32_t>();
-  sa.pair_y = c->d_py.as<uint32_t>();
-  sa.ref_off = c->d_roff.as<uint64_t>();
-  sa.ref_bucket = c->d_rbucket.as<uint32_t>();
-  sa.ref_pos = c->d_rpos.as<uint32_t>();
-  sa.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
-  sa.storage_mode = 2;
-  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
-    return fail(c, QF_ERR_UNSUPPORTED, "read + read length exceeds the LDS diagonal histogram");
-  launch_bin_units(sa, n_pairs, 0, c->stream);
-  HIPCHK(c, hipGetLastError());
-  BatchCounters bc;
-  if (int rc = read_counters(c, bc)) return rc;
-  if (bc.n_ovf && !(bc.error & 8u)) {
-    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (int rc = read_counters(c, bc)) return rc;
+  {
+    BatchCounters pb;
+    if (int rc = read_counters(c, pb)) return rc;
+    if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
   }
-  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
-  if (bc.error & 2u)
-    return fail(c, QF_ERR_UNSUPPORTED, "overlap band of " + std::to_string(bc.error_detail) + " diagonals: the overlap kernels take up to 512 (no row-space overlap kernel yet)");
-  if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
-  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
-
-  // ---- fill
-  const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
-  if (tb_bytes > (200ull << 30)) return fail(c, QF_ERR_MEMORY, "traceback needs " + std::to_string(tb_bytes >> 30) + " GiB; split the pair list");
-  HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
-  HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));
-  OvArgs oa{};
-  oa.n_pairs = n_pairs;
-  oa.units = c->d_units.as<Unit>();
-  oa.pair_x = c->d_px.as<uint32_t>();
-  oa.pair_y = c->d_py.as<uint32_t>();
-  oa.pair_comp = c->d_pc.as<uint8_t>();
-  oa.seq_off = c->d_roff.as<uint64_t>();
-  oa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
-  oa.ctxc = c->d_ctxc.as<uint32_t>() + kCtxPad;
-  oa.tb = c->d_tb.as<uint32_t>();
-  oa.mmi[0] = c->d_mmi0.as<double>();
-  oa.mmi[1] = c->d_mmi1.as<double>();
-  oa.gap[0] = c->d_gap0.as<double>();
-  oa.gap[1] = c->d_gap1.as<double>();
-  if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
-  if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
-  oa.lse = c->d_lse.as<double>();
-  oa.Km = sc.Km;
-  oa.Kg = sc.Kg;
-  oa.pair_head = c->d_pair_head.as<uint32_t>();
-  oa.ins_sum = c->d_ins_sum.as<double>();
-  oa.ins_sum_c = c->d_ins_sum_c.as<double>();
-  oa.nll = c->d_nll.as<double>();
-  oa.nll_c = c->d_nll_c.as<double>();
-  oa.pair_result = c->d_pair_result.as<double>();
-  oa.pair_score = c->d_pair_score.as<double>();
-  oa.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
-  oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
-  oa.recs = c->d_recs.as<AlignRec>();
-  oa.bc = c->d_bc.as<BatchCounters>();
-  for (int cls = 10; cls >= 0; --cls) {
-    oa.n_cls_units = bc.cls_count[cls];
-    oa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-    launch_overlap_fill(cls, oa, c->stream);
-  }
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-  launch_overlap_finalize(oa, c->stream);
-  HIPCHK(c, hipGetLastError());
-  const BatchCounters seed_bc = bc;
-  if (int rc = read_counters(c, bc)) return rc;
-  const uint32_t n_recs = bc.n_align;
-  HIPCHK(c, c->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
-  HIPCHK(c, c->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
-  oa.n_recs = n_recs;
-  oa.runs_tmp = c->d_runs_tmp.as<uint32_t>();
-  oa.runs_out = c->d_runs_out.as<uint32_t>();
-  launch_overlap_traceback(oa, c->stream);
-  HIPCHK(c, hipGetLastError());
-  if (int rc = read_counters(c, bc)) return rc;
-  const uint64_t total_runs = bc.total_runs_out;
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-
+  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
+  out->ms_total = out->ms_prep;
   c->h_ov_result.resize(n_pairs);
   c->h_ov_score.resize(n_pairs);
   c->h_cells.resize(n_pairs);
   c->h_ndiag.resize(n_pairs);
-  c->h_recs.resize(n_recs);
-  c->h_runs.resize(total_runs);
-  HIPCHK(c, hipMemcpyAsync(c->h_ov_result.data(), c->d_pair_result.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_ov_score.data(), c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_cells.data(), c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data(), c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data(), c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
-  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data(), c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->h_recs.clear();
+  c->h_runs.clear();
+  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n_pairs}};
+  while (!todo.empty()) {
+    const auto [lo, hi] = todo.back();
+    todo.pop_back();
+    bool too_big = false;
+    if (int rc = overlap_chunk(c, cfg, need, lo, hi, out, &too_big)) return rc;
+    if (too_big) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      todo.push_back({mid, hi});
+      todo.push_back({lo, mid});
+    }
+  }
+  const uint32_t n_recs = (uint32_t)c->h_recs.size();
   std::sort(c->h_recs.begin(), c->h_recs.end(), [](const AlignRec& p, const AlignRec& q) { return p.read < q.read; });
   c->h_ov_align.resize(n_recs);
   for (uint32_t a = 0; a < n_recs; ++a) {
@@ -1274,16 +1327,9 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   out->score = c->h_ov_score.data();
   out->cells = c->h_cells.data();
   out->n_diagonals = c->h_ndiag.data();
-  out->total_cells = seed_bc.total_cells;
   out->n_alignments = n_recs;
   out->alignments = c->h_ov_align.data();
   out->state_runs = c->h_runs.data();
-  out->traceback_bytes = tb_bytes;
-  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&out->ms_seed, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&out->ms_fill, c->ev[2], c->ev[3]);
-  (void)hipEventElapsedTime(&out->ms_traceback, c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[5]);
   return QF_OK;
 }
 

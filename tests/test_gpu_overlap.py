@@ -113,3 +113,27 @@ def test_c8f30_overlap_golden_through_gpu(ctx):
         assert O.overlap_stockholm(seqs[0], seqs[1], al) == open(os.path.join(golden, "c8f30-self-overlap.json")).read()
     finally:
         ctx.set_null_json(NULL_JSON)
+
+
+def test_overlap_internal_chunking(ctx):
+    """A pair list whose traceback exceeds the device budget runs in halves with identical results."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(45)
+    reads = overlapping_reads(rng, 1500, 7, 350)
+    seqs = reads + [r.revcomp() for r in reads]
+    pairs = O.overlap_task_pairs(7, 14)
+    ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    whole = ctx.overlap_resident(pairs, Q.DPConfig(kmer_threshold=14))
+    try:
+        ctx.set_memory_budget(whole["traceback_bytes"] // 6)
+        parts = ctx.overlap_resident(pairs, Q.DPConfig(kmer_threshold=14))
+    finally:
+        ctx.set_memory_budget(0)
+    for key in ("viterbi", "cells", "n_diagonals"):
+        assert np.array_equal(whole[key], parts[key]), key
+    assert whole["total_cells"] == parts["total_cells"]
+    assert sorted(whole["alignments"]) == sorted(parts["alignments"])
+    for k, a in whole["alignments"].items():
+        b = parts["alignments"][k]
+        assert (a["result"], a["score"], a["xStart"], a["xEnd"], a["yStart"], a["yEnd"], a["ops"]) == \
+               (b["result"], b["score"], b["xStart"], b["xEnd"], b["yStart"], b["yEnd"], b["ops"]), k
