@@ -41,6 +41,8 @@ def parse():
                     help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = scaled "
                          "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
     ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
+    ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
+    ap.add_argument("--align-flags", type=int, default=0, help="developer: QF_ALIGN_* flags (2 = scores only, not a valid bench)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (rehearse the N>1 path on a one-GPU box)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = this process's CPU share (at most 16)")
@@ -235,21 +237,21 @@ def main():
     ctx.set_refs([ref, api.revcomp(ref)])
     seq, qual, off = api.synth_reads(2 + rank, ref, a.reads, a.read_len)
     ctx.upload_reads_packed(seq, qual, off)          # resident in HBM before the timed region
-    cfg = Q.DPConfig(band_size=a.band, debug_flags=2 if a.reference_kernel else 0)
+    cfg = Q.DPConfig(band_size=a.band, debug_flags=(2 if a.reference_kernel else 0) | (4 if a.serial_classes else 0))
 
     def sync_all():
         if world > 1:
             dist.barrier()                    # barrier + torch.cuda.synchronize() on both sides
 
     for _ in range(a.warmup):
-        ctx.align_resident(cfg, 0, raw=True)
+        ctx.align_resident(cfg, a.align_flags, raw=True)
     sync_all()
     t0 = time.perf_counter()
     cls_ms, cls_cells, cls_names = {}, {}, {}
     phases = {"prep": 0.0, "seed": 0.0, "fill": 0.0, "traceback": 0.0, "total": 0.0}
     total_cells = 0
     for _ in range(a.steps):
-        res = ctx.align_resident(cfg, 0, raw=True)   # synchronous: returns after results are on the host
+        res = ctx.align_resident(cfg, a.align_flags, raw=True)   # synchronous: returns after results are on the host
         total_cells += int(res.total_cells)
         for k in range(res.n_fill_classes):
             if res.units_class[k]:

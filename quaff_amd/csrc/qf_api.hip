@@ -49,7 +49,8 @@ struct qf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
-  hipEvent_t cls_ev[kNumClasses + 1] = {};
+  hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
+  hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   std::string err, devname;
   // model
   Params params;
@@ -138,6 +139,8 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   }
   for (auto& ev : c->ev) (void)hipEventCreate(&ev);
   for (auto& ev : c->cls_ev) (void)hipEventCreate(&ev);
+  for (auto& ev : c->cls_end) (void)hipEventCreate(&ev);
+  for (auto& s : c->aux) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   *out = c;
   return QF_OK;
 }
@@ -160,6 +163,8 @@ void qf_ctx_destroy(qf_ctx* c) {
   if (c->sort_temp) (void)hipFree(c->sort_temp);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->cls_ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->cls_end) if (ev) (void)hipEventDestroy(ev);
+  for (auto& s : c->aux) if (s) (void)hipStreamDestroy(s);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -211,7 +216,7 @@ static int install_params(qf_ctx* c, const Params& p) {
   const Scores& s = c->scores;
   // device layout of the match table: [(kmer*95 + q)*4 + refTok] so the four reference-token variants
   // of one read column are adjacent
-  std::vector<double> em((size_t)s.Km * kNQ1 * 4);
+  std::vector<double> em((size_t)s.Km * kNQ1 * 4 + 4, -INFINITY);  // + one row of -inf (slots outside a band read it)
   for (uint32_t t = 0; t < 4; ++t)
     for (uint32_t k = 0; k < s.Km; ++k)
       for (int q = 0; q < kNQ1; ++q) em[((size_t)k * kNQ1 + q) * 4 + t] = s.mat[((size_t)t * s.Km + k) * kNQ1 + q];
@@ -589,6 +594,7 @@ static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint3
   fa.tb = c->d_tb.as<uint32_t>();
   const Scores& sc = c->scores;
   fa.dp.ematch = c->d_ematch.as<double>();
+  fa.dp.ematch_ninf_off = (uint32_t)((size_t)c->scores.Km * kNQ1 * 4 * 8);
   fa.dp.eins = c->d_eins.as<double>();
   fa.dp.trans = c->d_trans.as<double>();
   fa.dp.d2d = sc.trans[4 * sc.Kg + 0];
@@ -598,14 +604,26 @@ static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint3
   fa.dp.Kg = sc.Kg;
   fa.dp.local = cfg->local;
   fa.reference_kernel = (cfg->reserved >> 1) & 1;
-  // widest classes first: they run longest
-  for (int cls = kNumClasses - 1; cls >= 0; --cls) {
-    HIPCHK(c, hipEventRecord(c->cls_ev[cls + 1], c->stream));
-    fa.n_cls_units = bc.cls_count[cls];
-    fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-    launch_viterbi_fill(cls, fa, sc.Kg > 1, c->stream);
+  fa.no_lds_tables = (cfg->reserved >> 3) & 1;
+  // One kernel per class, the class with the most cells first, spread over the main and the side streams: the small
+  // classes (and the single-diagonal chains, which are latency-bound) fill the SIMDs the big class's last wavefronts
+  // leave idle.  Everything was seeded on the main stream, which the host has already waited for.
+  {
+    int order[kNumClasses], n_used = 0;
+    for (int cls = 0; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
+    std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
+    const bool concurrent = !(cfg->reserved & 4);
+    for (int k = 0; k < n_used; ++k) {
+      const int cls = order[k], lane = concurrent ? k % 4 : 0;
+      hipStream_t s = lane == 0 ? c->stream : c->aux[lane - 1];
+      HIPCHK(c, hipEventRecord(c->cls_ev[cls], s));
+      fa.n_cls_units = bc.cls_count[cls];
+      fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+      launch_viterbi_fill(cls, fa, sc.Kg > 1, s);
+      HIPCHK(c, hipEventRecord(c->cls_end[cls], s));
+      if (lane) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[cls], 0));
+    }
   }
-  HIPCHK(c, hipEventRecord(c->cls_ev[0], c->stream));
   const BatchCounters seed_bc = bc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
@@ -672,9 +690,8 @@ static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint3
   (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_traceback += ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
   for (int cls = 0; cls < kNumClasses; ++cls) {
-    // class cls ran between cls_ev[cls+1] and the next lower class's start (cls_ev[cls]); cls 0 ends at cls_ev[0]
     ms = 0;
-    if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&ms, c->cls_ev[cls + 1], c->cls_ev[cls]);
+    if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&ms, c->cls_ev[cls], c->cls_end[cls]);
     out->ms_fill_class[cls] += ms;
     out->cells_class[cls] += seed_bc.cls_cells[cls];
     out->units_class[cls] += seed_bc.cls_count[cls];
@@ -852,6 +869,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.fw = c->d_fw.as<double>();
   fa.lse = c->d_lse.as<double>();
   fa.dp.ematch = c->d_ematch.as<double>();
+  fa.dp.ematch_ninf_off = (uint32_t)((size_t)c->scores.Km * kNQ1 * 4 * 8);
   fa.dp.eins = c->d_eins.as<double>();
   fa.dp.trans = c->d_trans.as<double>();
   fa.dp.d2d = sc.trans[4 * sc.Kg + 0];

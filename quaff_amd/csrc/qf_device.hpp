@@ -114,6 +114,8 @@ struct BatchCounters {
   unsigned long long total_runs_out;  // compacted CIGAR runs written by the traceback kernel
 };
 
+constexpr uint32_t kInsRows = 4 * 95;  // insert-emission table: [token * 95 + quality]
+
 struct DpParams {  // kernel argument block for the fills
   const double* ematch;   // [(matchKmer*95 + q)*4 + refTok]
   const double* eins;     // [tok*95 + q]
@@ -121,6 +123,8 @@ struct DpParams {  // kernel argument block for the fills
   double d2d, d2m, i2i, i2m;
   uint32_t Kg;
   int32_t local;
+  uint32_t ematch_ninf_off;  // byte offset of a -inf entry placed after the last row of ematch
+  uint32_t pad_;
 };
 
 }  // namespace qf

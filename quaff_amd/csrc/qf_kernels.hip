@@ -846,14 +846,20 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
 //    reference's M, I, D order) instead of value/flag select chains.
 //  * Lane exchange by DPP row/wave shifts (a -inf "old" value fills the group's edge lane) instead of ds_bpermute.
 // ------------------------------------------------------------------------------------------------
+#ifndef QF_EXP
+#define QF_EXP 0
+#endif
 #ifndef QF_STEP_UNROLL
 #define QF_STEP_UNROLL 4
+#endif
+#ifndef QF_FILL2_OCC
+#define QF_FILL2_OCC
 #endif
 template <int G>
 __device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf in the group's lane 0
   constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
   const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
   const int hi = __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
@@ -861,13 +867,31 @@ template <int G>
 __device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf in the group's last lane
   constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
   const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
   const int hi = __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int G, int B, bool GAPCTX>
-__global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
+// acc = 2 * acc + (x > y): the compare's lane mask goes straight into an add-with-carry (no select / shift / or)
+__device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y) {
+  const unsigned long long mask = __builtin_amdgcn_fcmp(x, y, 2 /* ordered > */);
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
+  return acc;
+}
+
+template <int G, int B, bool GAPCTX, bool EMLDS>
+__global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) {
+  // EMLDS: the match-emission table (+ its -inf row) and the insert-emission table are copied to LDS once per workgroup.
+  // Every lane of a wavefront is on a different read column, so the B emission fetches of a step are 64-way gathers;
+  // through the vector L1 those gathers, not the arithmetic, bound the kernel (measured), LDS serves them far faster.
+  extern __shared__ double lds_tab[];
+  const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
+  if (EMLDS) {
+    for (uint32_t k = threadIdx.x; k < n_em; k += 256) lds_tab[k] = a.dp.ematch[k];
+    for (uint32_t k = threadIdx.x; k < kInsRows; k += 256) lds_tab[n_em + k] = a.dp.eins[k];
+    __syncthreads();
+  }
   constexpr int UPW = 64 / G;
   constexpr int WPL = B > 8 ? 2 : 1;
   const int lane = threadIdx.x & 63;
@@ -893,8 +917,8 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
   const int d0 = dlo + l * B;
   const int bmax = active ? dhi - d0 : -1;  // slots b > bmax are outside the band
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
-  const double* __restrict__ ematch = a.dp.ematch;
-  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ ematch = EMLDS ? lds_tab : a.dp.ematch;
+  const double* __restrict__ eins = EMLDS ? lds_tab + n_em : a.dp.eins;
   const double* __restrict__ trans = a.dp.trans;
   const uint32_t Kg = a.dp.Kg;
   const bool local = a.dp.local != 0;
@@ -928,21 +952,51 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
   uint32_t gkPrev = 0;
   uint32_t* __restrict__ tb = a.tb + tb_off;
 
+  // Emission scores are fetched one step ahead (context word, reference-token window and the B match rows of step t+1
+  // are all known at step t), so a step never waits for its own loads.
+  // Slots above the band's last diagonal read a -inf emission instead: their match and insert states stay -inf, and
+  // the delete state they pick up from inside the band never reaches a valid cell.
+  const uint32_t ninf_off = a.dp.ematch_ninf_off;
+  auto emis = [&](uint32_t w, uint32_t window, int b) -> double {
+    uint32_t off = ((w & 0x7FFFu) << 5) | (((window >> (2 * b)) & 3u) << 3);
+    if (b > bmax) off = ninf_off;
+    return *(const double*)((const char*)ematch + off);
+  };
+  uint32_t wN = cwn.v[0];
+  const uint32_t tok0 = (uint32_t)((((unsigned long long)xnx << 32) | xhi) >> sh0) & 3u;  // (xhi, xnx) become chunk 0's window
+  uint32_t winN = (win >> 2) | (tok0 << (2 * (B - 1)));
+  double eN[B], insEN = eins[(wN >> 15) & 0x1FFu];
+#pragma unroll
+  for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b);
+
   int chunk = 0;
   for (int t0 = 0; t0 < T; t0 += 16, ++chunk) {
     xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
     const unsigned long long xpair = ((unsigned long long)xhi << 32) | xlo;
     for (int s4 = 0; s4 < 16; s4 += 4) {
-      U32x4 cw = cwn;
+      const U32x4 cw = cwn;
       cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
-#pragma unroll QF_STEP_UNROLL
+#pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int t = t0 + s4 + s;
         const int j = t - l + 1;
         const bool colvalid = active && j >= 1 && j <= yLen;
-        const uint32_t w = cw.v[0];
-        cw.v[0] = cw.v[1]; cw.v[1] = cw.v[2]; cw.v[2] = cw.v[3];
-        const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
+        const uint32_t w = wN;
+        const double insE = insEN;
+        double e[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) e[b] = eN[b];
+        // step t+1's fetch (the token of step 16 of a chunk is the next chunk's first: still inside the 64-bit window)
+        wN = s < 3 ? cw.v[s + 1] : cwn.v[0];
+        winN = (winN >> 2) | (((uint32_t)(xpair >> (sh0 + 2 * (s4 + s + 1))) & 3u) << (2 * (B - 1)));
+        insEN = eins[(wN >> 15) & 0x1FFu];
+#pragma unroll
+#if QF_EXP == 2
+        for (int b = 0; b < B; ++b) eN[b] = insEN;
+#else
+        for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b);
+#endif
+        const uint32_t gk = w >> 24;
         double m2m, m2i, m2d;
         if (GAPCTX) {
           const uint32_t gp = j <= 1 ? 0u : gkPrev;
@@ -951,43 +1005,43 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
         } else {
           m2m = c_m2m; m2i = c_m2i; m2d = c_m2d;
         }
-        const double insE = eins[insrow];
-        const uint32_t newTok = (uint32_t)(xpair >> (sh0 + 2 * (s4 + s))) & 3u;
-        win = (win >> 2) | (newTok << (2 * (B - 1)));
         const double lowM = dpp_from_below<G>(pubM), lowD = dpp_from_below<G>(pubD);
-        double e[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) e[b] = ematch[erow4 + ((win >> (2 * b)) & 3u)];
 
         // a lane needs the general step on its first / last column and while its lowest row is above row 1
-        const bool needSlow = active && (j == 1 || j == yLen || (j > 1 && j < yLen && d0 + j < 1));
+        const bool needSlow = active & ((j == 1) | (j == yLen) | ((j > 1) & (j < yLen) & (d0 + j < 1)));
         uint32_t tbw0 = 0, tbw1 = 0;
         double upM = 0, upI = 0;
         double prevM = lowM, prevD = lowD;
         if (!__builtin_amdgcn_ballot_w64(needSlow)) {
           // ---------------- FAST step
+          // flags are shifted in as raw compare bits, one v_addc each (first slot ends up highest, bits I>M, D>max(M,I),
+          // ins-from-I, del-from-D from the top of its nibble); a bit reverse restores "slot b at nibble b" with the usual
+          // bit order.  Match source "I>M and D>max" reads as 3, which the traceback takes as D away from column 1.
+          uint32_t acc0 = 0, acc1 = 0;
 #pragma unroll
           for (int b = 0; b < B; ++b) {
             const double tM = (M[b] + m2m) + e[b], tI = (I[b] + i2m) + e[b], tD = (D[b] + d2m) + e[b];
             const double m1 = fmax(tM, tI);
             const double nm = fmax(m1, tD);
-            uint32_t sm = tI > tM ? 1u : 0u;     // first maximum in the order M, I, D (strict >)
-            sm = tD > m1 ? 2u : sm;
             double srcM, srcI;
             if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
             const double cM = (srcM + m2i) + insE, cI = (srcI + i2i) + insE;
             const double ni = fmax(cM, cI);
-            const uint32_t si = cI > cM ? 4u : 0u;
             const double gM = prevM + m2d, gD = prevD + d2d;
-            double ndl = fmax(gM, gD);
-            const uint32_t sd = gD > gM ? 8u : 0u;
-            if (b > bmax) ndl = QF_NEG_INF;      // the slot just outside the band must not pick up del from inside it
+            const double ndl = fmax(gM, gD);
+            uint32_t& acc = b < 8 ? acc0 : acc1;
+#if QF_EXP != 1
+            acc = shift_in_gt(acc, tI, tM);
+            acc = shift_in_gt(acc, tD, m1);
+            acc = shift_in_gt(acc, cI, cM);
+            acc = shift_in_gt(acc, gD, gM);
+#endif
             M[b] = nm; I[b] = ni; D[b] = ndl;
             prevM = nm; prevD = ndl;
-            const uint32_t nib = sm | si | sd;
-            if (b < 8) tbw0 |= nib << (4 * (b & 7)); else tbw1 |= nib << (4 * (b & 7));
             if (b == 0) { upM = dpp_from_above<G>(nm); upI = dpp_from_above<G>(ni); }
           }
+          tbw0 = __builtin_bitreverse32(acc0) >> (32 - 4 * (B < 8 ? B : 8));
+          if (B > 8) tbw1 = __builtin_bitreverse32(acc1) >> (B > 8 ? 32 - 4 * (B - 8) : 0);
         } else {
           // ---------------- general step (start candidate, end tracking, full validity masking)
           const bool startCol = j == 1, endCol = j == yLen;
@@ -1026,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
           }
         }
         pubM = prevM; pubD = prevD;
-        if (colvalid) {
+        if (colvalid && QF_EXP != 3) {
           if (WPL == 1) tb[(uint64_t)t * G + l] = tbw0;
           else { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
         }
@@ -1385,7 +1439,9 @@ __global__ void k_traceback(FinalArgs a) {
       op = 0;
       const uint32_t s = nib & 3u;
       --i; --j;
-      state = s == 0 ? 1 : s == 1 ? 2 : s == 2 ? 3 : 0;
+      // 3 = Start on column 1 (the only place a start candidate exists); elsewhere the trimmed fill's raw compare bits
+      // "I>M and D>max(M,I)", i.e. D
+      state = s == 0 ? 1 : s == 1 ? 2 : (s == 2 || j > 0) ? 3 : 0;
     } else if (state == 2) {
       op = 1;
       --j;
@@ -1424,8 +1480,15 @@ static void launch_fill_gb(const FillArgs& a, bool gapctx, hipStream_t s) {
     if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_viterbi_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
   } else {
-    if (gapctx) hipLaunchKernelGGL((k_viterbi_fill2<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_viterbi_fill2<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+    // emission tables in LDS when three workgroups' copies fit a CU's 160 KB (match contexts of up to 2 bases)
+    const uint32_t lds_bytes = a.dp.ematch_ninf_off + 32 + kInsRows * 8;
+    if (lds_bytes <= 52 * 1024 && !a.no_lds_tables) {
+      if (gapctx) hipLaunchKernelGGL((k_viterbi_fill2<G, B, true, true>), dim3(blocks), dim3(256), lds_bytes, s, a);
+      else hipLaunchKernelGGL((k_viterbi_fill2<G, B, false, true>), dim3(blocks), dim3(256), lds_bytes, s, a);
+    } else {
+      if (gapctx) hipLaunchKernelGGL((k_viterbi_fill2<G, B, true, false>), dim3(blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_viterbi_fill2<G, B, false, false>), dim3(blocks), dim3(256), 0, s, a);
+    }
   }
 }
 

@@ -79,6 +79,7 @@ struct FillArgs {
   uint32_t* tb;
   DpParams dp;
   int reference_kernel;        // 1: launch the first-generation fill kernel (debug / A-B)
+  int no_lds_tables;           // 1: keep the emission tables in global memory even when they fit LDS (debug / A-B)
 };
 
 struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
