@@ -42,6 +42,7 @@ def parse():
                          "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
     ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
     ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
+    ap.add_argument("--chunks", type=int, default=0, help="pieces per batch kept two in flight (0 = library default)")
     ap.add_argument("--align-flags", type=int, default=0, help="developer: QF_ALIGN_* flags (2 = scores only, not a valid bench)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (rehearse the N>1 path on a one-GPU box)")
@@ -237,6 +238,7 @@ def main():
     ctx.set_refs([ref, api.revcomp(ref)])
     seq, qual, off = api.synth_reads(2 + rank, ref, a.reads, a.read_len)
     ctx.upload_reads_packed(seq, qual, off)          # resident in HBM before the timed region
+    ctx.set_pipeline_chunks(a.chunks)
     cfg = Q.DPConfig(band_size=a.band, debug_flags=(2 if a.reference_kernel else 0) | (4 if a.serial_classes else 0))
 
     def sync_all():

@@ -83,7 +83,7 @@ class _OverlapResult(C.Structure):
 EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
-           "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget"]
+           "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks"]
 
 
 def load_library():
@@ -211,6 +211,10 @@ class Context:
     def set_memory_budget(self, nbytes):
         self.L.qf_set_memory_budget.argtypes = [C.c_void_p, C.c_uint64]
         self._chk(self.L.qf_set_memory_budget(self.h, nbytes))
+
+    def set_pipeline_chunks(self, n):
+        self.L.qf_set_pipeline_chunks.argtypes = [C.c_void_p, C.c_uint32]
+        self._chk(self.L.qf_set_pipeline_chunks(self.h, n))
 
     def device_name(self):
         b = C.create_string_buffer(256)

@@ -3,7 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -43,15 +47,87 @@ struct DevBuf {
     cap = 0;
   }
 };
+
+// Host-side result array in pinned memory (device-to-host copies into pageable memory run at a fraction of the link rate).
+// The little of std::vector the result code uses; contents survive growth.
+template <typename T>
+struct HostBuf {
+  T* p = nullptr;
+  size_t n = 0, cap = 0;
+  bool pinned = false;
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { release(); }
+  void release() {
+    if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+    p = nullptr; n = cap = 0;
+  }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    const size_t ncap = std::max(want, cap + cap / 2 + 64);
+    T* q = nullptr;
+    bool pin = hipHostMalloc((void**)&q, ncap * sizeof(T), hipHostMallocDefault) == hipSuccess;
+    if (!pin) q = (T*)malloc(ncap * sizeof(T));
+    if (n) memcpy(q, p, n * sizeof(T));
+    const size_t keep = n;
+    release();
+    p = q; n = keep; cap = ncap; pinned = pin;
+  }
+  void resize(size_t m) { reserve(m); n = m; }
+  void clear() { n = 0; }
+  size_t size() const { return n; }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
+  void append(const T* src, size_t m) { reserve(n + m); if (m) memcpy(p + n, src, m * sizeof(T)); n += m; }
+};
 }  // namespace
 
-struct qf_ctx {
-  int device = 0;
+// One in-flight chunk of a batch: its streams, events, per-chunk device buffers and result staging.  The context is
+// itself slot 0 (every single-chunk path uses it); align batches run two slots from two host threads so that one
+// chunk's seeding and traceback (latency-bound) overlap the other's fill (VALU-bound).
+struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
-  std::string err, devname;
+  DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
+      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out;
+  HostBuf<AlignRec> h_recs;
+  HostBuf<uint32_t> h_runs;
+  std::string err;
+
+  int create() {
+    if (hipStreamCreate(&stream) != hipSuccess) return 1;
+    for (auto& e : ev) (void)hipEventCreate(&e);
+    for (auto& e : cls_ev) (void)hipEventCreate(&e);
+    for (auto& e : cls_end) (void)hipEventCreate(&e);
+    for (auto& s : aux) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    return 0;
+  }
+  void destroy() {
+    for (DevBuf* b : {&d_units, &d_cls_list, &d_pair_head, &d_pair_bands, &d_pair_nbands, &d_ovf, &d_pair_ndiag, &d_pair_cells,
+                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out})
+      b->release();
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : cls_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : cls_end) if (e) (void)hipEventDestroy(e);
+    for (auto& s : aux) if (s) (void)hipStreamDestroy(s);
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+  }
+};
+
+struct qf_ctx : Slot {
+  int device = 0;
+  Slot second;             // created on first use
+  bool second_ready = false;
+  uint32_t pipeline_chunks = 0;  // 0 = automatic
+  std::string devname;
   // model
   Params params;
   Scores scores;
@@ -72,19 +148,17 @@ struct qf_ctx {
   bool reads_have_qual = false;
   DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll;
   // batch state
-  DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score, d_pair_end_unit, d_bc, d_tb,
-      d_recs, d_runs_tmp, d_runs_out, d_cover, d_lse, d_fw, d_weight, d_fwd_out, d_counts, d_order_in, d_order_n_in,
+  DevBuf d_cover, d_lse, d_fw, d_weight, d_fwd_out, d_counts, d_order_in, d_order_n_in,
       d_order_out, d_order_n_out, d_rll, d_skip, d_ctxc, d_ins_sum, d_ins_sum_c, d_nll_c, d_rbucket, d_rcursor, d_rpos,
       d_px, d_py, d_pc, d_mmi0, d_mmi1, d_gap0, d_gap1, d_pair_result, d_pair_ij, d_skmer64, d_skeys, d_keys_tmp, d_vals_tmp,
       d_off32, d_rskeys, d_roff32;
   void* sort_temp = nullptr;
   size_t sort_temp_cap = 0;
   // host results
-  std::vector<double> h_viterbi, h_nll;
-  std::vector<uint64_t> h_cells;
-  std::vector<uint32_t> h_ndiag, h_runs;
+  HostBuf<double> h_viterbi, h_nll;
+  HostBuf<uint64_t> h_cells;
+  HostBuf<uint32_t> h_ndiag;
   std::vector<qf_alignment> h_align;
-  std::vector<AlignRec> h_recs;
   std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
@@ -104,7 +178,7 @@ struct qf_ctx {
     }                                                                                           \
   } while (0)
 
-static int fail(qf_ctx* c, int code, const std::string& msg) {
+static int fail(Slot* c, int code, const std::string& msg) {
   c->err = msg;
   return code;
 }
@@ -130,17 +204,14 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   }
   qf_ctx* c = new qf_ctx();
   c->device = device_id;
+  if (const char* e = getenv("QUAFF_HIP_CHUNKS")) c->pipeline_chunks = (uint32_t)atoi(e);  // tuning aid; 0 = automatic
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-  if ((e = hipStreamCreate(&c->stream)) != hipSuccess) {
-    g_create_error = hipGetErrorString(e);
+  if (c->create()) {
+    g_create_error = "hipStreamCreate failed";
     delete c;
     return QF_ERR_DEVICE;
   }
-  for (auto& ev : c->ev) (void)hipEventCreate(&ev);
-  for (auto& ev : c->cls_ev) (void)hipEventCreate(&ev);
-  for (auto& ev : c->cls_end) (void)hipEventCreate(&ev);
-  for (auto& s : c->aux) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   *out = c;
   return QF_OK;
 }
@@ -151,9 +222,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_units, &c->d_cls_list,
-                    &c->d_pair_head, &c->d_pair_bands, &c->d_pair_nbands, &c->d_ovf, &c->d_pair_ndiag, &c->d_pair_cells, &c->d_pair_score, &c->d_pair_end_unit,
-                    &c->d_bc, &c->d_tb, &c->d_recs, &c->d_runs_tmp, &c->d_runs_out, &c->d_cover, &c->d_lse, &c->d_fw,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_fw,
                     &c->d_weight, &c->d_fwd_out, &c->d_counts, &c->d_order_in, &c->d_order_n_in, &c->d_order_out,
                     &c->d_order_n_out, &c->d_rll, &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
@@ -161,11 +230,11 @@ void qf_ctx_destroy(qf_ctx* c) {
                     &c->d_vals_tmp, &c->d_off32, &c->d_rskeys, &c->d_roff32})
     b->release();
   if (c->sort_temp) (void)hipFree(c->sort_temp);
-  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-  for (auto& ev : c->cls_ev) if (ev) (void)hipEventDestroy(ev);
-  for (auto& ev : c->cls_end) if (ev) (void)hipEventDestroy(ev);
-  for (auto& s : c->aux) if (s) (void)hipStreamDestroy(s);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->second_ready) {
+    (void)hipStreamSynchronize(c->second.stream);
+    c->second.destroy();
+  }
+  c->destroy();
   delete c;
 }
 
@@ -314,7 +383,7 @@ int qf_get_lse_table(const qf_ctx*, const double** table, int* n) {
 }
 
 // ------------------------------------------------------------------------------ sequences
-static int read_counters(qf_ctx* c, BatchCounters& bc) {
+static int read_counters(Slot* c, BatchCounters& bc) {
   HIPCHK(c, hipMemcpyAsync(&bc, c->d_bc.p, sizeof bc, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return QF_OK;
@@ -481,7 +550,7 @@ static int check_cfg(qf_ctx* c, const qf_dp_config* cfg) {
   return QF_OK;
 }
 
-static void fill_seed_args(qf_ctx* c, const qf_dp_config* cfg, SeedArgs& s, uint32_t max_units, int max_nd) {
+static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs& s, uint32_t max_units, int max_nd) {
   s = SeedArgs{};
   s.n_refs = c->n_refs;
   s.ref_off = c->d_ref_off.as<uint64_t>();
@@ -500,21 +569,22 @@ static void fill_seed_args(qf_ctx* c, const qf_dp_config* cfg, SeedArgs& s, uint
   s.cell_size = 24;  // QuaffDPMatrixContainer::cellSize(), src/qmodel.h:384 (align / overlap)
   s.max_size = cfg->max_size;
   s.max_nd = max_nd;
-  s.units = c->d_units.as<Unit>();
+  s.units = S.d_units.as<Unit>();
   s.max_units = max_units;
-  s.cls_list = c->d_cls_list.as<uint32_t>();
-  s.pair_head = c->d_pair_head.as<uint32_t>();
-  s.pair_bands = c->d_pair_bands.as<int2>();
-  s.pair_nbands = c->d_pair_nbands.as<uint32_t>();
-  s.ovf_bands = c->d_ovf.as<int4>();
+  s.cls_list = S.d_cls_list.as<uint32_t>();
+  s.pair_head = S.d_pair_head.as<uint32_t>();
+  s.pair_bands = S.d_pair_bands.as<int2>();
+  s.pair_nbands = S.d_pair_nbands.as<uint32_t>();
+  s.ovf_bands = S.d_ovf.as<int4>();
   s.ovf_cap = max_units;
-  s.pair_ndiag = c->d_pair_ndiag.as<uint32_t>();
-  s.pair_cells = c->d_pair_cells.as<unsigned long long>();
+  s.pair_ndiag = S.d_pair_ndiag.as<uint32_t>();
+  s.pair_cells = S.d_pair_cells.as<unsigned long long>();
   s.force_block_kernel = cfg->reserved & 1;  // debug/testing: workgroup-per-pair seeding kernel
-  s.bc = c->d_bc.as<BatchCounters>();
+  s.bc = S.d_bc.as<BatchCounters>();
 }
 
-static int reserve_pair_buffers(qf_ctx* c, uint64_t n_pairs, uint32_t max_units) {
+static int reserve_pair_buffers(Slot* c, uint64_t n_pairs, uint32_t max_units) {
+  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
   HIPCHK(c, c->d_units.reserve((size_t)max_units * sizeof(Unit)));
   HIPCHK(c, c->d_cls_list.reserve((size_t)kNumClasses * max_units * 4));
   HIPCHK(c, c->d_pair_head.reserve(n_pairs * 4));
@@ -536,62 +606,62 @@ static int reserve_pair_buffers(qf_ctx* c, uint64_t n_pairs, uint32_t max_units)
 // Reads [lo, hi) of the resident set against every reference.  Results go to the context's host arrays at the chunk's
 // offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
 // *too_big is set (the caller splits the range).
-static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi, qf_align_result* out,
-                       bool* too_big) {
+static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
+                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool* too_big) {
   *too_big = false;
   const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
   const uint32_t n_pairs = n_reads * n_refs;
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
   const uint32_t max_units = n_pairs * 4 + 1024;
-  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  if (int rc = reserve_pair_buffers(S, n_pairs, max_units)) return rc;
   const uint64_t* d_roff = c->d_roff.as<uint64_t>() + lo;   // the chunk's reads: offsets stay absolute, indices local
   const double* d_nll = c->d_nll.as<double>() + lo;
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(S, hipEventRecord(S->ev[1], S->stream));
 
   // ---- seeding
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
-  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  fill_seed_args(c, *S, cfg, sa, max_units, sparse ? max_nd : 2);
   sa.read_off = d_roff;
-  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
-    return fail(c, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
+  if (launch_seed(sa, n_pairs, mem, S->stream) != 0)
+    return fail(S, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
                                            " exceeds the LDS diagonal histogram (global-memory histogram not built yet)");
-  launch_bin_units(sa, n_pairs, 0, c->stream);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  launch_bin_units(sa, n_pairs, 0, S->stream);
+  HIPCHK(S, hipGetLastError());
+  HIPCHK(S, hipEventRecord(S->ev[2], S->stream));
   BatchCounters bc;
-  if (int rc = read_counters(c, bc)) return rc;
+  if (int rc = read_counters(S, bc)) return rc;
   if (bc.n_ovf && !(bc.error & 8u)) {  // pairs with more than kMaxBandsPerPair bands: second binning pass
-    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    if (int rc = read_counters(c, bc)) return rc;
+    launch_bin_units(sa, n_pairs, bc.n_ovf, S->stream);
+    HIPCHK(S, hipGetLastError());
+    HIPCHK(S, hipEventRecord(S->ev[2], S->stream));
+    if (int rc = read_counters(S, bc)) return rc;
   }
-  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
-  if (bc.error & 2u) return fail(c, QF_ERR_UNSUPPORTED, "unsupported band of " + std::to_string(bc.error_detail) + " diagonals");
+  if (bc.error & 4u) return fail(S, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  if (bc.error & 2u) return fail(S, QF_ERR_UNSUPPORTED, "unsupported band of " + std::to_string(bc.error_detail) + " diagonals");
   if (bc.error & 8u)
-    return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
-  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
+    return fail(S, QF_ERR_MEMORY, "band overflow list exhausted");
+  if (bc.error & 1u) return fail(S, QF_ERR_MEMORY, "unit table overflow");
 
   // ---- fill
   const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
-  if (tb_bytes > c->tb_budget) {
-    if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "one read needs " + std::to_string(tb_bytes >> 20) + " MiB of traceback, over the memory budget");
+  if (tb_bytes > budget) {
+    if (n_reads == 1) return fail(S, QF_ERR_MEMORY, "one read needs " + std::to_string(tb_bytes >> 20) + " MiB of traceback, over the memory budget");
     *too_big = true;
     return QF_OK;
   }
-  HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
+  HIPCHK(S, S->d_tb.reserve(tb_bytes + 64));
   FillArgs fa{};
   fa.n_refs = n_refs;
-  fa.units = c->d_units.as<Unit>();
+  fa.units = S->d_units.as<Unit>();
   fa.ref_off = c->d_ref_off.as<uint64_t>();
   fa.ref_woff = c->d_ref_woff.as<uint64_t>();
   fa.ref_tok = c->d_ref_tok.as<uint8_t>();
   fa.ref_packed = c->d_ref_packed.as<uint32_t>();
   fa.read_off = d_roff;
   fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
-  fa.tb = c->d_tb.as<uint32_t>();
+  fa.tb = S->d_tb.as<uint32_t>();
   const Scores& sc = c->scores;
   fa.dp.ematch = c->d_ematch.as<double>();
   fa.dp.ematch_ninf_off = (uint32_t)((size_t)c->scores.Km * kNQ1 * 4 * 8);
@@ -615,18 +685,18 @@ static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint3
     const bool concurrent = !(cfg->reserved & 4);
     for (int k = 0; k < n_used; ++k) {
       const int cls = order[k], lane = concurrent ? k % 4 : 0;
-      hipStream_t s = lane == 0 ? c->stream : c->aux[lane - 1];
-      HIPCHK(c, hipEventRecord(c->cls_ev[cls], s));
+      hipStream_t s = lane == 0 ? S->stream : S->aux[lane - 1];
+      HIPCHK(S, hipEventRecord(S->cls_ev[cls], s));
       fa.n_cls_units = bc.cls_count[cls];
-      fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+      fa.cls_list = S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
       launch_viterbi_fill(cls, fa, sc.Kg > 1, s);
-      HIPCHK(c, hipEventRecord(c->cls_end[cls], s));
-      if (lane) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[cls], 0));
+      HIPCHK(S, hipEventRecord(S->cls_end[cls], s));
+      if (lane) HIPCHK(S, hipStreamWaitEvent(S->stream, S->cls_end[cls], 0));
     }
   }
   const BatchCounters seed_bc = bc;
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(S, hipGetLastError());
+  HIPCHK(S, hipEventRecord(S->ev[3], S->stream));
 
   // ---- pair results, selection, traceback
   FinalArgs fin{};
@@ -634,67 +704,69 @@ static int align_chunk(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, uint3
   fin.n_reads = n_reads;
   fin.n_refs = n_refs;
   fin.all = (flags & QF_ALIGN_ALL) != 0;
-  fin.units = c->d_units.as<Unit>();
-  fin.pair_head = c->d_pair_head.as<uint32_t>();
-  fin.pair_score = c->d_pair_score.as<double>();
-  fin.pair_end_unit = c->d_pair_end_unit.as<uint32_t>();
+  fin.units = S->d_units.as<Unit>();
+  fin.pair_head = S->d_pair_head.as<uint32_t>();
+  fin.pair_score = S->d_pair_score.as<double>();
+  fin.pair_end_unit = S->d_pair_end_unit.as<uint32_t>();
   fin.nll = d_nll;
   fin.read_off = d_roff;
   fin.ref_off = c->d_ref_off.as<uint64_t>();
-  fin.tb = c->d_tb.as<uint32_t>();
-  fin.bc = c->d_bc.as<BatchCounters>();
-  launch_finalize(fin, c->stream);
+  fin.tb = S->d_tb.as<uint32_t>();
+  fin.bc = S->d_bc.as<BatchCounters>();
+  launch_finalize(fin, S->stream);
   uint32_t n_recs = 0;
   uint64_t total_runs = 0;
   if (!(flags & QF_ALIGN_NO_TRACEBACK)) {
     const size_t max_recs = fin.all ? n_pairs : n_reads;
-    HIPCHK(c, c->d_recs.reserve(max_recs * sizeof(AlignRec)));
-    fin.recs = c->d_recs.as<AlignRec>();
-    launch_select(fin, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (int rc = read_counters(c, bc)) return rc;
+    HIPCHK(S, S->d_recs.reserve(max_recs * sizeof(AlignRec)));
+    fin.recs = S->d_recs.as<AlignRec>();
+    launch_select(fin, S->stream);
+    HIPCHK(S, hipGetLastError());
+    if (int rc = read_counters(S, bc)) return rc;
     n_recs = bc.n_align;
-    HIPCHK(c, c->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
-    HIPCHK(c, c->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
+    HIPCHK(S, S->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
+    HIPCHK(S, S->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
     fin.n_recs = n_recs;
-    fin.runs_tmp = c->d_runs_tmp.as<uint32_t>();
-    fin.runs_out = c->d_runs_out.as<uint32_t>();
-    launch_traceback(fin, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (int rc = read_counters(c, bc)) return rc;
+    fin.runs_tmp = S->d_runs_tmp.as<uint32_t>();
+    fin.runs_out = S->d_runs_out.as<uint32_t>();
+    launch_traceback(fin, S->stream);
+    HIPCHK(S, hipGetLastError());
+    if (int rc = read_counters(S, bc)) return rc;
     total_runs = bc.total_runs_out;
   }
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(S, hipEventRecord(S->ev[4], S->stream));
 
   // ---- results to the host, at the chunk's offsets
-  const size_t p0 = (size_t)lo * n_refs, recs0 = c->h_recs.size(), runs0 = c->h_runs.size();
-  c->h_recs.resize(recs0 + n_recs);
-  c->h_runs.resize(runs0 + total_runs);
-  HIPCHK(c, hipMemcpyAsync(c->h_viterbi.data() + p0, c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + p0, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data() + p0, c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-  if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data() + recs0, c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
-  if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data() + runs0, c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t p0 = (size_t)lo * n_refs, recs0 = S->h_recs.size(), runs0 = S->h_runs.size();
+  S->h_recs.resize(recs0 + n_recs);
+  S->h_runs.resize(runs0 + total_runs);
+  HIPCHK(S, hipMemcpyAsync(c->h_viterbi.data() + p0, S->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_cells.data() + p0, S->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_ndiag.data() + p0, S->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, S->stream));
+  if (n_recs) HIPCHK(S, hipMemcpyAsync(S->h_recs.data() + recs0, S->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, S->stream));
+  if (total_runs) HIPCHK(S, hipMemcpyAsync(S->h_runs.data() + runs0, S->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipEventRecord(S->ev[5], S->stream));
+  HIPCHK(S, hipStreamSynchronize(S->stream));
   for (size_t a = recs0; a < recs0 + n_recs; ++a) {
-    c->h_recs[a].read += lo;
-    c->h_recs[a].run_off += runs0;
+    S->h_recs[a].read += lo;
+    S->h_recs[a].run_off += runs0;
   }
-  out->total_cells += seed_bc.total_cells;
-  out->n_units += seed_bc.n_units;
-  out->traceback_bytes += tb_bytes;
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); out->ms_seed += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); out->ms_fill += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_traceback += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
-  for (int cls = 0; cls < kNumClasses; ++cls) {
-    ms = 0;
-    if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&ms, c->cls_ev[cls], c->cls_end[cls]);
-    out->ms_fill_class[cls] += ms;
-    out->cells_class[cls] += seed_bc.cls_cells[cls];
-    out->units_class[cls] += seed_bc.cls_count[cls];
+  {
+    std::lock_guard<std::mutex> lk(out_mu);
+    out->total_cells += seed_bc.total_cells;
+    out->n_units += seed_bc.n_units;
+    out->traceback_bytes += tb_bytes;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, S->ev[1], S->ev[2]); out->ms_seed += ms;
+    (void)hipEventElapsedTime(&ms, S->ev[2], S->ev[3]); out->ms_fill += ms;
+    (void)hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); out->ms_traceback += ms;
+    for (int cls = 0; cls < kNumClasses; ++cls) {
+      ms = 0;
+      if (seed_bc.cls_count[cls]) (void)hipEventElapsedTime(&ms, S->cls_ev[cls], S->cls_end[cls]);
+      out->ms_fill_class[cls] += ms;
+      out->cells_class[cls] += seed_bc.cls_cells[cls];
+      out->units_class[cls] += seed_bc.cls_count[cls];
+    }
   }
   return QF_OK;
 }
@@ -714,6 +786,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   if (!n_pairs) return QF_OK;
   const bool sparse = cfg->sparse != 0;
   if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
+  const auto t_begin = std::chrono::steady_clock::now();
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
   HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
@@ -733,34 +806,87 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
     if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
   }
   (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
-  out->ms_total = out->ms_prep;
-  // the whole batch at once when its traceback fits the memory budget, else halves (recursively)
-  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n_reads}};
-  while (!todo.empty()) {
-    const auto [lo, hi] = todo.back();
-    todo.pop_back();
-    bool too_big = false;
-    if (int rc = align_chunk(c, cfg, flags, lo, hi, out, &too_big)) return rc;
-    if (too_big) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      todo.push_back({mid, hi});
-      todo.push_back({lo, mid});
+  // Work list: the batch in `n_chunks` pieces (one when it is small); a piece whose traceback exceeds the memory budget
+  // is halved.  Two host threads, each with its own slot (stream, buffers), take pieces off the list, so the device
+  // always has one chunk's fill to run under the other's seeding / selection / traceback.
+  uint32_t n_chunks = c->pipeline_chunks ? c->pipeline_chunks : (n_pairs >= 65536 ? 4u : 1u);
+  if (cfg->reserved & 4) n_chunks = 1;
+  n_chunks = std::min(n_chunks, n_reads);
+  std::vector<std::pair<uint32_t, uint32_t>> todo;
+  for (uint32_t k = n_chunks; k-- > 0;)
+    todo.push_back({(uint32_t)((uint64_t)n_reads * k / n_chunks), (uint32_t)((uint64_t)n_reads * (k + 1) / n_chunks)});
+  std::mutex mu, out_mu;
+  int in_flight = 0, rc_all = QF_OK;
+  std::condition_variable cv;
+  auto worker = [&](Slot* S) {
+    (void)hipSetDevice(c->device);
+    for (;;) {
+      std::pair<uint32_t, uint32_t> job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !todo.empty() || in_flight == 0 || rc_all != QF_OK; });
+        if (rc_all != QF_OK || todo.empty()) return;
+        job = todo.back();
+        todo.pop_back();
+        ++in_flight;
+      }
+      bool too_big = false;
+      const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, n_chunks > 1 ? c->tb_budget / 2 : c->tb_budget, out,
+                                 out_mu, &too_big);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        --in_flight;
+        if (rc != QF_OK && rc_all == QF_OK) {
+          rc_all = rc;
+          if (S != static_cast<Slot*>(c)) c->err = S->err;
+        }
+        if (too_big) {
+          const uint32_t mid = job.first + (job.second - job.first) / 2;
+          todo.push_back({mid, job.second});
+          todo.push_back({job.first, mid});
+        }
+      }
+      cv.notify_all();
     }
+  };
+  c->second.h_recs.clear();
+  c->second.h_runs.clear();
+  if (n_chunks > 1) {
+    if (!c->second_ready) {
+      if (c->second.create()) return fail(c, QF_ERR_DEVICE, "cannot create the second stream");
+      c->second_ready = true;
+    }
+    std::thread t(worker, &c->second);
+    worker(c);
+    t.join();
+  } else {
+    worker(c);
   }
-  const uint32_t n_recs = (uint32_t)c->h_recs.size();
-  // order: by read; within a read by descending score, earlier reference first on ties (multiset order,
-  // src/qmodel.cpp:2773-2775)
-  std::vector<uint32_t> order(n_recs);
-  for (uint32_t a = 0; a < n_recs; ++a) order[a] = a;
-  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-    const AlignRec &p = c->h_recs[x], &q = c->h_recs[y];
-    if (p.read != q.read) return p.read < q.read;
-    if (p.score != q.score) return p.score > q.score;
-    return p.ref < q.ref;
-  });
+  if (rc_all != QF_OK) return rc_all;
+  // Output order: by read; within a read by descending score, earlier reference first on ties (the reference's multiset
+  // order, src/qmodel.cpp:2773-2775).  Records arrive in device order from two slots: bucket them by read (one pass),
+  // then order the few reads that have several (QF_ALIGN_ALL).
+  const size_t runs_first = c->h_runs.size();
+  c->h_runs.append(c->second.h_runs.data(), c->second.h_runs.size());
+  const uint32_t n_first = (uint32_t)c->h_recs.size(), n_recs = n_first + (uint32_t)c->second.h_recs.size();
+  auto rec_at = [&](uint32_t k) -> const AlignRec& { return k < n_first ? c->h_recs[k] : c->second.h_recs[k - n_first]; };
+  std::vector<uint32_t> start(n_reads + 1, 0), order(n_recs);
+  for (uint32_t k = 0; k < n_recs; ++k) ++start[rec_at(k).read + 1];
+  for (uint32_t r = 0; r < n_reads; ++r) start[r + 1] += start[r];
+  {
+    std::vector<uint32_t> cursor(start.begin(), start.end() - 1);
+    for (uint32_t k = 0; k < n_recs; ++k) order[cursor[rec_at(k).read]++] = k;
+  }
+  for (uint32_t r = 0; r < n_reads; ++r)
+    if (start[r + 1] - start[r] > 1)
+      std::sort(order.begin() + start[r], order.begin() + start[r + 1], [&](uint32_t x, uint32_t y) {
+        const AlignRec &p = rec_at(x), &q = rec_at(y);
+        if (p.score != q.score) return p.score > q.score;
+        return p.ref < q.ref;
+      });
   c->h_align.resize(n_recs);
   for (uint32_t a = 0; a < n_recs; ++a) {
-    const AlignRec& r = c->h_recs[order[a]];
+    const AlignRec& r = rec_at(order[a]);
     if (!r.ok) return fail(c, QF_ERR_DEVICE, "traceback did not reach the start state (read " + std::to_string(r.read) + ")");
     qf_alignment& o = c->h_align[a];
     o.read = r.read;
@@ -771,7 +897,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
     o.x_end = r.x_end;
     o.n_columns = r.n_columns;
     o.n_runs = r.n_runs;
-    o.run_offset = r.run_off;
+    o.run_offset = r.run_off + (order[a] >= n_first ? runs_first : 0);
   }
   out->viterbi = c->h_viterbi.data();
   out->cells = c->h_cells.data();
@@ -781,6 +907,13 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   out->alignments = c->h_align.data();
   out->cigar_runs = c->h_runs.data();
   out->n_fill_classes = kNumClasses;
+  out->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return QF_OK;
+}
+
+int qf_set_pipeline_chunks(qf_ctx* c, uint32_t n_chunks) {
+  if (!c) return QF_ERR_ARG;
+  c->pipeline_chunks = n_chunks;
   return QF_OK;
 }
 
@@ -822,7 +955,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   // ---- seeding (cellSize = 2 * 24 for counting, qmodel.cpp:2249; only matters in memory mode)
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
-  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  fill_seed_args(c, *c, cfg, sa, max_units, sparse ? max_nd : 2);
   sa.read_off = d_roff;
   sa.cell_size = 48;
   sa.storage_mode = 1;
@@ -1088,7 +1221,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
   const int max_nd = (int)(2 * c->read_maxlen - 1);
   SeedArgs sa;
-  fill_seed_args(c, cfg, sa, max_units, sparse ? max_nd : 2);
+  fill_seed_args(c, *c, cfg, sa, max_units, sparse ? max_nd : 2);
   sa.pair_x = c->d_px.as<uint32_t>() + lo;
   sa.pair_y = c->d_py.as<uint32_t>() + lo;
   sa.ref_off = c->d_roff.as<uint64_t>();
@@ -1365,7 +1498,7 @@ int64_t qf_envelope(qf_ctx* c, const qf_dp_config* cfg, uint32_t read, uint32_t 
   const int nd = xLen + yLen - 1;
   if (c->d_cover.reserve((size_t)nd + 16) != hipSuccess) return fail(c, QF_ERR_MEMORY, "out of device memory");
   SeedArgs sa;
-  fill_seed_args(c, cfg, sa, max_units, sparse ? (int)(c->ref_maxlen + c->read_maxlen - 1) : 2);
+  fill_seed_args(c, *c, cfg, sa, max_units, sparse ? (int)(c->ref_maxlen + c->read_maxlen - 1) : 2);
   sa.pair_base = read * c->n_refs + ref;
   sa.dump_cover = c->d_cover.as<uint8_t>();
   if (launch_seed(sa, 1, sparse && cfg->kmer_threshold < 0, c->stream) != 0) return fail(c, QF_ERR_UNSUPPORTED, "sequence too long for the LDS histogram");

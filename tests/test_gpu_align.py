@@ -299,6 +299,22 @@ def test_internal_chunking_matches_single_pass(ctx):
     for a, b in zip(whole["alignments"], parts["alignments"]):
         assert (a["read"], a["ref"], a["score"], a["xStart"], a["xEnd"], a["ops"]) == \
                (b["read"], b["ref"], b["score"], b["xStart"], b["xEnd"], b["ops"])
+    # pipelined pieces (two host threads, two streams) with and without a tight budget
+    try:
+        ctx.set_pipeline_chunks(5)
+        piped = ctx.align_resident(Q.DPConfig(), 1)
+        ctx.set_memory_budget(whole["traceback_bytes"] // 3)
+        piped2 = ctx.align_resident(Q.DPConfig(), 1)
+    finally:
+        ctx.set_memory_budget(0)
+        ctx.set_pipeline_chunks(0)
+    for other in (piped, piped2):
+        for key in ("viterbi", "cells", "n_diagonals", "null_loglike"):
+            assert np.array_equal(whole[key], other[key]), key
+        assert whole["total_cells"] == other["total_cells"] and len(other["alignments"]) == 74
+        for a, b in zip(whole["alignments"], other["alignments"]):
+            assert (a["read"], a["ref"], a["score"], a["xStart"], a["xEnd"], a["ops"]) == \
+                   (b["read"], b["ref"], b["score"], b["xStart"], b["xEnd"], b["ops"])
     # a budget below a single read's traceback is an error, not a silent truncation
     try:
         ctx.set_memory_budget(1024)
