@@ -123,7 +123,7 @@ int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
  * batches are processed in halves transparently. */
 int qf_set_memory_budget(qf_ctx *ctx, uint64_t bytes);
 /* qf_align_* cuts a batch into this many pieces and keeps two in flight (one piece's seeding and traceback overlap the
- * other's fill).  0 = automatic (4 for batches of 65536 pairs or more, else 1).  Results do not depend on it. */
+ * other's fill).  0 = default (1: the whole batch at once).  Results do not depend on it. */
 int qf_set_pipeline_chunks(qf_ctx *ctx, uint32_t n_chunks);
 
 /* ---- model ------------------------------------------------------------------------ */

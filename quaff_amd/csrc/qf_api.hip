@@ -607,7 +607,7 @@ static int reserve_pair_buffers(Slot* c, uint64_t n_pairs, uint32_t max_units) {
 // offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
 // *too_big is set (the caller splits the range).
 static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
-                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool* too_big) {
+                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, std::mutex* fill_token, bool* too_big) {
   *too_big = false;
   const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
   const uint32_t n_pairs = n_reads * n_refs;
@@ -678,13 +678,18 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   // One kernel per class, the class with the most cells first, spread over the main and the side streams: the small
   // classes (and the single-diagonal chains, which are latency-bound) fill the SIMDs the big class's last wavefronts
   // leave idle.  Everything was seeded on the main stream, which the host has already waited for.
+  // With two chunks in flight only one of them fills at a time: the token keeps the other on its seeding or traceback,
+  // which is what overlaps well with a fill (two fills side by side just share the VALUs).
+  std::unique_lock<std::mutex> token;
+  if (fill_token) token = std::unique_lock<std::mutex>(*fill_token);
   {
     int order[kNumClasses], n_used = 0;
     for (int cls = 0; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
     std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
     const bool concurrent = !(cfg->reserved & 4);
+    const int n_lanes = fill_token ? 2 : 4;  // two chunks in flight: one side stream each (hardware queues are few)
     for (int k = 0; k < n_used; ++k) {
-      const int cls = order[k], lane = concurrent ? k % 4 : 0;
+      const int cls = order[k], lane = concurrent ? (k < n_lanes ? k : 1 + (k - 1) % (n_lanes - 1)) : 0;
       hipStream_t s = lane == 0 ? S->stream : S->aux[lane - 1];
       HIPCHK(S, hipEventRecord(S->cls_ev[cls], s));
       fa.n_cls_units = bc.cls_count[cls];
@@ -723,6 +728,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     launch_select(fin, S->stream);
     HIPCHK(S, hipGetLastError());
     if (int rc = read_counters(S, bc)) return rc;
+    if (token.owns_lock()) token.unlock();  // the fill has drained
     n_recs = bc.n_align;
     HIPCHK(S, S->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
     HIPCHK(S, S->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
@@ -809,13 +815,15 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   // Work list: the batch in `n_chunks` pieces (one when it is small); a piece whose traceback exceeds the memory budget
   // is halved.  Two host threads, each with its own slot (stream, buffers), take pieces off the list, so the device
   // always has one chunk's fill to run under the other's seeding / selection / traceback.
-  uint32_t n_chunks = c->pipeline_chunks ? c->pipeline_chunks : (n_pairs >= 65536 ? 4u : 1u);
+  // Measured on config 2 (MI355X): the overlap gained is paid back by the smaller grids, so the default is one piece;
+  // pieces bound the peak traceback memory (two in flight) and overlap the result copies with compute.
+  uint32_t n_chunks = c->pipeline_chunks ? c->pipeline_chunks : 1u;
   if (cfg->reserved & 4) n_chunks = 1;
   n_chunks = std::min(n_chunks, n_reads);
   std::vector<std::pair<uint32_t, uint32_t>> todo;
   for (uint32_t k = n_chunks; k-- > 0;)
     todo.push_back({(uint32_t)((uint64_t)n_reads * k / n_chunks), (uint32_t)((uint64_t)n_reads * (k + 1) / n_chunks)});
-  std::mutex mu, out_mu;
+  std::mutex mu, out_mu, fill_mu;
   int in_flight = 0, rc_all = QF_OK;
   std::condition_variable cv;
   auto worker = [&](Slot* S) {
@@ -832,7 +840,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
       }
       bool too_big = false;
       const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, n_chunks > 1 ? c->tb_budget / 2 : c->tb_budget, out,
-                                 out_mu, &too_big);
+                                 out_mu, n_chunks > 1 ? &fill_mu : nullptr, &too_big);
       {
         std::lock_guard<std::mutex> lk(mu);
         --in_flight;

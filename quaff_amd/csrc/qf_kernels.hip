@@ -982,8 +982,16 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
         const int j = t - l + 1;
         const bool colvalid = active && j >= 1 && j <= yLen;
         const uint32_t w = wN;
-        const double insE = insEN;
         double e[B];
+#if QF_EXP == 4   // A/B: fetch this step's emissions now instead of one step ahead
+        const double insE = eins[(w >> 15) & 0x1FFu];
+#pragma unroll
+        for (int b = 0; b < B; ++b) e[b] = emis(w, winN, b);
+        wN = s < 3 ? cw.v[s + 1] : cwn.v[0];
+        winN = (winN >> 2) | (((uint32_t)(xpair >> (sh0 + 2 * (s4 + s + 1))) & 3u) << (2 * (B - 1)));
+        (void)eN; (void)insEN;
+#else
+        const double insE = insEN;
 #pragma unroll
         for (int b = 0; b < B; ++b) e[b] = eN[b];
         // step t+1's fetch (the token of step 16 of a chunk is the next chunk's first: still inside the 64-bit window)
@@ -991,9 +999,6 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
         winN = (winN >> 2) | (((uint32_t)(xpair >> (sh0 + 2 * (s4 + s + 1))) & 3u) << (2 * (B - 1)));
         insEN = eins[(wN >> 15) & 0x1FFu];
 #pragma unroll
-#if QF_EXP == 2
-        for (int b = 0; b < B; ++b) eN[b] = insEN;
-#else
         for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b);
 #endif
         const uint32_t gk = w >> 24;
