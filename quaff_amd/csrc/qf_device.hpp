@@ -85,6 +85,21 @@ __host__ __device__ inline uint64_t row_unit_words(int dlo, int dhi, int xLen, i
   }
   return w;
 }
+// Forward storage of a row-space unit, in doubles: [ (nStripes+1) u64 stripe offsets | 2 boundary rows x 3 states x
+// (yLen+2) | per stripe: steps x 8 rows x 3 states x 64 lanes ]
+__host__ __device__ inline uint64_t row_fw_header(const RowGeom& g, int yLen) {
+  return (uint64_t)(g.nStripes + 1) + 2ull * 3 * (uint64_t)(yLen + 2);
+}
+__host__ __device__ inline uint64_t row_fw_doubles(int dlo, int dhi, int xLen, int yLen) {
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  uint64_t w = row_fw_header(g, yLen);
+  for (int s = 0; s < g.nStripes; ++s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + 63) * 64 * 8 * 3;
+  }
+  return w;
+}
 // traceback words a unit occupies
 __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   if (cls == 0) return (yLen + 7) / 8;

@@ -377,6 +377,313 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Row-space Forward / Backward for bands wider than the diagonal-space kernels take (-kmatchoff, or the full-envelope
+// fallback of a short read against a long reference).  Geometry of k_viterbi_rows (qf_kernels.hip): one wavefront per
+// unit, stripes of 64 lanes x 8 rows, lane l one column behind lane l-1 (Forward) or lane l+1 (Backward), the stripe's
+// edge row handed to the next stripe through a boundary buffer.  Forward cell (i,j) of stripe s is stored at
+//   stripe_off[s] + (((j - jlo + l) * 8 + b) * 3 + state) * 64 + l          (l = lane, b = row slot)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_forward_rows(FbArgs a) {
+  constexpr int G = 64, B = 8, S = kRowStripe;
+  const uint32_t uidx = blockIdx.x;
+  if (uidx >= a.n_cls_units) return;
+  const int l = threadIdx.x;
+  const uint32_t uid = a.cls_list[uidx];
+  const Unit u = a.units[uid];
+  const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+  const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
+  const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
+  const int dlo = u.dlo, dhi = u.dhi;
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  double* base = a.fw + u.tb_off;
+  unsigned long long* stripe_off = (unsigned long long*)base;
+  double* bnd = base + (g.nStripes + 1);
+  double* cells = base + row_fw_header(g, yLen);
+  const size_t bndStride = 3ull * (yLen + 2);
+  if (l == 0) {
+    unsigned long long w = 0;
+    for (int s = 0; s < g.nStripes; ++s) {
+      int jlo, jhi;
+      row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+      stripe_off[s] = w;
+      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + 63) * 64 * B * 3;
+    }
+    stripe_off[g.nStripes] = w;
+  }
+  for (size_t c = l; c < bndStride; c += 64) bnd[c] = QF_NEG_INF;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const double* __restrict__ tab = a.lse;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  double endv = QF_NEG_INF;   // lse over rows, ascending (src/qmodel.cpp:1379-1381)
+  unsigned long long woff = 0;
+
+  for (int s = 0; s < g.nStripes; ++s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    const int i0 = g.ilo + s * S + l * B;
+    const double* __restrict__ bprev = bnd + (size_t)(s & 1) * bndStride;
+    double* __restrict__ bnext = bnd + (size_t)((s + 1) & 1) * bndStride;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
+    if (jhi < jlo) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      continue;
+    }
+    uint32_t tk[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) tk[b] = (i0 + b >= 1 && i0 + b <= xLen) ? xt[i0 + b - 1] : 0u;
+    double M[B], I[B], D[B], endTerm[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) { M[b] = I[b] = D[b] = QF_NEG_INF; endTerm[b] = QF_NEG_INF; }
+    double p1M = QF_NEG_INF, p1I = QF_NEG_INF, p1D = QF_NEG_INF, p2M = QF_NEG_INF, p2I = QF_NEG_INF, p2D = QF_NEG_INF;
+    const int steps = jhi - jlo + 1 + G - 1;
+    for (int t = 0; t < steps; ++t) {
+      const int j = jlo + t - l;
+      const bool colvalid = j >= jlo && j <= jhi;
+      const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+      const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
+      const uint32_t gp = j > 1 ? (ctx[min(j - 2, yLen + 4)] >> 24) : 0u;
+      const double m2m = trans[gp], m2i = trans[Kg + gp], m2d = trans[2 * Kg + gk];
+      const double insE = eins[insrow];
+      double upM = __shfl_up(p1M, 1, G), upD = __shfl_up(p1D, 1, G);
+      double dgM = __shfl_up(p2M, 1, G), dgI = __shfl_up(p2I, 1, G), dgD = __shfl_up(p2D, 1, G);
+      if (l == 0) {
+        const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
+        upM = bprev[jc]; upD = bprev[2 * (yLen + 2) + jc];
+        dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
+      }
+      double aboveM = upM, aboveD = upD;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int i = i0 + b, dgl = i - j;
+        const bool valid = colvalid && i >= 1 && i <= xLen && dgl >= dlo && dgl <= dhi;
+        const double e = ematch[erow4 + tk[b]];
+        const double oM = M[b], oI = I[b], oD = D[b];   // (i, j-1)
+        double nm = lse2(tab, lse2(tab, dgM + m2m, dgD + d2m), dgI + i2m);
+        if (j == 1 && (i == 1 || local)) nm = lse2(tab, nm, 0.0);
+        nm += e;
+        double ni = insE + lse2(tab, oI + i2i, oM + m2i);
+        double ndl = lse2(tab, aboveD + d2d, aboveM + m2d);
+        if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+        M[b] = nm; I[b] = ni; D[b] = ndl;
+        dgM = oM; dgI = oI; dgD = oD;
+        aboveM = nm; aboveD = ndl;
+        if (colvalid) {
+          const unsigned long long at = woff + (((unsigned long long)t * B + b) * 3) * G + l;
+          cells[at] = nm; cells[at + G] = ni; cells[at + 2 * G] = ndl;
+        }
+        if (j == yLen && valid && (local || i == xLen)) endTerm[b] = nm + trans[3 * Kg + gk];
+      }
+      p2M = p1M; p2I = p1I; p2D = p1D;
+      p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
+      if (colvalid && l == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
+    }
+    woff += (unsigned long long)steps * G * B * 3;
+    for (int q = 0; q < G; ++q) {   // this stripe's end terms, rows ascending
+      double v = endv;
+#pragma unroll
+      for (int b = 0; b < B; ++b) if (endTerm[b] > QF_NEG_INF) v = lse2(tab, v, endTerm[b]);
+      endv = __shfl(l == q ? v : endv, q, G);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  if (l == 0) a.units[uid].end_val = endv;
+}
+
+// Backward over a row-space unit: stripes bottom-up, columns right-to-left, lane l one column behind lane l+1; the
+// arithmetic, association order and count bookkeeping of k_backward_fill.
+__global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
+  constexpr int G = 64, B = 8, S = kRowStripe, RING = 2 * G;
+  __shared__ double ring[RING][8];
+  const uint32_t uidx = blockIdx.x;
+  if (uidx >= a.n_cls_units) return;
+  const int l = threadIdx.x, rl = G - 1 - l;
+  const uint32_t uid = a.cls_list[uidx];
+  const Unit u = a.units[uid];
+  const double Fres = a.pair_fwd[u.pair], wgt = a.pair_weight[u.pair];
+  if (!(wgt > 0.0) || !(Fres > QF_NEG_INF)) return;   // pruned pair (qmodel.cpp:2252)
+  const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+  const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
+  const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
+  const int dlo = u.dlo, dhi = u.dhi;
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  double* base = a.fw + u.tb_off;
+  const unsigned long long* stripe_off = (const unsigned long long*)base;
+  double* bnd = base + (g.nStripes + 1);            // reused: [2][2][yLen+2] Backward mat / del of a stripe's first row
+  const double* __restrict__ cells = base + row_fw_header(g, yLen);
+  const size_t bndStride = 2ull * (yLen + 2);
+  for (int c = l; c < RING * 8; c += 64) (&ring[0][0])[c] = 0.0;
+  for (size_t c = l; c < 2 * bndStride; c += 64) bnd[c] = QF_NEG_INF;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+  __builtin_amdgcn_wave_barrier();
+
+  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ trans = a.dp.trans;
+  const double* __restrict__ tab = a.lse;
+  const uint32_t Kg = a.dp.Kg, Km = a.Km;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  double* __restrict__ cnt = a.counts;
+  const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
+  double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
+  const uint32_t gkEnd = ctx[yLen - 1] >> 24;
+
+  for (int s = g.nStripes - 1; s >= 0; --s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    const int i0 = g.ilo + s * S + l * B;
+    const int par = (g.nStripes - 1 - s) & 1;
+    const double* __restrict__ bprev = bnd + (size_t)par * bndStride;          // first row of the stripe below
+    double* __restrict__ bnext = bnd + (size_t)(par ^ 1) * bndStride;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
+    if (jhi < jlo) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      continue;
+    }
+    const unsigned long long woff = stripe_off[s];
+    uint32_t tkN[B], tk0 = (i0 >= 1 && i0 <= xLen) ? xt[i0 - 1] : 0u;   // tokens of rows i+1; tk0: row i0 itself
+#pragma unroll
+    for (int b = 0; b < B; ++b) tkN[b] = (i0 + b >= 0 && i0 + b < xLen) ? xt[i0 + b] : 0u;
+    double Bm[B], Bi[B], Bd[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) Bm[b] = Bi[b] = Bd[b] = QF_NEG_INF;
+    double p1M = QF_NEG_INF, p1D = QF_NEG_INF, p2M = QF_NEG_INF;   // slot 0 after the previous / the one before
+    uint32_t wNext = 0;
+    const int steps = jhi - jlo + 1 + G - 1;
+    for (int t = 0; t < steps; ++t) {
+      const int j = jhi - (t - rl);
+      const bool colvalid = j >= jlo && j <= jhi;
+      const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+      const uint32_t gk = w >> 24;
+      const double m2m = trans[gk], m2i = trans[Kg + gk], m2d = trans[2 * Kg + gk];
+      const uint32_t erowN4 = (wNext & 0x7FFFu) * 4u;
+      const double insEN = eins[(wNext >> 15) & 0x1FFu];
+      // row below the last slot: lane l+1's first row (column j one step ago, column j+1 two steps ago) or the boundary
+      double belowD = __shfl_down(p1D, 1, G), dgM = __shfl_down(p2M, 1, G);
+      if (l == G - 1) {
+        const int jc = min(max(j, 0), yLen + 1), jn = min(max(j + 1, 0), yLen + 1);
+        belowD = bprev[(yLen + 2) + jc];
+        dgM = bprev[jn];
+      }
+      double pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int b = B - 1; b >= 0; --b) {
+        const int i = i0 + b, dgl = i - j;
+        const bool valid = colvalid && i >= 1 && i <= xLen && dgl >= dlo && dgl <= dhi;
+        const double eN = ematch[erowN4 + tkN[b]];
+        const double oM = Bm[b];            // Bm(i, j+1): the diagonal neighbour of row i-1
+        const double BmN = dgM;             // Bm(i+1, j+1)
+        const double BiN = Bi[b];           // Bi(i, j+1)
+        const double BdN = belowD;          // Bd(i+1, j)
+        const double T_mm = (m2m + eN) + BmN, T_im = (i2m + eN) + BmN, T_dm = (d2m + eN) + BmN;
+        const double T_mi = (m2i + insEN) + BiN, T_ii = (i2i + insEN) + BiN;
+        const double T_md = m2d + BdN, T_dd = d2d + BdN;
+        const bool isEnd = j == yLen && (local || i == xLen);
+        const double T_me = isEnd ? trans[3 * Kg + gk] : QF_NEG_INF;
+        double nbm = lse2(tab, lse2(tab, T_mm, T_mi), T_md);
+        if (isEnd) nbm = lse2(tab, nbm, T_me);
+        double nbi = lse2(tab, T_im, T_ii);
+        double nbd = lse2(tab, T_dm, T_dd);
+        if (!valid) { nbm = QF_NEG_INF; nbi = QF_NEG_INF; nbd = QF_NEG_INF; }
+        if (valid) {
+          const unsigned long long at = woff + (((unsigned long long)(j - jlo + l) * B + b) * 3) * G + l;
+          const double Fm = cells[at] - Fres, Fi = cells[at + G] - Fres, Fd = cells[at + 2 * G] - Fres;
+          const double c_mm = wgt * exp(Fm + T_mm), c_im = wgt * exp(Fi + T_im), c_dm = wgt * exp(Fd + T_dm);
+          const double c_mi = wgt * exp(Fm + T_mi), c_ii = wgt * exp(Fi + T_ii);
+          const double c_md = wgt * exp(Fm + T_md), c_dd = wgt * exp(Fd + T_dd);
+          const double cmat = c_mm + c_im + c_dm;
+          const uint32_t tokN = tkN[b];
+          pc[0] += tokN == 0 ? cmat : 0.0; pc[1] += tokN == 1 ? cmat : 0.0;
+          pc[2] += tokN == 2 ? cmat : 0.0; pc[3] += tokN == 3 ? cmat : 0.0;
+          pc[4] += c_mi + c_ii;
+          pc[5] += c_mm; pc[6] += c_mi; pc[7] += c_md;
+          acc_i2m += c_im; acc_d2m += c_dm; acc_i2i += c_ii; acc_d2d += c_dd;
+          if (isEnd) acc_m2e += wgt * exp(Fm + T_me);
+          if (j == 1 && (i == 1 || local)) {
+            const uint32_t tok = b > 0 ? tkN[b - 1] : tk0;
+            const double Sv = ematch[(w & 0x7FFFu) * 4u + tok] + nbm;
+            const double cs = wgt * exp(Sv - Fres);
+            pc0[0] += tok == 0 ? cs : 0.0; pc0[1] += tok == 1 ? cs : 0.0;
+            pc0[2] += tok == 2 ? cs : 0.0; pc0[3] += tok == 3 ? cs : 0.0;
+            startv = lse2(tab, startv, Sv);
+          }
+        }
+        Bm[b] = nbm; Bi[b] = nbi; Bd[b] = nbd;
+        dgM = oM;
+        belowD = nbd;
+      }
+      p2M = p1M;
+      p1M = Bm[0]; p1D = Bd[0];
+      if (colvalid && l == 0) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1D; }
+      if (colvalid) {
+        double* slot = ring[j & (RING - 1)];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+        if (j == 1) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) if (pc0[c] != 0.0) unsafeAtomicAdd(&ring[0][c], pc0[c]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (colvalid && l == 0) {  // lane 0 is the last of the stripe to process column j
+        for (int jj = j; jj >= (j == 1 ? 0 : j); --jj) {
+          double* slot = ring[jj & (RING - 1)];
+          const uint32_t wd = ctx[jj];
+          const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+          const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
+          if (jj < yLen && q < (uint32_t)kNQualDev) {
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+              if (slot[tk] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)tk * Km + mk) * kNQualDev + q], slot[tk]);
+            if (slot[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], slot[4]);
+          }
+          if (jj >= 1) {
+            const uint32_t gs = ctx[jj - 1] >> 24;
+            if (slot[5] != 0.0) unsafeAtomicAdd(&cnt[cTr + gs], slot[5]);
+            if (slot[6] != 0.0) unsafeAtomicAdd(&cnt[cTr + Kg + gs], slot[6]);
+            if (slot[7] != 0.0) unsafeAtomicAdd(&cnt[cTr + 2 * Kg + gs], slot[7]);
+          }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) slot[c] = 0.0;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      wNext = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  for (int o = 1; o < G; o <<= 1) {
+    acc_i2m += __shfl_xor(acc_i2m, o, G); acc_d2m += __shfl_xor(acc_d2m, o, G);
+    acc_i2i += __shfl_xor(acc_i2i, o, G); acc_d2d += __shfl_xor(acc_d2d, o, G);
+    acc_m2e += __shfl_xor(acc_m2e, o, G);
+    startv = lse2(tab, startv, __shfl_xor(startv, o, G));
+  }
+  if (l == 0) {
+    if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], acc_m2e);
+    if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], acc_d2d);
+    if (acc_d2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 1], acc_d2m);
+    if (acc_i2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 2], acc_i2i);
+    if (acc_i2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 3], acc_i2m);
+    a.units[uid].end_val = startv;
+  }
+}
+
+
 template <int G, int B>
 static void launch_fwd_gb(const FbArgs& a, hipStream_t s) {
   const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
@@ -404,10 +711,12 @@ static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   }
 void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
+  if (cls == kRowClass) { hipLaunchKernelGGL(k_forward_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); return; }
   QF_FB_DISPATCH(launch_fwd_gb)
 }
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
+  if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); return; }
   QF_FB_DISPATCH(launch_bwd_gb)
 }
 void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s) {

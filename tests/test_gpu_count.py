@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.helpers import rand_seq, make_reads
+from tests.helpers import rand_seq, make_reads, rand_qual
 from tests.test_gpu_align import NULL_JSON, DEFAULT_JSON, both_strands, synth_params_json
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +48,7 @@ def run_case(ctx, refs, reads, sc, null, cfg_kw=None, orders=None, force=False):
     ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
     res = ctx.count_resident(Q.DPConfig(**cfg_kw), force=force, sort_order=orders)
     ocfg = O.DPConfig(local=cfg_kw.get("local", True), kmer_threshold=cfg_kw.get("kmer_threshold", 20),
-                      band=cfg_kw.get("band_size", 64), kmer_len=cfg_kw.get("kmer_len", 6))
+                      band=cfg_kw.get("band_size", 64), kmer_len=cfg_kw.get("kmer_len", 6), sparse=cfg_kw.get("sparse", True))
     want, ylogs, new_orders = oracle_estep(refs, reads, sc, null, ocfg, orders, use_null=not force)
     np.testing.assert_allclose(res["read_loglike"], ylogs, rtol=RTOL)
     assert abs(res["loglike"] - ylogs.sum()) <= RTOL * abs(ylogs.sum())
@@ -148,3 +148,17 @@ def test_count_internal_chunking(ctx):
         assert w["sort_order"] == p["sort_order"] and w["loglike"] == p["loglike"]
         assert w["total_cells"] == p["total_cells"] and w["forward_bytes"] == p["forward_bytes"]
         np.testing.assert_allclose(p["counts"], w["counts"], rtol=1e-9, atol=1e-12)
+
+
+def test_count_wide_bands_row_space(ctx):
+    """Bands wider than 1024 diagonals (-kmatchoff, and the full-envelope fallback of reads shorter than 2(k+threshold))
+    run on the row-space Forward/Backward kernels: several 512-row stripes, both strands, local and global."""
+    rng = np.random.default_rng(36)
+    ref = rand_seq(rng, 1400)
+    sc, null = O.Scores(O.Params.from_json(DEFAULT_JSON)), O.NullParams.from_json(NULL_JSON)
+    reads = make_reads(rng, ref, 4, 240)
+    reads.append(O.FastSeq("short", ref[700:745], rand_qual(rng, 45)))     # 45 < 2 * (6 + 20): full envelope
+    res, _ = run_case(ctx, both_strands(ref), reads, sc, null, cfg_kw=dict(sparse=False))
+    assert res["total_cells"] == 2 * 1400 * sum(len(r.seq) for r in reads)
+    run_case(ctx, both_strands(ref), reads, sc, null)                       # mixed: narrow bands + one full envelope
+    run_case(ctx, [O.FastSeq("ref", ref)], reads[:2], sc, null, cfg_kw=dict(sparse=False, local=False), force=True)
