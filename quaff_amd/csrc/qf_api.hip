@@ -1251,7 +1251,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u)
-    return fail(c, QF_ERR_UNSUPPORTED, "overlap band of " + std::to_string(bc.error_detail) + " diagonals: the overlap kernels take up to 512 (no row-space overlap kernel yet)");
+    return fail(c, QF_ERR_UNSUPPORTED, "unsupported overlap band of " + std::to_string(bc.error_detail) + " diagonals");
   if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
   if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
 
@@ -1296,7 +1296,8 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
   oa.recs = c->d_recs.as<AlignRec>();
   oa.bc = c->d_bc.as<BatchCounters>();
-  for (int cls = 10; cls >= 0; --cls) {
+  for (int cls = kNumClasses - 1; cls >= 0; --cls) {
+    if (cls > 10 && cls != kRowClass) continue;
     oa.n_cls_units = bc.cls_count[cls];
     oa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
     launch_overlap_fill(cls, oa, c->stream);

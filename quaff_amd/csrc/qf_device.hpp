@@ -100,6 +100,18 @@ __host__ __device__ inline uint64_t row_fw_doubles(int dlo, int dhi, int xLen, i
   }
   return w;
 }
+// overlap traceback of a row-space unit, in 4-byte words: the Viterbi header, then per stripe steps x 64 lanes x 2 words
+// (one byte per cell, 8 rows per lane)
+__host__ __device__ inline uint64_t row_ov_words(int dlo, int dhi, int xLen, int yLen) {
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  uint64_t w = row_header_words(g, yLen);
+  for (int s = 0; s < g.nStripes; ++s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + 63) * 64 * 2;
+  }
+  return w;
+}
 // traceback words a unit occupies
 __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   if (cls == 0) return (yLen + 7) / 8;

@@ -592,8 +592,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
       const int xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]);
       yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
       cls = classify_width(dhi - dlo + 1);
-      if (cls == kRowClass && a.storage_mode == 2) cls = -1;  // overlap: no row-space kernel yet
-      if (a.storage_mode == 2 && cls > 10) cls = -1;           // overlap kernels take up to 8 diagonals per lane
+      if (a.storage_mode == 2 && cls > 10) cls = kRowClass;    // overlap kernels take up to 8 diagonals per lane
       if (cls < 0) {
         atomicOr(&a.bc->error, 2u);
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
@@ -603,6 +602,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
         tbw = a.storage_mode == 2 ? (cls == 0 ? (unsigned long long)(yLen + 7) / 8
+                                     : cls == kRowClass ? row_ov_words(dlo, dhi, xLen, yLen)
                                                : (unsigned long long)(yLen + fill_class(cls).G - 1) * fill_class(cls).G * 2)
               : a.storage_mode == 1 ? (cls == kRowClass ? row_fw_doubles(dlo, dhi, xLen, yLen) : unit_fw_doubles(cls, (uint32_t)yLen))
               : cls == kRowClass  ? row_unit_words(dlo, dhi, xLen, yLen)

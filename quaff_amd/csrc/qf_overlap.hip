@@ -301,6 +301,153 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
   }
 }
 
+
+// Row-space overlap Viterbi for bands wider than 512 diagonals (-kmatchoff, or a sequence shorter than 2(k+threshold):
+// full envelope).  Geometry of k_viterbi_rows (qf_kernels.hip): one wavefront per unit, stripes of 64 lanes x 8 rows,
+// lane l one column behind lane l-1, the stripe's last row handed on through a boundary buffer.  Arithmetic, candidate
+// order and traceback bytes of k_overlap_fill.
+__global__ __launch_bounds__(64) void k_overlap_rows(OvArgs a) {
+  constexpr int G = 64, B = 8, S = kRowStripe;
+  const uint32_t uidx = blockIdx.x;
+  if (uidx >= a.n_cls_units) return;
+  const int l = threadIdx.x;
+  const uint32_t uid = a.cls_list[uidx];
+  const Unit u = a.units[uid];
+  const uint32_t x = a.pair_x[u.pair], y = a.pair_y[u.pair], comp = a.pair_comp[u.pair];
+  const uint64_t xb = a.seq_off[x], yb = a.seq_off[y];
+  const int xLen = (int)(a.seq_off[x + 1] - xb), yLen = (int)(a.seq_off[y + 1] - yb);
+  const int dlo = u.dlo, dhi = u.dhi;
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  uint32_t* base = a.tb + u.tb_off;
+  unsigned long long* stripe_off = (unsigned long long*)base;
+  double* bnd = (double*)(base + 2ull * (g.nStripes + 1));
+  uint32_t* tbw = base + row_header_words(g, yLen);
+  const size_t bndStride = 3ull * (yLen + 2);
+  if (l == 0) {
+    unsigned long long w = 0;
+    for (int s = 0; s < g.nStripes; ++s) {
+      int jlo, jhi;
+      row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+      stripe_off[s] = w;
+      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + 63) * 64 * 2;
+    }
+    stripe_off[g.nStripes] = w;
+  }
+  for (size_t c = l; c < bndStride; c += 64) bnd[c] = QF_NEG_INF;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+
+  const double* __restrict__ mmi = a.mmi[comp];
+  const double* __restrict__ gap = a.gap[comp];
+  const double* __restrict__ tab = a.lse;
+  const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
+  const double* gsc = gap + 3ull * Kg * Kg;
+  const double i2mS = gsc[1], i2iS = gsc[0], i2dS = gsc[2], d2mS = gsc[4], d2iS = gsc[3], d2dS = gsc[5];
+  const uint32_t* __restrict__ xc = a.ctx + xb;
+  const uint32_t* __restrict__ yc = (comp ? a.ctxc : a.ctx) + yb;
+  double colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
+  uint32_t colI = 0, rowJ = 0;
+  unsigned long long woff = 0;
+
+  for (int s = 0; s < g.nStripes; ++s) {
+    int jlo, jhi;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+    const int i0 = g.ilo + s * S + l * B;
+    const double* __restrict__ bprev = bnd + (size_t)(s & 1) * bndStride;
+    double* __restrict__ bnext = bnd + (size_t)((s + 1) & 1) * bndStride;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
+    if (jhi < jlo) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      continue;
+    }
+    uint32_t erX[B], gkx[B], gkxP[B];   // row i: emission row, xIndelKmer[i], xIndelKmer[i-1] (padded 0)
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int i = i0 + b;
+      const uint32_t wx = (i >= 1 && i <= xLen) ? xc[i - 1] : 0u;
+      const uint32_t wp = (i >= 2 && i <= xLen + 1) ? xc[i - 2] : 0u;
+      erX[b] = wx & 0x7FFFu; gkx[b] = wx >> 24; gkxP[b] = i > 1 ? (wp >> 24) : 0u;
+    }
+    double M[B], I[B], D[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
+    double p1M = QF_NEG_INF, p1I = QF_NEG_INF, p1D = QF_NEG_INF, p2M = QF_NEG_INF, p2I = QF_NEG_INF, p2D = QF_NEG_INF;
+    const int steps = jhi - jlo + 1 + G - 1;
+    for (int t = 0; t < steps; ++t) {
+      const int j = jlo + t - l;
+      const bool colvalid = j >= jlo && j <= jhi;
+      const uint32_t wy = yc[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+      const uint32_t erowY = wy & 0x7FFFu, gky = wy >> 24;
+      const uint32_t gkyP = j > 1 ? (yc[min(j - 2, yLen + 4)] >> 24) : 0u;
+      double upM = __shfl_up(p1M, 1, G), upI = __shfl_up(p1I, 1, G), upD = __shfl_up(p1D, 1, G);
+      double dgM = __shfl_up(p2M, 1, G), dgI = __shfl_up(p2I, 1, G), dgD = __shfl_up(p2D, 1, G);
+      if (l == 0) {
+        const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
+        upM = bprev[jc]; upI = bprev[(yLen + 2) + jc]; upD = bprev[2 * (yLen + 2) + jc];
+        dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
+      }
+      uint32_t tbw0 = 0, tbw1 = 0;
+      double abM = upM, abI = upI, abD = upD;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int i = i0 + b, dgl = i - j;
+        const bool valid = colvalid && i >= 1 && i <= xLen && dgl >= dlo && dgl <= dhi;
+        const double e = mmi[(size_t)erX[b] * KQ + erowY];
+        const double m2m = gap[gkxP[b] * Kg + gkyP];
+        const double m2i = gap[(size_t)Kg * Kg + gkx[b] * Kg + gkyP];
+        const double m2d = gap[2ull * Kg * Kg + gkxP[b] * Kg + gky];
+        const double oM = M[b], oI = I[b], oD = D[b];   // (i, j-1)
+        const double tM = (dgM + m2m) + e, tI = (dgI + i2mS) + e, tD = (dgD + d2mS) + e;
+        double nm = tM;
+        uint32_t sm = 0;
+        if (tI > nm) { nm = tI; sm = 1; }
+        if (tD > nm) { nm = tD; sm = 2; }
+        if ((j == 1 || i == 1) && e > nm) { nm = e; sm = 3; }
+        const double iM = oM + m2i, iI = oI + i2iS, iD = oD + d2iS;
+        const double lseI = lse_exact(tab, iI, iD);
+        double ni = lseI > iM ? lseI : iM;
+        uint32_t si = 0;
+        { double sv = iM; if (iI > sv) { sv = iI; si = 1; } if (iD > sv) { sv = iD; si = 2; } }
+        const double dM = abM + m2d, dD = abD + d2dS, dIfill = abI + d2iS, dItb = abI + i2dS;
+        const double lseD = lse_exact(tab, dD, dIfill);
+        double ndl = lseD > dM ? lseD : dM;
+        uint32_t sd = 0;
+        { double sv = dM; if (dItb > sv) { sv = dItb; sd = 1; } if (dD > sv) { sv = dD; sd = 2; } }
+        if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
+        M[b] = nm; I[b] = ni; D[b] = ndl;
+        dgM = oM; dgI = oI; dgD = oD;
+        abM = nm; abI = ni; abD = ndl;
+        const uint32_t byte = sm | (si << 2) | (sd << 4);
+        if (b < 4) tbw0 |= byte << (8 * b); else tbw1 |= byte << (8 * (b - 4));
+        if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
+        if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+      }
+      p2M = p1M; p2I = p1I; p2D = p1D;
+      p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
+      if (colvalid) {
+        tbw[woff + ((unsigned long long)t * G + l) * 2] = tbw0;
+        tbw[woff + ((unsigned long long)t * G + l) * 2 + 1] = tbw1;
+        if (l == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
+      }
+    }
+    woff += (unsigned long long)steps * G * 2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  for (int o = 1; o < G; o <<= 1) {
+    const double ov = __shfl_xor(colBest, o, G);
+    const uint32_t oi = __shfl_xor(colI, o, G);
+    if (ov > colBest || (ov == colBest && oi > colI)) { colBest = ov; colI = oi; }
+    const double rv = __shfl_xor(rowBest, o, G);
+    const uint32_t rj = __shfl_xor(rowJ, o, G);
+    if (rv > rowBest || (rv == rowBest && rj > rowJ)) { rowBest = rv; rowJ = rj; }
+  }
+  if (l == 0) {
+    Unit* uu = &a.units[uid];
+    uu->end_val = colBest; uu->end_i = colI;
+    uu->end2_val = rowBest; uu->end2_j = rowJ;
+  }
+}
+
 // End cell (src/qoverlap.cpp:164-182): start from mat(xLen,yLen), scan the last read column downwards, then the last
 // reference row, replacing only on strict '>'.  result = end + xInsertScore + yInsertScore (:157); adjusted score
 // subtracts both reads' null log-likelihoods (:292-302).
@@ -353,8 +500,19 @@ __global__ void k_overlap_traceback(OvArgs a) {
   const Unit u = a.units[rec.unit];
   const FillClass fc = fill_class((int)u.cls);
   const uint32_t* __restrict__ tb = a.tb + u.tb_off;
+  const uint32_t px = a.pair_x[p], py = a.pair_y[p];
+  const int xLenR = (int)(a.seq_off[px + 1] - a.seq_off[px]), yLenR = (int)(a.seq_off[py + 1] - a.seq_off[py]);
+  const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, yLenR) : RowGeom{0, 0, 0};
   auto cellbyte = [&](int i, int j) -> uint32_t {
     if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0x3u;  // single diagonal: match flags only
+    if (u.cls == (uint32_t)kRowClass) {
+      const int rr = i - rg.ilo, s = rr / kRowStripe, li = (rr % kRowStripe) / 8, b = rr % 8;
+      int jlo, jhi;
+      row_stripe_cols(rg, s, u.dlo, u.dhi, yLenR, jlo, jhi);
+      const unsigned long long* so = (const unsigned long long*)tb;
+      const uint32_t* words = tb + row_header_words(rg, yLenR);
+      return (words[so[s] + ((unsigned long long)(j - jlo + li) * 64 + li) * 2 + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+    }
     const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
     const uint64_t w = ((uint64_t)(j - 1 + l) * fc.G + l) * 2 + (b >> 2);
     return (tb[w] >> (8 * (b & 3))) & 0xFFu;
@@ -411,6 +569,7 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
     case 8: launch_ov_gb<64, 4>(a, s); break;
     case 9: launch_ov_gb<64, 6>(a, s); break;
     case 10: launch_ov_gb<64, 8>(a, s); break;
+    case 13: hipLaunchKernelGGL(k_overlap_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); break;
   }
 }
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s) {

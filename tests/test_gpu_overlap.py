@@ -48,7 +48,7 @@ def check_overlap(ctx, reads, params_json, cfg_kw, with_revcomps=True):
     ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
     res = ctx.overlap_resident(pairs, Q.DPConfig(**cfg_kw))
     ocfg = O.DPConfig(kmer_len=cfg_kw.get("kmer_len", 6), kmer_threshold=cfg_kw.get("kmer_threshold", 14),
-                      band=cfg_kw.get("band_size", 64))
+                      band=cfg_kw.get("band_size", 64), sparse=cfg_kw.get("sparse", True))
     nfinite = 0
     for k, (nx, ny, comp) in enumerate(pairs):
         want = O.overlap_pair(seqs[nx], seqs[ny], comp, osc[comp], sc, null, ocfg)
@@ -137,3 +137,15 @@ def test_overlap_internal_chunking(ctx):
         b = parts["alignments"][k]
         assert (a["result"], a["score"], a["xStart"], a["xEnd"], a["yStart"], a["yEnd"], a["ops"]) == \
                (b["result"], b["score"], b["xStart"], b["xEnd"], b["yStart"], b["yEnd"], b["ops"]), k
+
+
+def test_overlap_wide_bands_row_space(ctx):
+    """-kmatchoff (every diagonal: > 512 wide) and a sequence shorter than 2(k+threshold) (full-envelope fallback) run on
+    the row-space overlap kernel; 700-base reads make two 512-row stripes."""
+    rng = np.random.default_rng(46)
+    reads = overlapping_reads(rng, 1600, 4, 700)
+    res, nfinite = check_overlap(ctx, reads, DEFAULT_JSON, dict(sparse=False))
+    assert nfinite == len(O.overlap_task_pairs(4, 8)) and res["n_diagonals"].min() > 1024
+    g = reads[0].seq
+    reads.append(O.FastSeq("short", g[100:135], rand_qual(rng, 35)))        # 35 < 2 * (6 + 14)
+    check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
