@@ -96,7 +96,7 @@ struct Slot {
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
-      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out;
+      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws;
   HostBuf<AlignRec> h_recs;
   HostBuf<uint32_t> h_runs;
   std::string err;
@@ -111,7 +111,7 @@ struct Slot {
   }
   void destroy() {
     for (DevBuf* b : {&d_units, &d_cls_list, &d_pair_head, &d_pair_bands, &d_pair_nbands, &d_ovf, &d_pair_ndiag, &d_pair_cells,
-                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out})
+                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws})
       b->release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_ev) if (e) (void)hipEventDestroy(e);
@@ -583,6 +583,22 @@ static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs
   s.bc = S.d_bc.as<BatchCounters>();
 }
 
+// Sequences too long for the LDS diagonal histogram are seeded through global-memory workspaces, one per resident
+// workgroup (at most 1024, at most ~4 GiB in all).
+static int reserve_seed_workspace(Slot* c, SeedArgs& sa, bool mem, uint64_t n_pairs) {
+  sa.ws = nullptr;
+  sa.ws_slots = 0;
+  sa.ws_words = 0;
+  const size_t per = (seed_lds_bytes(sa.max_nd, mem) + 15) & ~(size_t)15;
+  if (!seed_needs_workspace(sa, mem)) return QF_OK;
+  const uint64_t slots = std::max<uint64_t>(1, std::min<uint64_t>({n_pairs, 1024, (4ull << 30) / per}));
+  HIPCHK(c, c->d_seed_ws.reserve(per * slots));
+  sa.ws = c->d_seed_ws.as<uint32_t>();
+  sa.ws_words = per / 4;
+  sa.ws_slots = (uint32_t)slots;
+  return QF_OK;
+}
+
 static int reserve_pair_buffers(Slot* c, uint64_t n_pairs, uint32_t max_units) {
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
   HIPCHK(c, c->d_units.reserve((size_t)max_units * sizeof(Unit)));
@@ -624,6 +640,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   SeedArgs sa;
   fill_seed_args(c, *S, cfg, sa, max_units, sparse ? max_nd : 2);
   sa.read_off = d_roff;
+  if (int rc = reserve_seed_workspace(S, sa, mem, n_pairs)) return rc;
   if (launch_seed(sa, n_pairs, mem, S->stream) != 0)
     return fail(S, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
                                            " exceeds the LDS diagonal histogram (global-memory histogram not built yet)");
@@ -968,6 +985,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   sa.cell_size = 48;
   sa.storage_mode = 1;
   sa.pair_skip = d_skip;
+  if (int rc = reserve_seed_workspace(c, sa, mem, n_pairs)) return rc;
   if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
     return fail(c, QF_ERR_UNSUPPORTED, "reference + read length exceeds the LDS diagonal histogram");
   launch_bin_units(sa, n_pairs, 0, c->stream);
@@ -1237,6 +1255,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   sa.ref_pos = c->d_rpos.as<uint32_t>();
   sa.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
   sa.storage_mode = 2;
+  if (int rc = reserve_seed_workspace(c, sa, mem, n_pairs)) return rc;
   if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
     return fail(c, QF_ERR_UNSUPPORTED, "read + read length exceeds the LDS diagonal histogram");
   launch_bin_units(sa, n_pairs, 0, c->stream);
@@ -1510,6 +1529,7 @@ int64_t qf_envelope(qf_ctx* c, const qf_dp_config* cfg, uint32_t read, uint32_t 
   fill_seed_args(c, *c, cfg, sa, max_units, sparse ? (int)(c->ref_maxlen + c->read_maxlen - 1) : 2);
   sa.pair_base = read * c->n_refs + ref;
   sa.dump_cover = c->d_cover.as<uint8_t>();
+  if (int rc = reserve_seed_workspace(c, sa, sparse && cfg->kmer_threshold < 0, 1)) return rc;
   if (launch_seed(sa, 1, sparse && cfg->kmer_threshold < 0, c->stream) != 0) return fail(c, QF_ERR_UNSUPPORTED, "sequence too long for the LDS histogram");
   std::vector<uint8_t> cover(nd);
   if (hipMemcpyAsync(cover.data(), c->d_cover.p, nd, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

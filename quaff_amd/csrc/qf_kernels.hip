@@ -246,9 +246,8 @@ __device__ __forceinline__ void record_band(const SeedArgs& a, uint32_t pair, in
 // One 256-thread workgroup per (read, ref) pair.  LDS: a dense histogram of k-mer matches per diagonal
 // (two 16-bit counters per dword) and a per-diagonal membership array.
 template <bool MEM>
-__global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
-  extern __shared__ uint32_t lds[];
-  const uint32_t pair = a.pair_base + blockIdx.x, tid = threadIdx.x;
+__device__ void seed_pair(const SeedArgs& a, uint32_t pair, uint32_t* lds, uint32_t* s_red) {
+  const uint32_t tid = threadIdx.x;
   if (a.pair_skip && a.pair_skip[pair]) return;
   uint32_t r, x;
   pair_rx(a, pair, r, x);
@@ -278,7 +277,6 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
   uint8_t* cover8 = (uint8_t*)(lds + histWords);
   uint16_t* cover16 = (uint16_t*)(lds + histWords);
   uint16_t* st16 = cover16 + ((a.max_nd + 3) & ~1);
-  __shared__ uint32_t s_red[256];
 
   for (int w = tid; w < (nd + 1) / 2; w += 256) hist[w] = 0;
   if (MEM) {
@@ -388,6 +386,24 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
   __syncthreads();
   for (int o = 128; o; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
   if (tid == 0) a.pair_ndiag[pair] = s_red[0];
+}
+template <bool MEM>
+__global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
+  extern __shared__ uint32_t lds[];
+  __shared__ uint32_t s_red[256];
+  seed_pair<MEM>(a, a.pair_base + blockIdx.x, lds, s_red);
+}
+// The same per-pair procedure with the histogram and membership arrays in a global-memory workspace (one per resident
+// workgroup, reused pair after pair): references too long for the LDS histogram (genome scale).
+template <bool MEM>
+__global__ __launch_bounds__(256) void k_seed_global(SeedArgs a, uint32_t n_pairs) {
+  __shared__ uint32_t s_red[256];
+  uint32_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_words;
+  for (uint32_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+    seed_pair<MEM>(a, a.pair_base + p, ws, s_red);
+    __threadfence();
+    __syncthreads();
+  }
 }
 template __global__ void k_seed<false>(SeedArgs);
 template __global__ void k_seed<true>(SeedArgs);
@@ -1542,6 +1558,15 @@ size_t seed_lds_bytes(int max_nd, bool mem) {
   const size_t hist = (size_t)((max_nd + 1) / 2) * 4;
   return mem ? hist + (size_t)((max_nd + 3) & ~1) * 2 + (size_t)(max_nd + 4) * 2 : hist + (size_t)max_nd + 4;
 }
+bool seed_needs_workspace(const SeedArgs& a, bool mem) {
+  if (!a.sparse) return false;
+  if (!mem && a.threshold >= 0 && !a.force_block_kernel) {
+    const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
+    const uint32_t words = ((nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
+    if ((size_t)words * 4 * 4 <= 150 * 1024) return false;
+  }
+  return seed_lds_bytes(a.max_nd, mem) > 150 * 1024;
+}
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
   if (!mem && a.sparse && a.threshold >= 0 && !a.force_block_kernel) {
@@ -1554,10 +1579,15 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
       hipLaunchKernelGGL(k_seed_wave, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
       return 0;
     }
-    return -1;
   }
   const size_t lds = seed_lds_bytes(a.max_nd, mem);
-  if (lds > 150 * 1024) return -1;
+  if (lds > 150 * 1024) {  // too long for LDS: global-memory workspaces
+    if (!a.ws || !a.ws_slots || a.ws_words * 4 < lds) return -1;
+    const uint32_t grid = n_pairs < a.ws_slots ? n_pairs : a.ws_slots;
+    if (mem) hipLaunchKernelGGL(k_seed_global<true>, dim3(grid), dim3(256), 0, s, a, n_pairs);
+    else hipLaunchKernelGGL(k_seed_global<false>, dim3(grid), dim3(256), 0, s, a, n_pairs);
+    return 0;
+  }
   if (mem) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_seed<true>, dim3(n_pairs), dim3(256), lds, s, a);

@@ -60,6 +60,9 @@ struct SeedArgs {
   uint32_t* pair_ndiag;        // [n_pairs]
   unsigned long long* pair_cells;  // [n_pairs] (zero-initialised)
   uint8_t* dump_cover;         // optional [nd] membership of a single pair
+  uint32_t* ws;                // global-memory seeding workspaces (sequences too long for the LDS histogram)
+  uint64_t ws_words;           // 4-byte words per workspace
+  uint32_t ws_slots;
   const uint8_t* pair_skip;    // optional [n_pairs]: 1 = do not seed this pair (train: pruned references)
   int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
   int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
@@ -179,6 +182,7 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
                       uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s);
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s);
 size_t seed_lds_bytes(int max_nd, bool mem);
+bool seed_needs_workspace(const SeedArgs& a, bool mem);
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
 void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s);
 void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s);

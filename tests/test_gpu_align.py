@@ -322,3 +322,27 @@ def test_internal_chunking_matches_single_pass(ctx):
             ctx.align_resident(Q.DPConfig(), 0)
     finally:
         ctx.set_memory_budget(0)
+
+
+def test_long_reference_global_seeding(ctx):
+    """A reference too long for the LDS diagonal histogram (> ~190 k diagonals): seeding runs through global-memory
+    workspaces; threshold mode with the bucket index (k = 6) and the sorted index (k = 11), and memory mode."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(30)
+    ref = rand_seq(rng, 260000)
+    sc, null = oracle_model()
+    reads = make_reads(rng, ref, 4, 450, sub=0.03, ins=0.02, dele=0.02)
+    refs = both_strands(ref)
+    res = check_against_oracle(ctx, refs, reads, dict(), sc, null)
+    assert res["n_diagonals"].max() > 65
+    check_against_oracle(ctx, refs, reads[:2], dict(kmer_len=11, kmer_threshold=6), sc, null)
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    for nb in (1, 40, 200):
+        kw = dict(kmer_threshold=-1, max_size=nb * 450 * 24)
+        ocfg = O.DPConfig(kmer_threshold=-1, max_size=kw["max_size"])
+        for r in (0, 3):
+            for x, rf in enumerate(refs):
+                got = ctx.envelope(r, x, Q.DPConfig(**kw))
+                want = O.envelope(O.tokens(rf.seq), O.tokens(reads[r].seq), ocfg, 24)
+                assert np.array_equal(got, want), (nb, r, x, len(got), len(want))
