@@ -127,6 +127,7 @@ struct qf_ctx : Slot {
   Slot second;             // created on first use
   bool second_ready = false;
   uint32_t pipeline_chunks = 0;  // 0 = automatic
+  bool byte_prep = false;        // QUAFF_HIP_BYTE_PREP=1: first-generation read-preparation kernel (A/B)
   std::string devname;
   // model
   Params params;
@@ -204,6 +205,7 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   }
   qf_ctx* c = new qf_ctx();
   c->device = device_id;
+  if (const char* e = getenv("QUAFF_HIP_BYTE_PREP")) c->byte_prep = atoi(e) != 0;
   if (const char* e = getenv("QUAFF_HIP_CHUNKS")) c->pipeline_chunks = (uint32_t)atoi(e);  // tuning aid; 0 = automatic
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
@@ -535,6 +537,7 @@ static int prep_reads(qf_ctx* c, int seed_k) {
     a.null_logQual = c->d_nullq.as<double>();
   }
   a.bc = c->d_bc.as<BatchCounters>();
+  a.byte_kernel = c->byte_prep;
   launch_prep_reads(a, c->n_reads, c->stream);
   HIPCHK(c, hipGetLastError());
   return QF_OK;

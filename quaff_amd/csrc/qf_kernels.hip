@@ -152,6 +152,180 @@ __global__ __launch_bounds__(64) void k_prep_reads(PrepArgs a) {
   }
 }
 
+
+// k_prep_reads2: the same outputs as k_prep_reads, sixteen bases per lane.  The byte-at-a-time version spends its time in
+// ~10 single-byte gathers per base (every base re-reads its context and seed-k-mer neighbours); here each base is
+// tokenised once (SWAR on 4 characters), staged in LDS, and the context / seeding k-mers roll over a 48-token register
+// window.  One wavefront per read, 1024 bases per tile.  Seeding k-mers are produced by their LAST base (the k-mer that
+// starts at i is stored when base i + k - 1 is reached), so the window only looks backwards.
+struct __attribute__((packed, aligned(1))) C16 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(4))) W4a { uint32_t v[4]; };
+struct __attribute__((packed, aligned(4))) L4a { unsigned long long v[2]; };
+
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {  // 0x80 in every byte of v that is zero (exact)
+  const uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | v | 0x7F7F7F7Fu);
+}
+
+template <bool K64>
+__global__ __launch_bounds__(64) void k_prep_reads2(PrepArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_tok[(32 + 1024) / 4];
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
+  const uint64_t b = a.off[r];
+  const uint32_t L = (uint32_t)(a.off[r + 1] - b);
+  const uint32_t mlen = a.match_len, glen = a.gap_len, K = a.seed_k;
+  const uint32_t maskM = (1u << (2 * mlen)) - 1u, maskG = glen ? (1u << (2 * glen)) - 1u : 0u;
+  const unsigned long long maskK = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1ull);
+  uint32_t cnt1 = 0, cnt2 = 0, cnt3 = 0, nvalid = 0;
+  if (lane < 2) ((uint4*)s_tok)[lane] = make_uint4(0, 0, 0, 0);   // no bases before the read (pad fixed up below)
+  for (uint32_t T0 = 0; T0 < L; T0 += 1024) {
+    const uint32_t p0 = T0 + lane * 16;
+    // ---- tokenise this lane's 16 characters
+    uint32_t tw[4] = {0, 0, 0, 0};
+    if (p0 < L) {
+      const C16 ch = *(const C16*)(a.seq + b + p0);
+      bool bad = false;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t cw = ch.v[w], up = cw & 0xDFDFDFDFu;
+        const uint32_t ok = zero_bytes(up ^ 0x41414141u) | zero_bytes(up ^ 0x43434343u) | zero_bytes(up ^ 0x47474747u) |
+                            zero_bytes(up ^ 0x54545454u);
+        const uint32_t x = (cw >> 1) & 0x03030303u;            // A 0, C 1, T 2, G 3
+        uint32_t t = x ^ ((x >> 1) & 0x01010101u);             // A 0, C 1, G 2, T 3
+        uint32_t live = 0;                                     // 0x80 in the bytes that are inside the read
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (p0 + w * 4 + c < L) live |= 0x80u << (8 * c);
+        bad |= (live & ~ok) != 0;
+        const uint32_t keep = ok & live;
+        t &= (keep >> 7) | (keep >> 6);
+        tw[w] = t;
+        const uint32_t lo = t & 0x01010101u, hi = (t >> 1) & 0x01010101u;
+        cnt1 += __popc(lo & ~hi); cnt2 += __popc(hi & ~lo); cnt3 += __popc(lo & hi);
+        nvalid += __popc(live);
+      }
+      if (bad) {
+        atomicOr(&a.bc->error, 4u);
+        a.bc->error_detail = r;
+      }
+    }
+    if (T0 && lane < 2) ((uint4*)s_tok)[lane] = ((const uint4*)s_tok)[64 + lane];  // last 32 tokens of the previous tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    ((uint4*)s_tok)[2 + lane] = make_uint4(tw[0], tw[1], tw[2], tw[3]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (p0 < L) {
+      // window: tokens of bases p0-32 .. p0+15 (byte o <-> base p0 - 32 + o)
+      uint32_t W[12];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const uint4 v = ((const uint4*)s_tok)[lane + q];
+        W[4 * q] = v.x; W[4 * q + 1] = v.y; W[4 * q + 2] = v.z; W[4 * q + 3] = v.w;
+      }
+      auto tk = [&](int o) -> uint32_t { return (W[o >> 2] >> (8 * (o & 3))) & 3u; };
+      C16 qc{};
+      if (a.qual) qc = *(const C16*)(a.qual + b + p0);
+      uint32_t mk = 0, gk = 0;
+#pragma unroll
+      for (int o = 28; o < 32; ++o) { mk = ((mk << 2) | tk(o)) & maskM; gk = ((gk << 2) | tk(o)) & maskG; }
+      uint32_t cw[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t t = tk(32 + e);
+        mk = ((mk << 2) | t) & maskM;
+        gk = ((gk << 2) | t) & maskG;
+        uint32_t q = kNQualDev;
+        if (a.qual) {
+          const int v = (int)(signed char)((qc.v[e >> 2] >> (8 * (e & 3))) & 0xFFu) - '!';
+          q = (uint32_t)max(0, min(kNQualDev - 1, v));
+        }
+        cw[e] = ctx_pack(mk * (kNQualDev + 1) + q, t * (kNQualDev + 1) + q, gk);
+      }
+      const bool whole = p0 + 16 <= L;
+      uint32_t* cdst = a.ctx + b + p0;
+      uint8_t* tdst = a.tok + b + p0;
+      if (whole) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { W4a o4; o4.v[0] = cw[4 * q]; o4.v[1] = cw[4 * q + 1]; o4.v[2] = cw[4 * q + 2]; o4.v[3] = cw[4 * q + 3]; *(W4a*)(cdst + 4 * q) = o4; }
+        C16 t16; t16.v[0] = tw[0]; t16.v[1] = tw[1]; t16.v[2] = tw[2]; t16.v[3] = tw[3];
+        *(C16*)tdst = t16;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (p0 + e < L) { cdst[e] = cw[e]; tdst[e] = (uint8_t)((tw[e >> 2] >> (8 * (e & 3))) & 3u); }
+      }
+      // ---- seeding k-mers by their last base
+      if (K) {
+        if (K64) {
+          unsigned long long sk = 0;
+#pragma unroll
+          for (int o = 0; o < 32; ++o) sk = (sk << 2) | tk(o);
+          unsigned long long kv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { sk = (sk << 2) | tk(32 + e); kv[e] = sk & maskK; }
+          const long long i0 = (long long)p0 - (long long)K + 1;   // start of the k-mer that ends at p0
+          if (whole && i0 >= 0) {
+            unsigned long long* dst = a.skmer64 + b + i0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { L4a o2; o2.v[0] = kv[2 * q]; o2.v[1] = kv[2 * q + 1]; *(L4a*)(dst + 2 * q) = o2; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (i0 + e >= 0 && p0 + e < L) a.skmer64[b + i0 + e] = kv[e];
+          }
+        } else {
+          uint32_t sk = 0;
+#pragma unroll
+          for (int o = 16; o < 32; ++o) sk = (sk << 2) | tk(o);
+          uint32_t kv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { sk = (sk << 2) | tk(32 + e); kv[e] = sk & (uint32_t)maskK; }
+          const long long i0 = (long long)p0 - (long long)K + 1;
+          if (whole && i0 >= 0) {
+            uint32_t* dst = a.skmer + b + i0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { W4a o4; o4.v[0] = kv[4 * q]; o4.v[1] = kv[4 * q + 1]; o4.v[2] = kv[4 * q + 2]; o4.v[3] = kv[4 * q + 3]; *(W4a*)(dst + 4 * q) = o4; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (i0 + e >= 0 && p0 + e < L) a.skmer[b + i0 + e] = kv[e];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- the first bases' context k-mers reach before the read: left-pad with the most frequent token, first maximum
+  // on ties (FastSeq::kmers, src/fastseq.cpp:85-99)
+  for (int o = 32; o; o >>= 1) {
+    cnt1 += __shfl_xor(cnt1, o); cnt2 += __shfl_xor(cnt2, o); cnt3 += __shfl_xor(cnt3, o); nvalid += __shfl_xor(nvalid, o);
+  }
+  const uint32_t cnt0 = nvalid - cnt1 - cnt2 - cnt3;
+  uint32_t padTok = 0, best = cnt0;
+  if (cnt1 > best) { best = cnt1; padTok = 1; }
+  if (cnt2 > best) { best = cnt2; padTok = 2; }
+  if (cnt3 > best) { best = cnt3; padTok = 3; }
+  const uint32_t H = max(mlen, glen ? glen : 1u) - 1u;
+  if (lane < H && lane < L) {
+    const uint32_t i = lane;
+    auto tokAt = [&](int64_t p) -> uint32_t {
+      if (p < 0) return padTok;
+      const int t = tokenize_char((unsigned char)a.seq[b + p]);
+      return t < 0 ? 0u : (uint32_t)t;
+    };
+    uint32_t mk = 0, gk = 0;
+    for (uint32_t c = 0; c < mlen; ++c) mk = mk * 4 + tokAt((int64_t)i - (mlen - 1) + c);
+    for (uint32_t c = 0; c < glen; ++c) gk = gk * 4 + tokAt((int64_t)i - (glen - 1) + c);
+    uint32_t q = kNQualDev;
+    if (a.qual) {
+      const int v = (int)(signed char)a.qual[b + i] - '!';
+      q = (uint32_t)max(0, min(kNQualDev - 1, v));
+    }
+    a.ctx[b + i] = ctx_pack(mk * (kNQualDev + 1) + q, tokAt(i) * (kNQualDev + 1) + q, gk);
+  }
+}
+
 // Null-model log-likelihood (QuaffNullParams::logLikelihood, src/qmodel.cpp:1875-1890): a strictly
 // sequential fp64 sum per read, so one LANE per read (64 reads per wavefront) rather than one wave.
 __global__ __launch_bounds__(64) void k_null_ll(PrepArgs a, uint32_t n_reads) {
@@ -1551,7 +1725,9 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
 }
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;
-  hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
+  if (a.byte_kernel) hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
+  else if (a.skmer64) hipLaunchKernelGGL(k_prep_reads2<true>, dim3(n_reads), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_prep_reads2<false>, dim3(n_reads), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_null_ll, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, n_reads);
 }
 size_t seed_lds_bytes(int max_nd, bool mem) {

@@ -32,6 +32,7 @@ struct PrepArgs {
   double* ins_sum_c;       // [n] same with complemented tokens
   double* nll_c;           // [n] null log-likelihood of the reverse complement
   BatchCounters* bc;
+  int byte_kernel;         // 1: the first-generation one-base-per-lane prep kernel (debug / A-B)
 };
 
 struct SeedArgs {
