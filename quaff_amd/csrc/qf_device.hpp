@@ -113,10 +113,17 @@ __host__ __device__ inline uint64_t row_ov_words(int dlo, int dhi, int xLen, int
   return w;
 }
 // traceback words a unit occupies
+// One-word classes (B <= 8) keep the words of four consecutive steps of a fill lane together ([step/4][lane][step%4]): the
+// fill stores 16 bytes per lane every four steps and a traceback, which follows one lane for many steps, touches a quarter
+// of the cache lines a step-major layout would make it touch.
+__host__ __device__ inline uint64_t tb_word_index(int t, int l, int G) {
+  return ((uint64_t)(t >> 2) * G + l) * 4 + (t & 3);
+}
 __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   if (cls == 0) return (yLen + 7) / 8;
   const FillClass fc = fill_class(cls);
-  return (uint64_t)(yLen + fc.G - 1) * fc.G * (fc.B > 8 ? 2 : 1);
+  if (fc.B > 8) return (uint64_t)(yLen + fc.G - 1) * fc.G * 2;
+  return (uint64_t)((yLen + fc.G - 1 + 3) & ~3u) * fc.G;
 }
 
 // Forward-matrix doubles a unit occupies (3 states x B slots x G lanes per step); single-diagonal bands run on

@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
         }
         pubM = prevM; pubD = prevD;
         if (colvalid) {
-          if (WPL == 1) tb[(uint64_t)t * G + l] = tbw0;
+          if (WPL == 1) tb[tb_word_index(t, l, G)] = tbw0;
           else { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
         }
       }
@@ -1166,6 +1166,7 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
     for (int s4 = 0; s4 < 16; s4 += 4) {
       const U32x4 cw = cwn;
       cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
+      U32x4 tile;   // this lane's traceback words of the four steps (one 16-byte store)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int t = t0 + s4 + s;
@@ -1275,10 +1276,13 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
           }
         }
         pubM = prevM; pubD = prevD;
-        if (colvalid && QF_EXP != 3) {
-          if (WPL == 1) tb[(uint64_t)t * G + l] = tbw0;
-          else { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
-        }
+        if (WPL == 1) tile.v[s] = tbw0;
+        else if (colvalid) { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
+      }
+      // steps t0+s4 .. +3 hold columns j0 .. j0+3 of this lane; stored when any of them is a real column
+      if (WPL == 1) {
+        const int j0 = t0 + s4 - l + 1;
+        if (active && j0 + 3 >= 1 && j0 <= yLen) *(U32x4*)(tb + tb_word_index(t0 + s4, l, G)) = tile;
       }
     }
   }
@@ -1572,90 +1576,138 @@ __global__ void k_select(FinalArgs a) {
 
 // QuaffViterbiMatrix::alignment, src/qmodel.cpp:1576-1622, replayed from the packed traceback bits.
 // One thread per alignment; CIGAR runs are produced end-to-start, then written start-to-end.
-// Few alignments per wavefront (kTbLanes of the 64 lanes): every memory stall of one path stalls its whole wavefront,
-// so narrow wavefronts, many of them, hide the dependent traceback loads far better than full ones.
-constexpr uint32_t kTbLanes = 64;
-__global__ void k_traceback(FinalArgs a) {
-  if (threadIdx.x >= kTbLanes) return;
+// One lane per alignment.  A wavefront advances at the pace of its slowest lane, and a lane that has to fetch a traceback
+// word from HBM stalls all 64, so the words are fetched for everybody at a fixed cadence instead: every 8 moves each lane
+// loads the 3 x 8 words around its position (its own lane-of-the-fill and both neighbours, this step and the seven
+// before: a path cannot leave that window in 8 moves) as 24 independent loads and parks them in LDS.  The position is
+// tracked as (fill lane, slot, step) incrementally: no divisions on the path.
+#ifndef QF_TB_LANES
+#define QF_TB_LANES 32
+#endif
+constexpr uint32_t kTbLanes = QF_TB_LANES;  // alignments per wavefront: few, so that many wavefronts interleave on a SIMD
+constexpr int kTbStride = 37;  // 3 lanes x 3 tiles x 4 words per lane in LDS (odd stride: conflict-free)
+// WINDOWED = true handles the alignments of the one-word diagonal classes (everything a banded run produces), false the
+// rest (single diagonals, row-space units, two-word classes) with one dependent load per move; each alignment is taken
+// by exactly one of the two launches.
+template <bool WINDOWED>
+__global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
+  __shared__ uint32_t s_win[WINDOWED ? kTbLanes * kTbStride : 1];
   const uint32_t idx = blockIdx.x * kTbLanes + threadIdx.x;
-  if (idx >= a.n_recs) return;
-  AlignRec rec = a.recs[idx];
-  const Unit u = a.units[rec.unit];
-  const uint32_t yLen = (uint32_t)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+  bool live = idx < a.n_recs;
+  AlignRec rec{};
+  Unit u{};
+  uint32_t yLen = 0;
+  int xLenR = 0;
+  if (live) {
+    rec = a.recs[idx];
+    u = a.units[rec.unit];
+    const bool win_cls = u.cls != 0 && u.cls != (uint32_t)kRowClass && fill_class((int)u.cls).B <= 8;
+    live = win_cls == WINDOWED;
+  }
+  if (!WINDOWED && !live) return;
+  if (live) {
+    yLen = (uint32_t)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+    xLenR = (int)(a.ref_off[rec.ref + 1] - a.ref_off[rec.ref]);
+  }
   const FillClass fc = fill_class((int)u.cls);
+  const int G = fc.G, B = fc.B;
   const uint32_t* __restrict__ tb = a.tb + u.tb_off;
-  const uint32_t xR = rec.ref;
-  const int xLenR = (int)(a.ref_off[xR + 1] - a.ref_off[xR]);
-  const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, (int)yLen) : RowGeom{0, 0, 0};
-  int cl = -1, ct = -1;
-  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
-  auto nibble = [&](int i, int j) -> uint32_t {
-    if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0xFu;
-    if (u.cls == (uint32_t)kRowClass) {
-      const int rr = i - rg.ilo, s = rr / kRowStripe, li = (rr % kRowStripe) / 8, b = rr % 8;
-      int jlo, jhi;
-      row_stripe_cols(rg, s, u.dlo, u.dhi, (int)yLen, jlo, jhi);
-      const unsigned long long* so = (const unsigned long long*)tb;
-      const uint32_t* words = tb + row_header_words(rg, (int)yLen);
-      return (words[so[s] + (unsigned long long)(j - jlo + li) * 64 + li] >> (4 * b)) & 0xFu;
-    }
-    const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
-    const int t = j - 1 + l;
-    if (fc.B > 8) return (tb[((uint64_t)t * fc.G + l) * 2 + (b >> 3)] >> (4 * (b & 7))) & 0xFu;
-    // A path mostly stays inside one lane's diagonals, where consecutive moves read the words of steps t, t-1, ...
-    // of the same lane: keep eight of them (fetched as independent loads) instead of one dependent load per move.
-    if (l != cl || t > ct || t < ct - 7) return (tb[(uint64_t)t * fc.G + l] >> (4 * (b & 7))) & 0xFu;  // left the cached run
-    const int k = ct - t;
-    const uint32_t wv = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : k == 3 ? c3 : k == 4 ? c4 : k == 5 ? c5 : k == 6 ? c6 : c7;
-    return (wv >> (4 * (b & 7))) & 0xFu;
-  };
   uint32_t* tmp = a.runs_tmp + rec.tmp_off;
   int i = (int)u.end_i, j = (int)yLen;
   const uint32_t xEnd = u.end_i;
   uint32_t n = 0, ncol = 0, curOp = 3, curLen = 0;
-  int state = 1;  // 0 Start, 1 Match, 2 Insert, 3 Delete
-  const bool cached = u.cls != 0 && u.cls != (uint32_t)kRowClass && fc.B <= 8;
-  uint32_t it = 0;
-  while (state != 0 && i >= 0 && j >= 0 && (i > 0 || j > 0)) {
-    if (cached && (it++ & 7) == 0 && i >= 1 && j >= 1) {
-      // every 8 moves ALL lanes of the wavefront refill together (one round trip for eight independent loads per lane)
-      // instead of each lane stalling the wavefront whenever its own run is exhausted
-      const int dd = (i - j) - u.dlo, l = dd / fc.B, t = j - 1 + l;
-      cl = l; ct = t;
-      c0 = tb[(uint64_t)t * fc.G + l];
-      c1 = tb[(uint64_t)max(t - 1, 0) * fc.G + l]; c2 = tb[(uint64_t)max(t - 2, 0) * fc.G + l];
-      c3 = tb[(uint64_t)max(t - 3, 0) * fc.G + l]; c4 = tb[(uint64_t)max(t - 4, 0) * fc.G + l];
-      c5 = tb[(uint64_t)max(t - 5, 0) * fc.G + l]; c6 = tb[(uint64_t)max(t - 6, 0) * fc.G + l];
-      c7 = tb[(uint64_t)max(t - 7, 0) * fc.G + l];
-    }
-    const uint32_t nib = (i >= 1 && j >= 1) ? nibble(i, j) : 0u;
-    uint32_t op;
-    if (state == 1) {
-      op = 0;
-      const uint32_t s = nib & 3u;
-      --i; --j;
-      // 3 = Start on column 1 (the only place a start candidate exists); elsewhere the trimmed fill's raw compare bits
-      // "I>M and D>max(M,I)", i.e. D
-      state = s == 0 ? 1 : s == 1 ? 2 : (s == 2 || j > 0) ? 3 : 0;
-    } else if (state == 2) {
-      op = 1;
-      --j;
-      state = (nib >> 2) & 1u ? 2 : 1;
-    } else {
-      op = 2;
-      --i;
-      state = (nib >> 3) & 1u ? 3 : 1;
-    }
+  int state = live ? 1 : 0;  // 0 Start, 1 Match, 2 Insert, 3 Delete
+  auto walking = [&]() { return state != 0 && i >= 0 && j >= 0 && (i > 0 || j > 0); };
+  // one move, branch-free (the lanes of a wavefront are in different states): M steps to (i-1,j-1) on the same diagonal,
+  // I to (i,j-1) on diagonal d+1, D to (i-1,j) on diagonal d-1.  Match source 3 = Start on column 1 (the only place a start
+  // candidate exists); elsewhere the trimmed fill's raw compare bits "I>M and D>max(M,I)", i.e. D.
+  auto step = [&](uint32_t nib, int& db) {
+    const bool isM = state == 1, isI = state == 2;
+    const uint32_t op = isM ? 0u : isI ? 1u : 2u;
+    i -= isI ? 0 : 1;
+    j -= (isM || isI) ? 1 : 0;
+    db = isM ? 0 : isI ? 1 : -1;
+    const uint32_t s = nib & 3u;
+    const int fromM = s == 0 ? 1 : s == 1 ? 2 : (s == 2 || j > 0) ? 3 : 0;
+    const int fromI = (nib >> 2) & 1u ? 2 : 1, fromD = (nib >> 3) & 1u ? 3 : 1;
+    state = isM ? fromM : isI ? fromI : fromD;
     ++ncol;
     if (op == curOp) ++curLen;
     else {
       if (curLen) tmp[n++] = (curLen << 2) | curOp;
       curOp = op; curLen = 1;
     }
+  };
+  if (WINDOWED) {
+    uint32_t* win = s_win + threadIdx.x * kTbStride;
+    // position inside the unit: fill lane l, slot b; the word of cell (i,j) is tb[tb_word_index(j-1+l, l, G)]
+    int l = 0, b = 0, cl = 0, ct = 0;
+    if (live) { const int dd = (i - j) - u.dlo; l = dd / B; b = dd % B; }
+    while (__builtin_amdgcn_ballot_w64(walking())) {
+      if (walking() && i >= 1 && j >= 1) {
+        cl = l; ct = (j - 1 + l) >> 2;   // window: tiles ct, ct-1, ct-2 (12 steps) of fill lanes cl-1, cl, cl+1
+#pragma unroll
+        for (int dl = 0; dl < 3; ++dl) {
+          const int ll = min(max(cl - 1 + dl, 0), G - 1);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const U32x4 v = *(const U32x4*)(tb + ((uint64_t)max(ct - q, 0) * G + ll) * 4);
+            uint32_t* dst = win + (dl * 3 + q) * 4;
+            dst[0] = v.v[0]; dst[1] = v.v[1]; dst[2] = v.v[2]; dst[3] = v.v[3];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int mv = 0; mv < 8; ++mv) {
+        if (!walking()) continue;
+        uint32_t nib = 0;
+        if (i >= 1 && j >= 1) {
+          const int t = j - 1 + l, dl = l - cl + 1, q = ct - (t >> 2);
+          if ((unsigned)dl < 3u && (unsigned)q < 3u) nib = (win[(dl * 3 + q) * 4 + (t & 3)] >> (4 * b)) & 0xFu;
+          else nib = (tb[tb_word_index(max(t, 0), min(max(l, 0), G - 1), G)] >> (4 * b)) & 0xFu;   // left the window (rare)
+        }
+        int db;
+        step(nib, db);
+        b += db;
+        if (b == B) { b = 0; ++l; }
+        if (b < 0) { b = B - 1; --l; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, (int)yLen) : RowGeom{0, 0, 0};
+    while (walking()) {
+      uint32_t nib = 0;
+      if (i >= 1 && j >= 1) {
+        if (u.cls == 0) nib = (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0xFu;
+        else if (u.cls == (uint32_t)kRowClass) {
+          const int rr = i - rg.ilo, s = rr / kRowStripe, li = (rr % kRowStripe) / 8, b = rr % 8;
+          int jlo, jhi;
+          row_stripe_cols(rg, s, u.dlo, u.dhi, (int)yLen, jlo, jhi);
+          const unsigned long long* so = (const unsigned long long*)tb;
+          const uint32_t* words = tb + row_header_words(rg, (int)yLen);
+          nib = (words[so[s] + (unsigned long long)(j - jlo + li) * 64 + li] >> (4 * b)) & 0xFu;
+        } else {
+          const int dd = (i - j) - u.dlo, l = dd / B, b = dd % B, t = j - 1 + l;
+          nib = (tb[((uint64_t)t * G + l) * 2 + (b >> 3)] >> (4 * (b & 7))) & 0xFu;
+        }
+      }
+      int db;
+      step(nib, db);
+    }
   }
+  if (!live) return;
   if (curLen) tmp[n++] = (curLen << 2) | curOp;
   const unsigned long long off = atomicAdd(&a.bc->total_runs_out, (unsigned long long)n);
-  for (uint32_t c = 0; c < n; ++c) a.runs_out[off + c] = tmp[n - 1 - c];
+  uint32_t c = 0;
+  for (; c + 4 <= n; c += 4) {   // reversed copy, four independent loads at a time
+    const uint32_t r0 = tmp[n - 1 - c], r1 = tmp[n - 2 - c], r2 = tmp[n - 3 - c], r3 = tmp[n - 4 - c];
+    a.runs_out[off + c] = r0; a.runs_out[off + c + 1] = r1; a.runs_out[off + c + 2] = r2; a.runs_out[off + c + 3] = r3;
+  }
+  for (; c < n; ++c) a.runs_out[off + c] = tmp[n - 1 - c];
   rec.x_start = (uint32_t)(i + 1);
   rec.x_end = xEnd;
   rec.n_columns = ncol;
@@ -1785,7 +1837,9 @@ void launch_select(const FinalArgs& a, hipStream_t s) {
   if (a.n_reads) hipLaunchKernelGGL(k_select, dim3((a.n_reads + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_traceback(const FinalArgs& a, hipStream_t s) {
-  if (a.n_recs) hipLaunchKernelGGL(k_traceback, dim3((a.n_recs + kTbLanes - 1) / kTbLanes), dim3(64), 0, s, a);
+  if (!a.n_recs) return;
+  hipLaunchKernelGGL(k_traceback<true>, dim3((a.n_recs + kTbLanes - 1) / kTbLanes), dim3(kTbLanes), 0, s, a);
+  hipLaunchKernelGGL(k_traceback<false>, dim3((a.n_recs + kTbLanes - 1) / kTbLanes), dim3(kTbLanes), 0, s, a);
 }
 
 }  // namespace qf
