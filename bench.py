@@ -42,6 +42,7 @@ def parse():
                          "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
     ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
     ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
+    ap.add_argument("--debug-flags", type=int, default=0, help="developer: extra qf_dp_config.reserved bits (A/B switches)")
     ap.add_argument("--chunks", type=int, default=0, help="pieces per batch kept two in flight (0 = library default)")
     ap.add_argument("--align-flags", type=int, default=0, help="developer: QF_ALIGN_* flags (2 = scores only, not a valid bench)")
     ap.add_argument("--single-device", action="store_true",
@@ -239,7 +240,7 @@ def main():
     seq, qual, off = api.synth_reads(2 + rank, ref, a.reads, a.read_len)
     ctx.upload_reads_packed(seq, qual, off)          # resident in HBM before the timed region
     ctx.set_pipeline_chunks(a.chunks)
-    cfg = Q.DPConfig(band_size=a.band, debug_flags=(2 if a.reference_kernel else 0) | (4 if a.serial_classes else 0))
+    cfg = Q.DPConfig(band_size=a.band, debug_flags=(2 if a.reference_kernel else 0) | (4 if a.serial_classes else 0) | a.debug_flags)
 
     def sync_all():
         if world > 1:

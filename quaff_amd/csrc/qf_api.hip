@@ -92,7 +92,7 @@ struct HostBuf {
 // chunk's seeding and traceback (latency-bound) overlap the other's fill (VALU-bound).
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[7] = {};   // [6]: pair results final (their copy to the host overlaps selection and traceback)
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
@@ -583,6 +583,8 @@ static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs
   s.pair_ndiag = S.d_pair_ndiag.as<uint32_t>();
   s.pair_cells = S.d_pair_cells.as<unsigned long long>();
   s.force_block_kernel = cfg->reserved & 1;  // debug/testing: workgroup-per-pair seeding kernel
+  s.max_ref_len = (uint32_t)std::min<uint64_t>(c->ref_maxlen, 0xFFFFFFFFull);
+  s.no_lds_index = (cfg->reserved >> 4) & 1;
   s.bc = S.d_bc.as<BatchCounters>();
 }
 
@@ -739,6 +741,13 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   fin.tb = S->d_tb.as<uint32_t>();
   fin.bc = S->d_bc.as<BatchCounters>();
   launch_finalize(fin, S->stream);
+  // per-pair results are final: copy them out on a side stream while the alignments are selected and traced
+  const size_t p0 = (size_t)lo * n_refs;
+  HIPCHK(S, hipEventRecord(S->ev[6], S->stream));
+  HIPCHK(S, hipStreamWaitEvent(S->aux[2], S->ev[6], 0));
+  HIPCHK(S, hipMemcpyAsync(c->h_viterbi.data() + p0, S->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->aux[2]));
+  HIPCHK(S, hipMemcpyAsync(c->h_cells.data() + p0, S->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->aux[2]));
+  HIPCHK(S, hipMemcpyAsync(c->h_ndiag.data() + p0, S->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, S->aux[2]));
   uint32_t n_recs = 0;
   uint64_t total_runs = 0;
   if (!(flags & QF_ALIGN_NO_TRACEBACK)) {
@@ -763,16 +772,14 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   HIPCHK(S, hipEventRecord(S->ev[4], S->stream));
 
   // ---- results to the host, at the chunk's offsets
-  const size_t p0 = (size_t)lo * n_refs, recs0 = S->h_recs.size(), runs0 = S->h_runs.size();
+  const size_t recs0 = S->h_recs.size(), runs0 = S->h_runs.size();
   S->h_recs.resize(recs0 + n_recs);
   S->h_runs.resize(runs0 + total_runs);
-  HIPCHK(S, hipMemcpyAsync(c->h_viterbi.data() + p0, S->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
-  HIPCHK(S, hipMemcpyAsync(c->h_cells.data() + p0, S->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
-  HIPCHK(S, hipMemcpyAsync(c->h_ndiag.data() + p0, S->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, S->stream));
   if (n_recs) HIPCHK(S, hipMemcpyAsync(S->h_recs.data() + recs0, S->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, S->stream));
   if (total_runs) HIPCHK(S, hipMemcpyAsync(S->h_runs.data() + runs0, S->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(S, hipEventRecord(S->ev[5], S->stream));
   HIPCHK(S, hipStreamSynchronize(S->stream));
+  HIPCHK(S, hipStreamSynchronize(S->aux[2]));
   for (size_t a = recs0; a < recs0 + n_recs; ++a) {
     S->h_recs[a].read += lo;
     S->h_recs[a].run_off += runs0;

@@ -593,21 +593,17 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 struct __attribute__((packed, aligned(4))) U32x4u { uint32_t v[4]; };
 
-__global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words) {
+// LDSIDX: the reference's k-mer index (bucket starts and positions, 16 bits each) sits in LDS (sb, sp) instead of being
+// gathered from global memory.
+template <bool LDSIDX>
+__device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair, uint32_t r, uint32_t x, uint32_t* wlds,
+                                               const uint16_t* sb, const uint16_t* sp) {
   // Two-level histogram.  Pass 1 counts k-mer matches per COARSE bin of 32 diagonals; a diagonal can reach
   // the threshold only inside a coarse bin that does, so pass 2 re-walks the matches and keeps exact
   // per-diagonal counters for those candidate bins alone (none at all for unrelated / wrong-strand pairs).
-  // ~4 KB of LDS per wavefront instead of a dense 2 B/diagonal histogram: 32 waves per CU hide the
-  // dependent index loads.
+  // ~4 KB of LDS per wavefront instead of a dense 2 B/diagonal histogram.
   constexpr int kCand = 32;  // candidate coarse bins refined per round
-  extern __shared__ uint32_t lds[];
-  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + wv;
-  if (pidx >= n_pairs) return;
-  const uint32_t pair = a.pair_base + pidx;
-  if (a.pair_skip && a.pair_skip[pair]) return;
-  uint32_t r, x;
-  pair_rx(a, pair, r, x);
+  const uint32_t lane = threadIdx.x & 63;
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
   const int minD = 1 - yLen, maxD = xLen - 1, nd = xLen + yLen - 1;
@@ -623,7 +619,7 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
     return;
   }
   const int nCoarse = (nd + 31) >> 5, coarseWords = (nCoarse + 1) / 2, bmWords = nCoarse;
-  uint32_t* coarse = lds + (size_t)wv * wave_lds_words;      // two 16-bit counters per dword; later: slot map
+  uint32_t* coarse = wlds;                                   // two 16-bit counters per dword; later: slot map
   uint32_t* bm = coarse + (((a.max_nd + 31) / 32 + 1) / 2 + 1);  // membership bitmap, one bit per diagonal
   uint32_t* fine = bm + ((a.max_nd + 31) / 32 + 1);          // [kCand][16] dwords = 32 x 16-bit counters each
   uint32_t* misc = fine + kCand * 16;                        // [0] candidate count, [1..kCand] candidate bins
@@ -653,13 +649,21 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
       for (int c = 0; c < R; ++c) {
         const int j = j0 + c * 64 + (int)lane;
         s[c] = e[c] = 0;
-        if (j < nk) bucket_range(a, x, xb, xLen, km[c], s[c], e[c]);
+        if (j < nk) {
+          if (LDSIDX) { s[c] = sb[km[c]]; e[c] = sb[km[c] + 1]; }
+          else bucket_range(a, x, xb, xLen, km[c], s[c], e[c]);
+        }
       }
       uint32_t pa[R], pb[R], pc[R], pd[R];  // the first four entries of each bucket (the index has 4 words of slack)
 #pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
-        const uint32_t* q4 = pos + s[c];
-        pa[c] = q4[0]; pb[c] = q4[1]; pc[c] = q4[2]; pd[c] = q4[3];
+        if (LDSIDX) {
+          const uint16_t* q4 = sp + s[c];
+          pa[c] = q4[0]; pb[c] = q4[1]; pc[c] = q4[2]; pd[c] = q4[3];
+        } else {
+          const uint32_t* q4 = pos + s[c];
+          pa[c] = q4[0]; pb[c] = q4[1]; pc[c] = q4[2]; pd[c] = q4[3];
+        }
       }
 #pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
         if (n > 1) visit((int)pb[c] - j + yLen - 1);
         if (n > 2) visit((int)pc[c] - j + yLen - 1);
         if (n > 3) visit((int)pd[c] - j + yLen - 1);
-        for (uint32_t q = 4; q < n; ++q) visit((int)pos[s[c] + q] - j + yLen - 1);  // long buckets
+        for (uint32_t q = 4; q < n; ++q) visit((int)(LDSIDX ? (uint32_t)sp[s[c] + q] : pos[s[c] + q]) - j + yLen - 1);  // long buckets
       }
     }
   };
@@ -744,6 +748,47 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   }
   for (int o = 32; o; o >>= 1) nmem += __shfl_xor(nmem, o);
   if (lane == 0) a.pair_ndiag[pair] = nmem;
+}
+
+
+// One wavefront per (read, ref) pair, four pairs per workgroup; the index is gathered from global memory (any reference
+// set, explicit pair lists).
+__global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + wv;
+  if (pidx >= n_pairs) return;
+  const uint32_t pair = a.pair_base + pidx;
+  if (a.pair_skip && a.pair_skip[pair]) return;
+  uint32_t r, x;
+  pair_rx(a, pair, r, x);
+  seed_wave_pair<false>(a, pair, r, x, lds + (size_t)wv * wave_lds_words, nullptr, nullptr);
+}
+
+// Short references (k-mer index of one reference <= 48 KB as 16-bit entries): a workgroup of eight wavefronts copies one
+// reference's index to LDS and seeds kSeedReadsPerBlock reads against it.  The global-memory version spends two thirds
+// of its cycles waiting on L1 misses of those gathers (measured); here the only global traffic is the reads' k-mers.
+constexpr uint32_t kSeedReadsPerBlock = 64;
+__global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_reads, uint32_t wave_lds_words, uint32_t idx_words) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t x = blockIdx.x % a.n_refs, r0 = (blockIdx.x / a.n_refs) * kSeedReadsPerBlock;
+  const uint64_t xb = a.ref_off[x];
+  const uint32_t xLen = (uint32_t)(a.ref_off[x + 1] - xb), nb1 = a.nbuckets + 1;
+  uint16_t* sb = (uint16_t*)lds;
+  uint16_t* sp = sb + ((nb1 + 1) & ~1u);
+  const uint32_t* gb = a.ref_bucket + (uint64_t)x * nb1;
+  const uint32_t* gp = a.ref_pos + xb;
+  for (uint32_t q = threadIdx.x; q < nb1; q += 512) sb[q] = (uint16_t)gb[q];
+  for (uint32_t q = threadIdx.x; q < xLen + 4; q += 512) sp[q] = q < xLen ? (uint16_t)gp[q] : (uint16_t)0;
+  __syncthreads();
+  uint32_t* wlds = lds + idx_words + (size_t)wv * wave_lds_words;
+  for (uint32_t r = r0 + wv; r < min(r0 + kSeedReadsPerBlock, n_reads); r += 8) {
+    const uint32_t pair = a.pair_base + r * a.n_refs + x;
+    if (a.pair_skip && a.pair_skip[pair]) continue;
+    seed_wave_pair<true>(a, pair, r, x, wlds, sb, sp);
+    wave_lds_sync();
+  }
 }
 
 // Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
@@ -1802,6 +1847,18 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
     const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
     const uint32_t words = ((nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
     const size_t lds = (size_t)words * 4 * 4;
+    // LDS-resident index: bucket-indexed (k <= 8), implicit read x ref pair order, 16-bit positions, <= 48 KB
+    if (!a.pair_x && !a.ref_skeys && a.nbuckets && a.max_ref_len && a.max_ref_len + 4 < 65536 && !a.dump_cover && !a.no_lds_index) {
+      const uint32_t idx_words = (((a.nbuckets + 2) & ~1u) + ((a.max_ref_len + 5) & ~1u)) / 2;
+      const size_t lds2 = ((size_t)idx_words + (size_t)words * 8) * 4;
+      if ((size_t)idx_words * 4 <= 48 * 1024 && lds2 <= 80 * 1024 && n_pairs % a.n_refs == 0) {
+        const uint32_t n_reads = n_pairs / a.n_refs;
+        const uint32_t blocks = ((n_reads + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock) * a.n_refs;
+        if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(k_seed_wave_lds, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
+        return 0;
+      }
+    }
     if (lds <= 150 * 1024) {
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_seed_wave, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);

@@ -64,6 +64,8 @@ struct SeedArgs {
   uint32_t* ws;                // global-memory seeding workspaces (sequences too long for the LDS histogram)
   uint64_t ws_words;           // 4-byte words per workspace
   uint32_t ws_slots;
+  uint32_t max_ref_len;        // longest reference (0: unknown / not a reference set)
+  int no_lds_index;            // 1: never copy the reference index to LDS (debug / A-B)
   const uint8_t* pair_skip;    // optional [n_pairs]: 1 = do not seed this pair (train: pruned references)
   int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
   int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
