@@ -4,6 +4,8 @@
 // reference's scalar code does.  See DESIGN.md for the layout and the roofline of each kernel.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "qf_kernels.hpp"
 
 namespace qf {
@@ -1090,20 +1092,23 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
 #ifndef QF_FILL2_OCC
 #define QF_FILL2_OCC
 #endif
-template <int G>
-__device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf in the group's lane 0
+// ZERO: the group's edge lane receives 0.0 (both dwords zero-filled by bound_ctrl) instead of -inf
+template <int G, bool ZERO>
+__device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf (or 0) in the group's lane 0
   constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
   const long long bits = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
-  const int hi = __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
+                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-template <int G>
-__device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf in the group's last lane
+template <int G, bool ZERO>
+__device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf (or 0) in the group's last lane
   constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
   const long long bits = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
-  const int hi = __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
+                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
@@ -1192,7 +1197,15 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
   // Slots above the band's last diagonal read a -inf emission instead: their match and insert states stay -inf, and
   // the delete state they pick up from inside the band never reaches a valid cell.
   const uint32_t ninf_off = a.dp.ematch_ninf_off;
+  // LDS tables are addressed by their 32-bit LDS offset (the table base folded into the per-step row offset)
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  const uint32_t em_base = EMLDS ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)lds_tab : 0u;
   auto emis = [&](uint32_t w, uint32_t window, int b) -> double {
+    if (EMLDS) {  // em_base is 32-byte aligned (dynamic LDS starts at 0; rows are 32 bytes), so the or below is an add
+      uint32_t off = (((w & 0x7FFFu) << 5) + em_base) | (((window >> (2 * b)) & 3u) << 3);
+      if (b > bmax) off = ninf_off + em_base;
+      return *(lds_cdouble*)(uintptr_t)off;
+    }
     uint32_t off = ((w & 0x7FFFu) << 5) | (((window >> (2 * b)) & 3u) << 3);
     if (b > bmax) off = ninf_off;
     return *(const double*)((const char*)ematch + off);
@@ -1204,6 +1217,22 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
 #pragma unroll
   for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b);
 
+  // Steps are specialised four at a time (one traceback tile).  A FAST tile has no lane on its first or last read column
+  // and no lane whose lowest row is above reference row 1; the wave-uniform bounds below are conservative:
+  //   [0, slowA]      some lane is on column 1 or still has rows above row 1
+  //   [slowB0, slowB1] some lane is on its last column
+  int slowA = active ? max(l, l - d0 - 1) : -1, slowB0 = active ? yLen + l - 1 : 0x7FFFFFFF, slowB1 = active ? yLen + l - 1 : -1;
+  for (int o = 32; o; o >>= 1) {
+    slowA = max(slowA, __shfl_xor(slowA, o));
+    slowB0 = min(slowB0, __shfl_xor(slowB0, o));
+    slowB1 = max(slowB1, __shfl_xor(slowB1, o));
+  }
+  slowA = __builtin_amdgcn_readfirstlane(slowA);
+  slowB0 = __builtin_amdgcn_readfirstlane(slowB0);
+  slowB1 = __builtin_amdgcn_readfirstlane(slowB1);
+  // lane 0 of a group: in FAST tiles the exchange from below zero-fills it and these constants turn the zero into -inf
+  const double m2dEdge = l == 0 ? QF_NEG_INF : c_m2d, d2dEdge = l == 0 ? QF_NEG_INF : d2d;
+
   int chunk = 0;
   for (int t0 = 0; t0 < T; t0 += 16, ++chunk) {
     xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
@@ -1212,8 +1241,11 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
       const U32x4 cw = cwn;
       cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
       U32x4 tile;   // this lane's traceback words of the four steps (one 16-byte store)
+      const int ts = t0 + s4;
+      const bool tileFast = (ts > slowA && ts + 3 < slowB0) || ts > slowB1;   // wave-uniform
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        const bool SLOW = !tileFast;
         const int t = t0 + s4 + s;
         const int j = t - l + 1;
         const bool colvalid = active && j >= 1 && j <= yLen;
@@ -1246,29 +1278,28 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
         } else {
           m2m = c_m2m; m2i = c_m2i; m2d = c_m2d;
         }
-        const double lowM = dpp_from_below<G>(pubM), lowD = dpp_from_below<G>(pubD);
-
-        // a lane needs the general step on its first / last column and while its lowest row is above row 1
-        const bool needSlow = active & ((j == 1) | (j == yLen) | ((j > 1) & (j < yLen) & (d0 + j < 1)));
         uint32_t tbw0 = 0, tbw1 = 0;
         double upM = 0, upI = 0;
-        double prevM = lowM, prevD = lowD;
-        if (!__builtin_amdgcn_ballot_w64(needSlow)) {
+        if (!SLOW) {
           // ---------------- FAST step
-          // flags are shifted in as raw compare bits, one v_addc each (first slot ends up highest, bits I>M, D>max(M,I),
+          // Lane exchange zero-fills the group's edge lanes; the edge constants (-inf there) make the sums -inf.
+          // Flags are shifted in as raw compare bits, one v_addc each (first slot ends up highest, bits I>M, D>max(M,I),
           // ins-from-I, del-from-D from the top of its nibble); a bit reverse restores "slot b at nibble b" with the usual
           // bit order.  Match source "I>M and D>max" reads as 3, which the traceback takes as D away from column 1.
+          constexpr bool EDGE = !GAPCTX;   // with gap contexts the transition scores change per step: keep the -inf fill
+          double prevM = EDGE ? dpp_from_below<G, true>(pubM) : dpp_from_below<G, false>(pubM);
+          double prevD = EDGE ? dpp_from_below<G, true>(pubD) : dpp_from_below<G, false>(pubD);
           uint32_t acc0 = 0, acc1 = 0;
 #pragma unroll
           for (int b = 0; b < B; ++b) {
             const double tM = (M[b] + m2m) + e[b], tI = (I[b] + i2m) + e[b], tD = (D[b] + d2m) + e[b];
             const double m1 = fmax(tM, tI);
             const double nm = fmax(m1, tD);
-            double srcM, srcI;
-            if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
-            const double cM = (srcM + m2i) + insE, cI = (srcI + i2i) + insE;
+            double cM, cI;
+            if (b + 1 < B) { cM = (M[b + 1] + m2i) + insE; cI = (I[b + 1] + i2i) + insE; }
+            else { cM = (upM + m2i) + insE; cI = (upI + i2i) + insE; }
             const double ni = fmax(cM, cI);
-            const double gM = prevM + m2d, gD = prevD + d2d;
+            const double gM = prevM + ((EDGE && b == 0) ? m2dEdge : m2d), gD = prevD + ((EDGE && b == 0) ? d2dEdge : d2d);
             const double ndl = fmax(gM, gD);
             uint32_t& acc = b < 8 ? acc0 : acc1;
 #if QF_EXP != 1
@@ -1279,12 +1310,17 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
 #endif
             M[b] = nm; I[b] = ni; D[b] = ndl;
             prevM = nm; prevD = ndl;
-            if (b == 0) { upM = dpp_from_above<G>(nm); upI = dpp_from_above<G>(ni); }
+            if (b == 0) {
+              upM = dpp_from_above<G, false>(nm);
+              upI = dpp_from_above<G, false>(ni);
+            }
           }
           tbw0 = __builtin_bitreverse32(acc0) >> (32 - 4 * (B < 8 ? B : 8));
           if (B > 8) tbw1 = __builtin_bitreverse32(acc1) >> (B > 8 ? 32 - 4 * (B - 8) : 0);
+          pubM = prevM; pubD = prevD;
         } else {
           // ---------------- general step (start candidate, end tracking, full validity masking)
+          double prevM = dpp_from_below<G, false>(pubM), prevD = dpp_from_below<G, false>(pubD);
           const bool startCol = j == 1, endCol = j == yLen;
 #pragma unroll
           for (int b = 0; b < B; ++b) {
@@ -1317,10 +1353,10 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
               const double ev = nm + (GAPCTX ? trans[3 * Kg + gk] : c_m2e);
               if (ev >= bestEnd) { bestEnd = ev; bestI = (uint32_t)i; }
             }
-            if (b == 0) { upM = dpp_from_above<G>(nm); upI = dpp_from_above<G>(ni); }
+            if (b == 0) { upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); }
           }
+          pubM = prevM; pubD = prevD;
         }
-        pubM = prevM; pubD = prevD;
         if (WPL == 1) tile.v[s] = tbw0;
         else if (colvalid) { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
       }
