@@ -285,6 +285,16 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "cells_per_launch": cls_cells[dom], "bytes_per_cell": BYTES_PER_CELL, "ms_per_launch": round(dom_ms, 4)}
+    if not a.serial_classes and len(cls_ms) > 1:
+        # In the timed region the fill classes run on concurrent streams, so the dominant kernel's event-bracketed duration
+        # includes the share of the GPU the other classes took.  One extra, untimed pass with the classes one after
+        # another gives the same kernel's duration alone (what rocprofv3 --stats shows for a serialised run).
+        scfg = Q.DPConfig(band_size=a.band, debug_flags=cfg.reserved | 4)
+        sres = ctx.align_resident(scfg, a.align_flags, raw=True)
+        iso_ms = float(sres.ms_fill_class[dom])
+        iso = BYTES_PER_CELL * cls_cells[dom] / (iso_ms * 1e-3) / 1e9
+        roofline["concurrent_classes"] = sorted(ctx.L.qf_fill_class_name(k).decode() for k in cls_ms if k != dom)
+        roofline["isolated"] = {"ms_per_launch": round(iso_ms, 4), "achieved": round(iso, 1), "frac": round(iso / HBM_PEAK_GBS, 4)}
 
     cpu = None
     if a.cpu_sample > 0:

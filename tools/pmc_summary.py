@@ -31,7 +31,7 @@ def main():
         print("%-70s launches %3d  fetch(raw) %12.0f KiB  write %12.0f KiB  HBM/launch %8.3f GB" %
               (r["kernel"][:70], r["launches"], r["fetch_kib_raw"], r["write_kib"], r["hbm_bytes_per_launch"] / 1e9))
     if len(sys.argv) > 3:
-        dom = next(r for r in rows if "k_viterbi_fill<16, 5" in r["kernel"])
+        dom = next(r for r in rows if "k_viterbi_fill2<16, 5" in r["kernel"] or "k_viterbi_fill<16, 5" in r["kernel"])
         json.dump({"kernel": "k_viterbi_fill<16,5>", "reads": int(sys.argv[4]), "read_len": int(sys.argv[5]),
                    "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"], "fetch_kib_raw": dom["fetch_kib_raw"],
                    "write_kib": dom["write_kib"],
