@@ -113,17 +113,17 @@ __host__ __device__ inline uint64_t row_ov_words(int dlo, int dhi, int xLen, int
   return w;
 }
 // traceback words a unit occupies
-// One-word classes (B <= 8) keep the words of four consecutive steps of a fill lane together ([step/4][lane][step%4]): the
-// fill stores 16 bytes per lane every four steps and a traceback, which follows one lane for many steps, touches a quarter
-// of the cache lines a step-major layout would make it touch.
+// One-word classes (B <= 8) keep the words of eight consecutive steps of a fill lane together ([step/8][lane][step%8]): the
+// fill stores 16 bytes per lane every four steps (one half of the lane's 32-byte slot) and a traceback, which follows one
+// lane for many steps, reads one 128-byte line per eight moves instead of one per move.
 __host__ __device__ inline uint64_t tb_word_index(int t, int l, int G) {
-  return ((uint64_t)(t >> 2) * G + l) * 4 + (t & 3);
+  return ((uint64_t)(t >> 3) * G + l) * 8 + (t & 7);
 }
 __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   if (cls == 0) return (yLen + 7) / 8;
   const FillClass fc = fill_class(cls);
   if (fc.B > 8) return (uint64_t)(yLen + fc.G - 1) * fc.G * 2;
-  return (uint64_t)((yLen + fc.G - 1 + 3) & ~3u) * fc.G;
+  return (uint64_t)((yLen + fc.G - 1 + 7) & ~7u) * fc.G;
 }
 
 // Forward-matrix doubles a unit occupies (3 states x B slots x G lanes per step); single-diagonal bands run on

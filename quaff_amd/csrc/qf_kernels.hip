@@ -1666,7 +1666,7 @@ __global__ void k_select(FinalArgs a) {
 #define QF_TB_LANES 32
 #endif
 constexpr uint32_t kTbLanes = QF_TB_LANES;  // alignments per wavefront: few, so that many wavefronts interleave on a SIMD
-constexpr int kTbStride = 37;  // 3 lanes x 3 tiles x 4 words per lane in LDS (odd stride: conflict-free)
+constexpr int kTbStride = 49;  // 3 lanes x 2 tiles x 8 words per lane in LDS (odd stride: conflict-free)
 // WINDOWED = true handles the alignments of the one-word diagonal classes (everything a banded run produces), false the
 // rest (single diagonals, row-space units, two-word classes) with one dependent load per move; each alignment is taken
 // by exactly one of the two launches.
@@ -1726,15 +1726,17 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
     if (live) { const int dd = (i - j) - u.dlo; l = dd / B; b = dd % B; }
     while (__builtin_amdgcn_ballot_w64(walking())) {
       if (walking() && i >= 1 && j >= 1) {
-        cl = l; ct = (j - 1 + l) >> 2;   // window: tiles ct, ct-1, ct-2 (12 steps) of fill lanes cl-1, cl, cl+1
+        cl = l; ct = (j - 1 + l) >> 3;   // window: tiles ct, ct-1 (16 steps) of fill lanes cl-1, cl, cl+1
 #pragma unroll
         for (int dl = 0; dl < 3; ++dl) {
           const int ll = min(max(cl - 1 + dl, 0), G - 1);
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const U32x4 v = *(const U32x4*)(tb + ((uint64_t)max(ct - q, 0) * G + ll) * 4);
-            uint32_t* dst = win + (dl * 3 + q) * 4;
-            dst[0] = v.v[0]; dst[1] = v.v[1]; dst[2] = v.v[2]; dst[3] = v.v[3];
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t* src = tb + ((uint64_t)max(ct - q, 0) * G + ll) * 8;
+            const U32x4 v0 = *(const U32x4*)src, v1 = *(const U32x4*)(src + 4);
+            uint32_t* dst = win + (dl * 2 + q) * 8;
+            dst[0] = v0.v[0]; dst[1] = v0.v[1]; dst[2] = v0.v[2]; dst[3] = v0.v[3];
+            dst[4] = v1.v[0]; dst[5] = v1.v[1]; dst[6] = v1.v[2]; dst[7] = v1.v[3];
           }
         }
       }
@@ -1745,8 +1747,8 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
         if (!walking()) continue;
         uint32_t nib = 0;
         if (i >= 1 && j >= 1) {
-          const int t = j - 1 + l, dl = l - cl + 1, q = ct - (t >> 2);
-          if ((unsigned)dl < 3u && (unsigned)q < 3u) nib = (win[(dl * 3 + q) * 4 + (t & 3)] >> (4 * b)) & 0xFu;
+          const int t = j - 1 + l, dl = l - cl + 1, q = ct - (t >> 3);
+          if ((unsigned)dl < 3u && (unsigned)q < 2u) nib = (win[(dl * 2 + q) * 8 + (t & 7)] >> (4 * b)) & 0xFu;
           else nib = (tb[tb_word_index(max(t, 0), min(max(l, 0), G - 1), G)] >> (4 * b)) & 0xFu;   // left the window (rare)
         }
         int db;
