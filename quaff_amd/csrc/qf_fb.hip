@@ -13,6 +13,9 @@
 namespace qf {
 
 #define QF_NEG_INF (-__builtin_huge_val())
+#ifndef QF_FB_EXP
+#define QF_FB_EXP 0
+#endif
 
 // log_sum_exp, src/logsumexp.cpp:34-50 + log_sum_exp_unary :84-103 (x >= 10, NaN, inf -> 0).
 // n = (int)(x / 1e-4) is evaluated as x * 1e4: at worst the neighbouring interval of the same piecewise-
@@ -23,9 +26,18 @@ __device__ __forceinline__ double lse2(const double* __restrict__ tab, double a,
   if (!(diff < 10.0)) return a == b ? mx + tab[0] : mx;
   const int n = (int)(diff * 10000.0);
   const double dx = diff - n * .0001;
+#if QF_FB_EXP == 1
+  const double f0 = 0.3, f1 = 0.31;
+#else
   const double f0 = tab[n], f1 = tab[n + 1];
+#endif
   return mx + (f0 + (f1 - f0) * (dx * 10000.0));
 }
+
+// Expected counts are compared at 1e-4 relative: their exponential goes through the single-precision hardware exp2
+// (relative error ~1e-7 for the terms that matter, |x| of a few units; <= 1e-5 for the negligible ones near underflow;
+// below ~-87 the count flushes to 0).  The double-precision software exp was ~250 of Backward's ~300 VALU per cell.
+__device__ __forceinline__ double count_exp(double x) { return (double)__expf((float)x); }
 
 template <int G, int B>
 __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
@@ -198,6 +210,10 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
   constexpr int UPW = 64 / G;
   constexpr int RING = 2 * G;      // per-unit ring of per-column count partials (8 doubles each)
   __shared__ double s_ring[4][UPW][RING][8];
+  // context-dependent transition counts (m2m / m2i / m2d by indel context): a handful of addresses that every column of
+  // every band would hit with a global atomic; they are summed per wavefront in LDS (registers when there is one context)
+  // and flushed once at the end
+  extern __shared__ double s_tr_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int grp = lane / G, l = lane % G, rl = G - 1 - l;
@@ -221,6 +237,8 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   if (T == 0) return;
+  double* s_tr = s_tr_all + (size_t)wv * 3 * a.dp.Kg;
+  if (a.dp.Kg > 1) for (uint32_t c = lane; c < 3 * a.dp.Kg; c += 64) s_tr[c] = 0.0;
   double (*ring)[8] = s_ring[wv][grp];
   for (int c = l; c < RING * 8; c += G) (&ring[0][0])[c] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -245,6 +263,7 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
   for (int b = 0; b < B; ++b) Bm[b] = Bi[b] = Bd[b] = QF_NEG_INF;
   double pubD = QF_NEG_INF;     // slot 0's del after this lane's latest step (for lane l-1)
   double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
+  double acc_m2m = 0, acc_m2i = 0, acc_m2d = 0;   // Kg == 1 only
   uint32_t wNext = 0;           // context word of column j+1 (this lane's previous step)
   uint32_t gkEnd = 0;
 
@@ -291,20 +310,20 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
         const uint64_t base = ((uint64_t)(j - 1 + l) * B + b) * 3 * G + l;
         const double Fm = fw[base] - Fres, Fi = fw[base + G] - Fres, Fd = fw[base + 2 * G] - Fres;
         // NB (F - Fres) + T differs from the reference's (F + T) - Fres only in rounding
-        const double c_mm = wgt * exp(Fm + T_mm), c_im = wgt * exp(Fi + T_im), c_dm = wgt * exp(Fd + T_dm);
-        const double c_mi = wgt * exp(Fm + T_mi), c_ii = wgt * exp(Fi + T_ii);
-        const double c_md = wgt * exp(Fm + T_md), c_dd = wgt * exp(Fd + T_dd);
+        const double c_mm = wgt * count_exp(Fm + T_mm), c_im = wgt * count_exp(Fi + T_im), c_dm = wgt * count_exp(Fd + T_dm);
+        const double c_mi = wgt * count_exp(Fm + T_mi), c_ii = wgt * count_exp(Fi + T_ii);
+        const double c_md = wgt * count_exp(Fm + T_md), c_dd = wgt * count_exp(Fd + T_dd);
         const double cmat = c_mm + c_im + c_dm;
         pc[0] += tokN == 0 ? cmat : 0.0; pc[1] += tokN == 1 ? cmat : 0.0;
         pc[2] += tokN == 2 ? cmat : 0.0; pc[3] += tokN == 3 ? cmat : 0.0;
         pc[4] += c_mi + c_ii;
         pc[5] += c_mm; pc[6] += c_mi; pc[7] += c_md;
         acc_i2m += c_im; acc_d2m += c_dm; acc_i2i += c_ii; acc_d2d += c_dd;
-        if (isEnd) acc_m2e += wgt * exp(Fm + T_me);
+        if (isEnd) acc_m2e += wgt * count_exp(Fm + T_me);
         if (j == 1 && (i == 1 || local)) {  // start -> mat(i,1), src/qmodel.cpp:1448-1454
           const uint32_t tok = xt[i - 1];
           const double S = ematch[(w & 0x7FFFu) * 4u + tok] + nbm;
-          const double cs = wgt * exp(S - Fres);
+          const double cs = wgt * count_exp(S - Fres);
           pc0[0] += tok == 0 ? cs : 0.0; pc0[1] += tok == 1 ? cs : 0.0;
           pc0[2] += tok == 2 ? cs : 0.0; pc0[3] += tok == 3 ? cs : 0.0;
           startv = lse2(tab, startv, S);
@@ -322,7 +341,13 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
     if (colvalid) {
       double* slot = ring[j & (RING - 1)];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+      for (int c = 0; c < 5; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+      if (Kg == 1) { acc_m2m += pc[5]; acc_m2i += pc[6]; acc_m2d += pc[7]; }
+      else {
+        if (pc[5] != 0.0) unsafeAtomicAdd(&s_tr[gk], pc[5]);
+        if (pc[6] != 0.0) unsafeAtomicAdd(&s_tr[Kg + gk], pc[6]);
+        if (pc[7] != 0.0) unsafeAtomicAdd(&s_tr[2 * Kg + gk], pc[7]);
+      }
       if (j == 1) {
         double* slot0 = ring[0];
 #pragma unroll
@@ -344,14 +369,8 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
             if (slot[tk] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)tk * Km + mk) * kNQualDev + q], slot[tk]);
           if (slot[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], slot[4]);
         }
-        if (jj >= 1) {
-          const uint32_t gs = ctx[jj - 1] >> 24;
-          if (slot[5] != 0.0) unsafeAtomicAdd(&cnt[cTr + gs], slot[5]);
-          if (slot[6] != 0.0) unsafeAtomicAdd(&cnt[cTr + Kg + gs], slot[6]);
-          if (slot[7] != 0.0) unsafeAtomicAdd(&cnt[cTr + 2 * Kg + gs], slot[7]);
-        }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) slot[c] = 0.0;
+        for (int c = 0; c < 5; ++c) slot[c] = 0.0;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -363,8 +382,18 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
     acc_i2m += __shfl_xor(acc_i2m, o, G); acc_d2m += __shfl_xor(acc_d2m, o, G);
     acc_i2i += __shfl_xor(acc_i2i, o, G); acc_d2d += __shfl_xor(acc_d2d, o, G);
     acc_m2e += __shfl_xor(acc_m2e, o, G);
+    acc_m2m += __shfl_xor(acc_m2m, o, G); acc_m2i += __shfl_xor(acc_m2i, o, G); acc_m2d += __shfl_xor(acc_m2d, o, G);
     startv = lse2(tab, startv, __shfl_xor(startv, o, G));
     gkEnd = max(gkEnd, (uint32_t)__shfl_xor((int)gkEnd, o, G));
+  }
+  if (Kg > 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t c = lane; c < 3 * Kg; c += 64) if (s_tr[c] != 0.0) unsafeAtomicAdd(&cnt[cTr + c], s_tr[c]);
+  } else if (active && l == 0) {
+    if (acc_m2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 0], acc_m2m);
+    if (acc_m2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 1], acc_m2i);
+    if (acc_m2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 2], acc_m2d);
   }
   if (active && l == 0) {
     if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], acc_m2e);
@@ -504,6 +533,7 @@ __global__ __launch_bounds__(64) void k_forward_rows(FbArgs a) {
 __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   constexpr int G = 64, B = 8, S = kRowStripe, RING = 2 * G;
   __shared__ double ring[RING][8];
+  extern __shared__ double s_tr[];   // [3 * Kg] context-dependent transition counts of this unit
   const uint32_t uidx = blockIdx.x;
   if (uidx >= a.n_cls_units) return;
   const int l = threadIdx.x, rl = G - 1 - l;
@@ -522,6 +552,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   const double* __restrict__ cells = base + row_fw_header(g, yLen);
   const size_t bndStride = 2ull * (yLen + 2);
   for (int c = l; c < RING * 8; c += 64) (&ring[0][0])[c] = 0.0;
+  for (uint32_t c = l; c < 3 * a.dp.Kg; c += 64) s_tr[c] = 0.0;
   for (size_t c = l; c < 2 * bndStride; c += 64) bnd[c] = QF_NEG_INF;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
   __builtin_amdgcn_wave_barrier();
@@ -601,9 +632,9 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
         if (valid) {
           const unsigned long long at = woff + (((unsigned long long)(j - jlo + l) * B + b) * 3) * G + l;
           const double Fm = cells[at] - Fres, Fi = cells[at + G] - Fres, Fd = cells[at + 2 * G] - Fres;
-          const double c_mm = wgt * exp(Fm + T_mm), c_im = wgt * exp(Fi + T_im), c_dm = wgt * exp(Fd + T_dm);
-          const double c_mi = wgt * exp(Fm + T_mi), c_ii = wgt * exp(Fi + T_ii);
-          const double c_md = wgt * exp(Fm + T_md), c_dd = wgt * exp(Fd + T_dd);
+          const double c_mm = wgt * count_exp(Fm + T_mm), c_im = wgt * count_exp(Fi + T_im), c_dm = wgt * count_exp(Fd + T_dm);
+          const double c_mi = wgt * count_exp(Fm + T_mi), c_ii = wgt * count_exp(Fi + T_ii);
+          const double c_md = wgt * count_exp(Fm + T_md), c_dd = wgt * count_exp(Fd + T_dd);
           const double cmat = c_mm + c_im + c_dm;
           const uint32_t tokN = tkN[b];
           pc[0] += tokN == 0 ? cmat : 0.0; pc[1] += tokN == 1 ? cmat : 0.0;
@@ -611,11 +642,11 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
           pc[4] += c_mi + c_ii;
           pc[5] += c_mm; pc[6] += c_mi; pc[7] += c_md;
           acc_i2m += c_im; acc_d2m += c_dm; acc_i2i += c_ii; acc_d2d += c_dd;
-          if (isEnd) acc_m2e += wgt * exp(Fm + T_me);
+          if (isEnd) acc_m2e += wgt * count_exp(Fm + T_me);
           if (j == 1 && (i == 1 || local)) {
             const uint32_t tok = b > 0 ? tkN[b - 1] : tk0;
             const double Sv = ematch[(w & 0x7FFFu) * 4u + tok] + nbm;
-            const double cs = wgt * exp(Sv - Fres);
+            const double cs = wgt * count_exp(Sv - Fres);
             pc0[0] += tok == 0 ? cs : 0.0; pc0[1] += tok == 1 ? cs : 0.0;
             pc0[2] += tok == 2 ? cs : 0.0; pc0[3] += tok == 3 ? cs : 0.0;
             startv = lse2(tab, startv, Sv);
@@ -631,7 +662,10 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
       if (colvalid) {
         double* slot = ring[j & (RING - 1)];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+        for (int c = 0; c < 5; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+        if (pc[5] != 0.0) unsafeAtomicAdd(&s_tr[gk], pc[5]);
+        if (pc[6] != 0.0) unsafeAtomicAdd(&s_tr[Kg + gk], pc[6]);
+        if (pc[7] != 0.0) unsafeAtomicAdd(&s_tr[2 * Kg + gk], pc[7]);
         if (j == 1) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) if (pc0[c] != 0.0) unsafeAtomicAdd(&ring[0][c], pc0[c]);
@@ -651,14 +685,8 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
               if (slot[tk] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)tk * Km + mk) * kNQualDev + q], slot[tk]);
             if (slot[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], slot[4]);
           }
-          if (jj >= 1) {
-            const uint32_t gs = ctx[jj - 1] >> 24;
-            if (slot[5] != 0.0) unsafeAtomicAdd(&cnt[cTr + gs], slot[5]);
-            if (slot[6] != 0.0) unsafeAtomicAdd(&cnt[cTr + Kg + gs], slot[6]);
-            if (slot[7] != 0.0) unsafeAtomicAdd(&cnt[cTr + 2 * Kg + gs], slot[7]);
-          }
 #pragma unroll
-          for (int c = 0; c < 8; ++c) slot[c] = 0.0;
+          for (int c = 0; c < 5; ++c) slot[c] = 0.0;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -673,6 +701,9 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
     acc_m2e += __shfl_xor(acc_m2e, o, G);
     startv = lse2(tab, startv, __shfl_xor(startv, o, G));
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t c = l; c < 3 * Kg; c += 64) if (s_tr[c] != 0.0) unsafeAtomicAdd(&cnt[cTr + c], s_tr[c]);
   if (l == 0) {
     if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], acc_m2e);
     if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], acc_d2d);
@@ -692,7 +723,7 @@ static void launch_fwd_gb(const FbArgs& a, hipStream_t s) {
 template <int G, int B>
 static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL((k_backward_fill<G, B>), dim3(blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_backward_fill<G, B>), dim3(blocks), dim3(256), (size_t)4 * 3 * a.dp.Kg * 8, s, a);
 }
 #define QF_FB_DISPATCH(FN)                         \
   switch (cls) {                                   \
@@ -716,7 +747,7 @@ void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
 }
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
-  if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); return; }
+  if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), (size_t)3 * a.dp.Kg * 8, s, a); return; }
   QF_FB_DISPATCH(launch_bwd_gb)
 }
 void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s) {
