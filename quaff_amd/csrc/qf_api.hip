@@ -179,6 +179,8 @@ struct qf_ctx : Slot {
     }                                                                                           \
   } while (0)
 
+constexpr size_t kLseHermiteOffset = 100002;  // doubles: the exact table (100001) padded to even, then the spline nodes
+
 static int fail(Slot* c, int code, const std::string& msg) {
   c->err = msg;
   return code;
@@ -1037,6 +1039,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
   fa.fw = c->d_fw.as<double>();
   fa.lse = c->d_lse.as<double>();
+  fa.lse_h = c->d_lse.as<double>() + kLseHermiteOffset;
   fa.dp.ematch = c->d_ematch.as<double>();
   fa.dp.ematch_ninf_off = (uint32_t)((size_t)c->scores.Km * kNQ1 * 4 * 8);
   fa.dp.eins = c->d_eins.as<double>();
@@ -1139,7 +1142,13 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   const bool sparse = cfg->sparse != 0;
   if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
   if (!c->lse_uploaded) {
-    const std::vector<double>& t = lse_table();
+    std::vector<double> t = lse_table();
+    t.resize(kLseHermiteOffset, 0.0);
+    for (int k = 0; k <= 640; ++k) {   // Hermite nodes of log(1 + exp(-x)) on a 1/64 grid: value, slope
+      const double x = k / 64.0;
+      t.push_back(std::log1p(std::exp(-x)));
+      t.push_back(-1.0 / (1.0 + std::exp(x)));
+    }
     HIPCHK(c, c->d_lse.reserve(t.size() * 8));
     HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
     c->lse_uploaded = true;
@@ -1234,7 +1243,13 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
 // ------------------------------------------------------------------------------ read-vs-read overlap
 static int ensure_lse(qf_ctx* c) {
   if (c->lse_uploaded) return QF_OK;
-  const std::vector<double>& t = lse_table();
+  std::vector<double> t = lse_table();
+  t.resize(kLseHermiteOffset, 0.0);
+  for (int k = 0; k <= 640; ++k) {
+    const double x = k / 64.0;
+    t.push_back(std::log1p(std::exp(-x)));
+    t.push_back(-1.0 / (1.0 + std::exp(x)));
+  }
   HIPCHK(c, c->d_lse.reserve(t.size() * 8));
   HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
   c->lse_uploaded = true;
