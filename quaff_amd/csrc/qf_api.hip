@@ -1053,6 +1053,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.pair_fwd = c->d_pair_score.as<double>();
   fa.pair_weight = c->d_weight.as<double>();
   fa.counts = c->d_counts.as<double>();
+  fa.counts_stride = (csize + 31) & ~31ull;
   fa.Km = sc.Km;
   for (int cls = kNumClasses - 1; cls >= 1; --cls) {
     fa.n_cls_units = bc.cls_count[cls];
@@ -1184,8 +1185,9 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
     if (int rc = read_counters(c, pb)) return rc;
     if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
   }
-  HIPCHK(c, c->d_counts.reserve((size_t)csize * 8));
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)csize * 8, c->stream));
+  const size_t counts_stride = (csize + 31) & ~(size_t)31;
+  HIPCHK(c, c->d_counts.reserve(counts_stride * kCountReplicas * 8));
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, counts_stride * kCountReplicas * 8, c->stream));
   c->h_fwd.resize(n_pairs);
   c->h_weight.resize(n_pairs);
   c->h_rll.resize(n_reads);
@@ -1207,7 +1209,10 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
       todo.push_back({lo, mid});
     }
   }
-  HIPCHK(c, hipMemcpy(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost));
+  launch_sum_count_replicas(c->d_counts.as<double>(), csize, counts_stride, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   const Scores& sc = c->scores;
 
   // QuaffParamCounts(const QuaffCounts&), src/qmodel.cpp:407-417 (linear, so it commutes with the weighted sum)

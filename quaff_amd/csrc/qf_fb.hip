@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
   const double* __restrict__ fw = a.fw + fw_off;
-  double* __restrict__ cnt = a.counts;
+  double* __restrict__ cnt = a.counts + (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // contention: see kCountReplicas
   const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
 
   double Bm[B], Bi[B], Bd[B];   // Backward values of this lane's diagonals at the column of its previous step
@@ -384,21 +384,22 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (colvalid && l == 0) {  // rl = G-1: the last lane of the unit to process column j
-      for (int jj = j; jj >= (j == 1 ? 0 : j); --jj) {
-        double* slot = ring[jj & (RING - 1)];
-        // emission rows belong to the destination column jj+1; transition contexts to the source column jj
-        const uint32_t wd = ctx[jj];  // context word of column jj+1 (index jj); jj == yLen has no destination
-        const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
-        const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
-        if (QF_FB_EXP != 2 && jj < yLen && q < (uint32_t)kNQualDev) {
-#pragma unroll
-          for (int tk = 0; tk < 4; ++tk)
-            if (slot[tk] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)tk * Km + mk) * kNQualDev + q], slot[tk]);
-          if (slot[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], slot[4]);
+    {
+      // Column j0 = j + l is the one the unit's lane 0 (the last to get there) has just processed: its partials are
+      // complete.  Lanes 0..4 flush one value each (four match-by-token, insert); column 1 also flushes "column 0".
+      const int j0 = j + l;
+      if (active && j0 >= 1 && j0 <= yLen && l < 5) {
+        for (int jj = j0; jj >= (j0 == 1 ? 0 : j0); --jj) {
+          double* slot = ring[jj & (RING - 1)];
+          // emission rows belong to the destination column jj+1 (context word index jj); jj == yLen has no destination
+          const uint32_t wd = ctx[jj];
+          const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+          const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
+          const double v = slot[l];
+          if (QF_FB_EXP != 2 && jj < yLen && q < (uint32_t)kNQualDev && v != 0.0)
+            unsafeAtomicAdd(&cnt[l < 4 ? cMat + ((uint64_t)l * Km + mk) * kNQualDev + q : cIns + (uint64_t)ytok * kNQualDev + q], v);
+          slot[l] = 0.0;
         }
-#pragma unroll
-        for (int c = 0; c < 5; ++c) slot[c] = 0.0;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   const bool local = a.dp.local != 0;
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
-  double* __restrict__ cnt = a.counts;
+  double* __restrict__ cnt = a.counts + (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // contention: see kCountReplicas
   const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
   double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
   const uint32_t gkEnd = ctx[yLen - 1] >> 24;
@@ -707,20 +708,20 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (colvalid && l == 0) {  // lane 0 is the last of the stripe to process column j
-        for (int jj = j; jj >= (j == 1 ? 0 : j); --jj) {
-          double* slot = ring[jj & (RING - 1)];
-          const uint32_t wd = ctx[jj];
-          const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
-          const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
-          if (jj < yLen && q < (uint32_t)kNQualDev) {
-#pragma unroll
-            for (int tk = 0; tk < 4; ++tk)
-              if (slot[tk] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)tk * Km + mk) * kNQualDev + q], slot[tk]);
-            if (slot[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], slot[4]);
+      {
+        // column j0 = j + l: the one lane 0 (last of the stripe to get there) has just processed; lanes 0..4 flush it
+        const int j0 = j + l;
+        if (j0 >= jlo && j0 <= jhi && l < 5) {
+          for (int jj = j0; jj >= (j0 == 1 ? 0 : j0); --jj) {
+            double* slot = ring[jj & (RING - 1)];
+            const uint32_t wd = ctx[jj];
+            const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+            const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
+            const double v = slot[l];
+            if (jj < yLen && q < (uint32_t)kNQualDev && v != 0.0)
+              unsafeAtomicAdd(&cnt[l < 4 ? cMat + ((uint64_t)l * Km + mk) * kNQualDev + q : cIns + (uint64_t)ytok * kNQualDev + q], v);
+            slot[l] = 0.0;
           }
-#pragma unroll
-          for (int c = 0; c < 5; ++c) slot[c] = 0.0;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -783,6 +784,17 @@ void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
   if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), (size_t)3 * a.dp.Kg * 8, s, a); return; }
   QF_FB_DISPATCH(launch_bwd_gb)
+}
+// counts[0][i] += counts[1..R-1][i]
+__global__ void k_sum_count_replicas(double* counts, uint32_t n, uint64_t stride) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = counts[i];
+  for (int r = 1; r < kCountReplicas; ++r) v += counts[(size_t)r * stride + i];
+  counts[i] = v;
+}
+void launch_sum_count_replicas(double* counts, uint32_t n, uint64_t stride, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_sum_count_replicas, dim3((n + 255) / 256), dim3(256), 0, s, counts, n, stride);
 }
 void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s) {
   if (a.n_pairs) hipLaunchKernelGGL(k_pair_forward, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a, lse);

@@ -102,7 +102,8 @@ struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
   DpParams dp;
   const double* pair_fwd;      // [n_pairs] Forward result (Backward only)
   const double* pair_weight;   // [n_pairs] posterior weight, 0 = no Backward
-  double* counts;              // flattened weighted QuaffCounts accumulators
+  double* counts;              // flattened weighted QuaffCounts accumulators, kCountReplicas copies `counts_stride` apart
+  uint64_t counts_stride;
   uint32_t Km;
 };
 
@@ -185,6 +186,10 @@ void launch_pack_ref(const uint8_t* tok, const uint64_t* off, const uint64_t* wo
 void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, uint64_t max_len, uint32_t k,
                       uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s);
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s);
+// Emission counts of one read column go to the accumulator table with one global fp64 atomic each; workgroups spread over
+// this many copies of the table (summed at the end) so that popular (context, quality) entries are not serialised in L2.
+constexpr int kCountReplicas = 16;
+void launch_sum_count_replicas(double* counts, uint32_t n, uint64_t stride, hipStream_t s);
 size_t seed_lds_bytes(int max_nd, bool mem);
 bool seed_needs_workspace(const SeedArgs& a, bool mem);
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
