@@ -13,6 +13,9 @@
 namespace qf {
 
 #define QF_NEG_INF (-__builtin_huge_val())
+#ifndef QF_BWD_WAVES
+#define QF_BWD_WAVES 3
+#endif
 #ifndef QF_FB_EXP
 #define QF_FB_EXP 0
 #endif
@@ -50,15 +53,17 @@ __device__ __forceinline__ void lseh_load(double* s_h, const double* __restrict_
   for (int k = tid; k < 2 * kLseNodes; k += nthreads) s_h[k] = g_h[k];
 }
 __device__ __forceinline__ double lseh(const double* hs, double a, double b) {
-  const double mx = a > b ? a : b, mn = a > b ? b : a;
+  // branch-free: the spline is evaluated at a clamped argument and discarded when the cut-off (or -inf - -inf = NaN)
+  // applies, so the several calls of a cell overlap instead of each taking its own divergent branch
+  const double mx = fmax(a, b), mn = fmin(a, b);
   const double diff = mx - mn;
-  if (!(diff < 10.0)) return a == b ? mx + hs[0] : mx;
-  const double u = diff * 64.0;
+  const double u = fmin(diff * 64.0, 639.984375);   // NaN -> the bound
   const int n = (int)u;
   const double t = u - (double)n, s = 1.0 - t;
   const double g0 = hs[2 * n], d0 = hs[2 * n + 1], g1 = hs[2 * n + 2], d1 = hs[2 * n + 3];
   const double t2 = t * t, s2 = s * s;
-  return mx + ((g0 * (1.0 + 2.0 * t) + d0 * (t * (1.0 / 64.0))) * s2 + (g1 * (3.0 - 2.0 * t) - d1 * (s * (1.0 / 64.0))) * t2);
+  const double p = (g0 * (1.0 + 2.0 * t) + d0 * (t * (1.0 / 64.0))) * s2 + (g1 * (3.0 - 2.0 * t) - d1 * (s * (1.0 / 64.0))) * t2;
+  return mx + (diff < 10.0 ? p : (a == b ? hs[0] : 0.0));
 }
 
 template <int G, int B>
@@ -231,14 +236,12 @@ __global__ void k_count_plan(CountPlanArgs a) {
 // destination), and the expected count of each of those transitions is exp(F_src + term - F_result) — the same
 // operands, in the same association, as transCount (src/qmodel.cpp:1504-1510).
 template <int G, int B>
-__global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF_BWD_WAVES : 1))) void k_backward_fill(FbArgs a) {
   __shared__ double s_lseh[2 * kLseNodes];
   lseh_load(s_lseh, a.lse_h, threadIdx.x, 256);
   __syncthreads();
   const double* hs = s_lseh;
   constexpr int UPW = 64 / G;
-  constexpr int RING = 2 * G;      // per-unit ring of per-column count partials (8 doubles each)
-  __shared__ double s_ring[4][UPW][RING][8];
   // context-dependent transition counts (m2m / m2i / m2d by indel context): a handful of addresses that every column of
   // every band would hit with a global atomic; they are summed per wavefront in LDS (registers when there is one context)
   // and flushed once at the end
@@ -268,8 +271,6 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
   if (T == 0) return;
   double* s_tr = s_tr_all + (size_t)wv * 3 * a.dp.Kg;
   if (a.dp.Kg > 1) for (uint32_t c = lane; c < 3 * a.dp.Kg; c += 64) s_tr[c] = 0.0;
-  double (*ring)[8] = s_ring[wv][grp];
-  for (int c = l; c < RING * 8; c += G) (&ring[0][0])[c] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
   double pubD = QF_NEG_INF;     // slot 0's del after this lane's latest step (for lane l-1)
   double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
   double acc_m2m = 0, acc_m2i = 0, acc_m2d = 0;   // Kg == 1 only
+  double colsum[5] = {0, 0, 0, 0, 0};             // running match-by-token[4] / insert sums of the column this lane is on
   uint32_t wNext = 0;           // context word of column j+1 (this lane's previous step)
   uint32_t gkEnd = 0;
 
@@ -365,45 +367,45 @@ __global__ __launch_bounds__(256) void k_backward_fill(FbArgs a) {
       }
     }
     pubD = Bd[0];
-    // ---- per-column partials -> LDS ring; the last lane to touch a column flushes it
-    if (colvalid) {
-      double* slot = ring[j & (RING - 1)];
+    // ---- per-column partials travel with the column: lane l+1 was on column j one step ago and hands its running sums
+    // to lane l; the unit's lane 0 is the last on every column and flushes the complete sums (no LDS, no barriers)
+    {
+      double in[5];
 #pragma unroll
-      for (int c = 0; c < 5; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+      for (int c = 0; c < 5; ++c) {
+        in[c] = __shfl_down(colsum[c], 1, G);
+        if (l == G - 1) in[c] = 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < 5; ++c) colsum[c] = colvalid ? in[c] + pc[c] : 0.0;
+    }
+    if (colvalid) {
       if (Kg == 1) { acc_m2m += pc[5]; acc_m2i += pc[6]; acc_m2d += pc[7]; }
       else {
         if (pc[5] != 0.0) unsafeAtomicAdd(&s_tr[gk], pc[5]);
         if (pc[6] != 0.0) unsafeAtomicAdd(&s_tr[Kg + gk], pc[6]);
         if (pc[7] != 0.0) unsafeAtomicAdd(&s_tr[2 * Kg + gk], pc[7]);
       }
-      if (j == 1) {
-        double* slot0 = ring[0];
+      if (j == 1) {  // start -> mat(i,1): emission counts of column 1, once per lane
+        const uint32_t er = w & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+        if (q < (uint32_t)kNQualDev) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (pc0[c] != 0.0) unsafeAtomicAdd(&slot0[c], pc0[c]);
+          for (int c = 0; c < 4; ++c)
+            if (pc0[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], pc0[c]);
+        }
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    {
-      // Column j0 = j + l is the one the unit's lane 0 (the last to get there) has just processed: its partials are
-      // complete.  Lanes 0..4 flush one value each (four match-by-token, insert); column 1 also flushes "column 0".
-      const int j0 = j + l;
-      if (active && j0 >= 1 && j0 <= yLen && l < 5) {
-        for (int jj = j0; jj >= (j0 == 1 ? 0 : j0); --jj) {
-          double* slot = ring[jj & (RING - 1)];
-          // emission rows belong to the destination column jj+1 (context word index jj); jj == yLen has no destination
-          const uint32_t wd = ctx[jj];
-          const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
-          const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
-          const double v = slot[l];
-          if (QF_FB_EXP != 2 && jj < yLen && q < (uint32_t)kNQualDev && v != 0.0)
-            unsafeAtomicAdd(&cnt[l < 4 ? cMat + ((uint64_t)l * Km + mk) * kNQualDev + q : cIns + (uint64_t)ytok * kNQualDev + q], v);
-          slot[l] = 0.0;
+      if (l == 0 && j < yLen) {
+        // emission rows belong to the destination column j+1 (context word index j); column yLen has no destination
+        const uint32_t er = wNext & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+        const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
+        if (QF_FB_EXP != 2 && q < (uint32_t)kNQualDev) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (colsum[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], colsum[c]);
+          if (colsum[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], colsum[4]);
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
     wNext = w;
   }
   // context-free transitions, m2e and the Backward result (start), reduced over the unit's lanes
@@ -567,8 +569,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   lseh_load(s_lseh, a.lse_h, threadIdx.x, 64);
   __syncthreads();
   const double* hs = s_lseh;
-  constexpr int G = 64, B = 8, S = kRowStripe, RING = 2 * G;
-  __shared__ double ring[RING][8];
+  constexpr int G = 64, B = 8, S = kRowStripe;
   extern __shared__ double s_tr[];   // [3 * Kg] context-dependent transition counts of this unit
   const uint32_t uidx = blockIdx.x;
   if (uidx >= a.n_cls_units) return;
@@ -587,7 +588,6 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   double* bnd = base + (g.nStripes + 1);            // reused: [2][2][yLen+2] Backward mat / del of a stripe's first row
   const double* __restrict__ cells = base + row_fw_header(g, yLen);
   const size_t bndStride = 2ull * (yLen + 2);
-  for (int c = l; c < RING * 8; c += 64) (&ring[0][0])[c] = 0.0;
   for (uint32_t c = l; c < 3 * a.dp.Kg; c += 64) s_tr[c] = 0.0;
   for (size_t c = l; c < 2 * bndStride; c += 64) bnd[c] = QF_NEG_INF;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
@@ -627,6 +627,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
 #pragma unroll
     for (int b = 0; b < B; ++b) Bm[b] = Bi[b] = Bd[b] = QF_NEG_INF;
     double p1M = QF_NEG_INF, p1D = QF_NEG_INF, p2M = QF_NEG_INF;   // slot 0 after the previous / the one before
+    double colsum[5] = {0, 0, 0, 0, 0};
     uint32_t wNext = 0;
     const int steps = jhi - jlo + 1 + G - 1;
     for (int t = 0; t < steps; ++t) {
@@ -694,38 +695,39 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
       p2M = p1M;
       p1M = Bm[0]; p1D = Bd[0];
       if (colvalid && l == 0) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1D; }
-      if (colvalid) {
-        double* slot = ring[j & (RING - 1)];
+      {
+        double in[5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) if (pc[c] != 0.0) unsafeAtomicAdd(&slot[c], pc[c]);
+        for (int c = 0; c < 5; ++c) {
+          in[c] = __shfl_down(colsum[c], 1, G);
+          if (l == G - 1) in[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) colsum[c] = colvalid ? in[c] + pc[c] : 0.0;
+      }
+      if (colvalid) {
         if (pc[5] != 0.0) unsafeAtomicAdd(&s_tr[gk], pc[5]);
         if (pc[6] != 0.0) unsafeAtomicAdd(&s_tr[Kg + gk], pc[6]);
         if (pc[7] != 0.0) unsafeAtomicAdd(&s_tr[2 * Kg + gk], pc[7]);
         if (j == 1) {
+          const uint32_t er = w & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+          if (q < (uint32_t)kNQualDev) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) if (pc0[c] != 0.0) unsafeAtomicAdd(&ring[0][c], pc0[c]);
+            for (int c = 0; c < 4; ++c)
+              if (pc0[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], pc0[c]);
+          }
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      {
-        // column j0 = j + l: the one lane 0 (last of the stripe to get there) has just processed; lanes 0..4 flush it
-        const int j0 = j + l;
-        if (j0 >= jlo && j0 <= jhi && l < 5) {
-          for (int jj = j0; jj >= (j0 == 1 ? 0 : j0); --jj) {
-            double* slot = ring[jj & (RING - 1)];
-            const uint32_t wd = ctx[jj];
-            const uint32_t er = wd & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
-            const uint32_t ir = (wd >> 15) & 0x1FFu, ytok = ir / (kNQualDev + 1);
-            const double v = slot[l];
-            if (jj < yLen && q < (uint32_t)kNQualDev && v != 0.0)
-              unsafeAtomicAdd(&cnt[l < 4 ? cMat + ((uint64_t)l * Km + mk) * kNQualDev + q : cIns + (uint64_t)ytok * kNQualDev + q], v);
-            slot[l] = 0.0;
+        if (l == 0 && j < yLen) {
+          const uint32_t er = wNext & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+          const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
+          if (q < (uint32_t)kNQualDev) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (colsum[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], colsum[c]);
+            if (colsum[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], colsum[4]);
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
       wNext = w;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
