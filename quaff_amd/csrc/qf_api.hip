@@ -106,7 +106,11 @@ struct Slot {
     for (auto& e : ev) (void)hipEventCreate(&e);
     for (auto& e : cls_ev) (void)hipEventCreate(&e);
     for (auto& e : cls_end) (void)hipEventCreate(&e);
-    for (auto& s : aux) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    // side streams at the lowest priority: the small fill classes they carry should fill the gaps of the dominant class
+    // (main stream), not compete with it
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    for (auto& s : aux) (void)hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
     return 0;
   }
   void destroy() {
