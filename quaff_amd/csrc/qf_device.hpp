@@ -54,34 +54,39 @@ __host__ __device__ inline int classify_width(int W) {
   return kRowClass;
 }
 
-// Row-space geometry (class kRowClass): the band's rows [ilo, ihi] are cut into stripes of kRowStripe rows; stripe s
-// sweeps the columns [jlo, jhi] that its rows' band segments cover.
+// Row-space geometry (class kRowClass): the band's rows [ilo, ihi] are cut into stripes of S rows; stripe s sweeps the
+// columns [jlo, jhi] that its rows' band segments cover.  Forward/Backward and overlap run one wavefront per unit
+// (S = kRowStripe = 64 lanes x 8 rows); Viterbi runs a workgroup of kVitWaves wavefronts (S = kVitStripe).
 constexpr int kRowStripe = 64 * 8;
+constexpr int kVitWaves = 8;
+constexpr int kVitLanes = kVitWaves * 64;
+constexpr int kVitStripe = kVitLanes * 8;
 struct RowGeom { int ilo, ihi, nStripes; };
-__host__ __device__ inline RowGeom row_geom(int dlo, int dhi, int xLen, int yLen) {
+__host__ __device__ inline RowGeom row_geom(int dlo, int dhi, int xLen, int yLen, int S = kRowStripe) {
   RowGeom g;
   g.ilo = 1 + dlo > 1 ? 1 + dlo : 1;
   g.ihi = yLen + dhi < xLen ? yLen + dhi : xLen;
-  g.nStripes = g.ihi >= g.ilo ? (g.ihi - g.ilo + kRowStripe) / kRowStripe : 0;
+  g.nStripes = g.ihi >= g.ilo ? (g.ihi - g.ilo + S) / S : 0;
   return g;
 }
-__host__ __device__ inline void row_stripe_cols(const RowGeom& g, int s, int dlo, int dhi, int yLen, int& jlo, int& jhi) {
-  const int i0 = g.ilo + s * kRowStripe, i1 = i0 + kRowStripe - 1 < g.ihi ? i0 + kRowStripe - 1 : g.ihi;
+__host__ __device__ inline void row_stripe_cols(const RowGeom& g, int s, int dlo, int dhi, int yLen, int& jlo, int& jhi,
+                                                int S = kRowStripe) {
+  const int i0 = g.ilo + s * S, i1 = i0 + S - 1 < g.ihi ? i0 + S - 1 : g.ihi;
   jlo = i0 - dhi > 1 ? i0 - dhi : 1;
   jhi = i1 - dlo < yLen ? i1 - dlo : yLen;
 }
 // storage of a row-space unit, in 4-byte words: [ (nStripes+1) u64 stripe offsets | 2 boundary rows x 3 states x
-// (yLen+2) doubles | per stripe: steps x 64 traceback words ]
+// (yLen+2) doubles | per stripe: steps x lanes traceback words ]
 __host__ __device__ inline uint64_t row_header_words(const RowGeom& g, int yLen) {
   return 2ull * (g.nStripes + 1) + 2ull * 2 * 3 * (uint64_t)(yLen + 2);
 }
 __host__ __device__ inline uint64_t row_unit_words(int dlo, int dhi, int xLen, int yLen) {
-  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen, kVitStripe);
   uint64_t w = row_header_words(g, yLen);
   for (int s = 0; s < g.nStripes; ++s) {
     int jlo, jhi;
-    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
-    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + 63) * 64;
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi, kVitStripe);
+    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + kVitLanes - 1) * kVitLanes;
   }
   return w;
 }

@@ -1457,44 +1457,49 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Row-space Viterbi fill for bands wider than 1024 diagonals (-kmatchoff, or the full-envelope fallback of short
-// sequences against long references).  One wavefront per unit; the band's rows are cut into stripes of 64 lanes x 8
-// rows.  Lane l owns 8 consecutive rows and at step t is at column jlo + t - l, so
+// sequences against long references).  One workgroup of kVitWaves wavefronts per unit; the band's rows are cut into stripes
+// of 512 lanes x 8 rows.  Lane L (0..511) owns 8 consecutive rows and at step t is at column jlo + t - L, so
 //   ins(i,j) <- (i,  j-1): own registers (previous step)
-//   del(i,j) <- (i-1,j  ): own slot b-1 this step, or lane l-1's last row, which it finished one step ago
-//   mat(i,j) <- (i-1,j-1): own slot b-1 before this step's update, or lane l-1's last row two steps ago
-// The last row of a stripe is kept in a global boundary buffer for the next stripe (ping-pong).  Same arithmetic,
-// candidate order and 4-bit traceback records as k_viterbi_fill.
+//   del(i,j) <- (i-1,j  ): own slot b-1 this step, or lane L-1's last row, which it finished one step ago
+//   mat(i,j) <- (i-1,j-1): own slot b-1 before this step's update, or lane L-1's last row two steps ago
+// Inside a wavefront the neighbour's values come by shuffle; between wavefronts through a four-deep LDS ring (one
+// workgroup barrier per step).  The last row of a stripe is kept in a global boundary buffer for the next stripe
+// (ping-pong).  Same arithmetic, candidate order and 4-bit traceback records as k_viterbi_fill.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_viterbi_rows(FillArgs a) {
-  constexpr int G = 64, B = 8, S = kRowStripe;
+__global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
+  constexpr int G = kVitLanes, B = 8, S = kVitStripe, NW = kVitWaves;
+  __shared__ double s_x[NW][4][3];      // [wave][step & 3][M, I, D] of the wave's lane 63, last row
+  __shared__ double s_best[NW];
+  __shared__ uint32_t s_bi[NW];
   const uint32_t uidx = blockIdx.x;
   if (uidx >= a.n_cls_units) return;
-  const int l = threadIdx.x;
+  const int L = threadIdx.x, wv = L >> 6, l = L & 63;
   const uint32_t uid = a.cls_list[uidx];
   const Unit u = a.units[uid];
   const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
   const int dlo = u.dlo, dhi = u.dhi;
-  const RowGeom g = row_geom(dlo, dhi, xLen, yLen);
+  const RowGeom g = row_geom(dlo, dhi, xLen, yLen, S);
   uint32_t* base = a.tb + u.tb_off;
   unsigned long long* stripe_off = (unsigned long long*)base;                 // [nStripes+1]
   double* bnd = (double*)(base + 2ull * (g.nStripes + 1));                   // [2][3][yLen+2]
   uint32_t* tbw = base + row_header_words(g, yLen);
   const size_t bndStride = 3ull * (yLen + 2);
-  // stripe offsets (lane 0) and the row-0 boundary (-inf)
-  if (l == 0) {
+  // stripe offsets (thread 0) and the row-0 boundary (-inf)
+  if (L == 0) {
     unsigned long long w = 0;
     for (int s = 0; s < g.nStripes; ++s) {
       int jlo, jhi;
-      row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
+      row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi, S);
       stripe_off[s] = w;
-      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + 63) * 64;
+      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + G - 1) * G;
     }
     stripe_off[g.nStripes] = w;
   }
-  for (size_t c = l; c < bndStride; c += 64) bnd[c] = QF_NEG_INF;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  for (size_t c = L; c < bndStride; c += G) bnd[c] = QF_NEG_INF;
+  __threadfence();
+  __syncthreads();
 
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
   const double* __restrict__ ematch = a.dp.ematch;
@@ -1510,17 +1515,15 @@ __global__ __launch_bounds__(64) void k_viterbi_rows(FillArgs a) {
 
   for (int s = 0; s < g.nStripes; ++s) {
     int jlo, jhi;
-    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi);
-    const int i0 = g.ilo + s * S + l * B;           // this lane's first row
+    row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi, S);
+    const int i0 = g.ilo + s * S + L * B;           // this lane's first row
     const double* __restrict__ bprev = bnd + (size_t)(s & 1) * bndStride;      // last row of the previous stripe
     double* __restrict__ bnext = bnd + (size_t)((s + 1) & 1) * bndStride;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (jhi < jlo) {  // no cell of this stripe is inside the band: its last row is all -inf
-      for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      continue;
-    }
-    for (size_t c = l; c < bndStride; c += 64) bnext[c] = QF_NEG_INF;
+    for (size_t c = L; c < bndStride; c += G) bnext[c] = QF_NEG_INF;
+    if (L < NW * 4 * 3) (&s_x[0][0][0])[L] = QF_NEG_INF;
+    __threadfence();
+    __syncthreads();
+    if (jhi < jlo) continue;  // no cell of this stripe is inside the band: its last row is all -inf
     uint32_t tk[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) tk[b] = (i0 + b >= 1 && i0 + b <= xLen) ? xt[i0 + b - 1] : 0u;
@@ -1532,20 +1535,28 @@ __global__ __launch_bounds__(64) void k_viterbi_rows(FillArgs a) {
     double p1I = QF_NEG_INF;
     const int steps = jhi - jlo + 1 + G - 1;
     for (int t = 0; t < steps; ++t) {
-      const int j = jlo + t - l;
+      const int j = jlo + t - L;
       const bool colvalid = j >= jlo && j <= jhi;
       const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
       const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
-      const uint32_t gp = j > 1 ? (ctx[min(j - 2, yLen + 4)] >> 24) : 0u;  // yIndelKmer[j-1]; padded 0 for j == 1
+      const uint32_t gp = j > 1 ? (ctx[min(max(j - 2, -kCtxPad + 1), yLen + 4)] >> 24) : 0u;  // yIndelKmer[j-1]; padded 0 for j == 1
       const double m2m = trans[gp], m2i = trans[Kg + gp], m2d = trans[2 * Kg + gk];
       const double insE = eins[insrow];
-      // row above slot 0: lane l-1's last row (column j one step ago, column j-1 two steps ago) or the boundary
-      double upM = __shfl_up(p1M, 1, G), upD = __shfl_up(p1D, 1, G);
-      double dgM = __shfl_up(p2M, 1, G), dgI = __shfl_up(p2I, 1, G), dgD = __shfl_up(p2D, 1, G);
+      // row above slot 0: lane L-1's last row (column j one step ago, column j-1 two steps ago): by shuffle inside the
+      // wavefront, from the previous wavefront's ring, or (lane 0 of the stripe) from the boundary buffer
+      double upM = __shfl_up(p1M, 1, 64), upD = __shfl_up(p1D, 1, 64);
+      double dgM = __shfl_up(p2M, 1, 64), dgI = __shfl_up(p2I, 1, 64), dgD = __shfl_up(p2D, 1, 64);
       if (l == 0) {
-        const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
-        upM = bprev[jc]; upD = bprev[2 * (yLen + 2) + jc];
-        dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
+        if (wv == 0) {
+          const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
+          upM = bprev[jc]; upD = bprev[2 * (yLen + 2) + jc];
+          dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
+        } else {
+          const double* x1 = s_x[wv - 1][(t + 3) & 3];   // published at the end of step t-1
+          const double* x2 = s_x[wv - 1][(t + 2) & 3];   // ... of step t-2
+          upM = x1[0]; upD = x1[2];
+          dgM = x2[0]; dgI = x2[1]; dgD = x2[2];
+        }
       }
       uint32_t tbword = 0;
       double aboveM = upM, aboveD = upD;
@@ -1581,20 +1592,26 @@ __global__ __launch_bounds__(64) void k_viterbi_rows(FillArgs a) {
       }
       p2M = p1M; p2I = p1I; p2D = p1D;
       p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
+      if (l == 63) { double* xo = s_x[wv][t & 3]; xo[0] = p1M; xo[1] = p1I; xo[2] = p1D; }
       if (colvalid) {
-        tbw[woff + (unsigned long long)t * G + l] = tbword;
-        if (l == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
+        tbw[woff + (unsigned long long)t * G + L] = tbword;
+        if (L == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
       }
+      __syncthreads();
     }
     woff += (unsigned long long)steps * G;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
-  for (int o = 1; o < G; o <<= 1) {
-    const double ov = __shfl_xor(bestEnd, o, G);
-    const uint32_t oi = __shfl_xor(bestI, o, G);
+  // end cell of the unit: max value, largest row on ties
+  for (int o = 1; o < 64; o <<= 1) {
+    const double ov = __shfl_xor(bestEnd, o, 64);
+    const uint32_t oi = __shfl_xor(bestI, o, 64);
     if (ov > bestEnd || (ov == bestEnd && oi > bestI)) { bestEnd = ov; bestI = oi; }
   }
-  if (l == 0) {
+  if (l == 0) { s_best[wv] = bestEnd; s_bi[wv] = bestI; }
+  __syncthreads();
+  if (L == 0) {
+    for (int q = 1; q < NW; ++q)
+      if (s_best[q] > bestEnd || (s_best[q] == bestEnd && s_bi[q] > bestI)) { bestEnd = s_best[q]; bestI = s_bi[q]; }
     a.units[uid].end_val = bestEnd;
     a.units[uid].end_i = bestI;
   }
@@ -1761,18 +1778,18 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   } else {
-    const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, (int)yLen) : RowGeom{0, 0, 0};
+    const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, (int)yLen, kVitStripe) : RowGeom{0, 0, 0};
     while (walking()) {
       uint32_t nib = 0;
       if (i >= 1 && j >= 1) {
         if (u.cls == 0) nib = (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0xFu;
         else if (u.cls == (uint32_t)kRowClass) {
-          const int rr = i - rg.ilo, s = rr / kRowStripe, li = (rr % kRowStripe) / 8, b = rr % 8;
+          const int rr = i - rg.ilo, s = rr / kVitStripe, li = (rr % kVitStripe) / 8, b = rr % 8;
           int jlo, jhi;
-          row_stripe_cols(rg, s, u.dlo, u.dhi, (int)yLen, jlo, jhi);
+          row_stripe_cols(rg, s, u.dlo, u.dhi, (int)yLen, jlo, jhi, kVitStripe);
           const unsigned long long* so = (const unsigned long long*)tb;
           const uint32_t* words = tb + row_header_words(rg, (int)yLen);
-          nib = (words[so[s] + (unsigned long long)(j - jlo + li) * 64 + li] >> (4 * b)) & 0xFu;
+          nib = (words[so[s] + (unsigned long long)(j - jlo + li) * kVitLanes + li] >> (4 * b)) & 0xFu;
         } else {
           const int dd = (i - j) - u.dlo, l = dd / B, b = dd % B, t = j - 1 + l;
           nib = (tb[((uint64_t)t * G + l) * 2 + (b >> 3)] >> (4 * (b & 7))) & 0xFu;
@@ -1838,7 +1855,7 @@ void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s)
     case 10: launch_fill_gb<64, 8>(a, gapctx, s); break;
     case 11: launch_fill_gb<64, 12>(a, gapctx, s); break;
     case 12: launch_fill_gb<64, 16>(a, gapctx, s); break;
-    case 13: hipLaunchKernelGGL(k_viterbi_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); break;
+    case 13: hipLaunchKernelGGL(k_viterbi_rows, dim3(a.n_cls_units), dim3(kVitLanes), 0, s, a); break;
   }
 }
 
