@@ -61,6 +61,9 @@ constexpr int kRowStripe = 64 * 8;
 constexpr int kVitWaves = 8;
 constexpr int kVitLanes = kVitWaves * 64;
 constexpr int kVitStripe = kVitLanes * 8;
+constexpr int kVitLag = 8;        // extra column lag per wavefront: neighbouring wavefronts synchronise every kVitLag steps
+__host__ __device__ inline int vit_skew(int lane) { return lane + kVitLag * (lane >> 6); }   // lane's column lag
+constexpr int kVitSkewMax = kVitLanes - 1 + kVitLag * (kVitWaves - 1);
 struct RowGeom { int ilo, ihi, nStripes; };
 __host__ __device__ inline RowGeom row_geom(int dlo, int dhi, int xLen, int yLen, int S = kRowStripe) {
   RowGeom g;
@@ -86,7 +89,7 @@ __host__ __device__ inline uint64_t row_unit_words(int dlo, int dhi, int xLen, i
   for (int s = 0; s < g.nStripes; ++s) {
     int jlo, jhi;
     row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi, kVitStripe);
-    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + kVitLanes - 1) * kVitLanes;
+    if (jhi >= jlo) w += (uint64_t)(jhi - jlo + 1 + kVitSkewMax) * kVitLanes;
   }
   return w;
 }

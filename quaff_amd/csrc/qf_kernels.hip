@@ -1458,17 +1458,18 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Row-space Viterbi fill for bands wider than 1024 diagonals (-kmatchoff, or the full-envelope fallback of short
 // sequences against long references).  One workgroup of kVitWaves wavefronts per unit; the band's rows are cut into stripes
-// of 512 lanes x 8 rows.  Lane L (0..511) owns 8 consecutive rows and at step t is at column jlo + t - L, so
+// of 512 lanes x 8 rows.  Lane L (0..511) owns 8 consecutive rows and at step t is at column jlo + t - vit_skew(L), so
 //   ins(i,j) <- (i,  j-1): own registers (previous step)
 //   del(i,j) <- (i-1,j  ): own slot b-1 this step, or lane L-1's last row, which it finished one step ago
 //   mat(i,j) <- (i-1,j-1): own slot b-1 before this step's update, or lane L-1's last row two steps ago
-// Inside a wavefront the neighbour's values come by shuffle; between wavefronts through a four-deep LDS ring (one
-// workgroup barrier per step).  The last row of a stripe is kept in a global boundary buffer for the next stripe
+// Inside a wavefront the neighbour's values come by shuffle; between wavefronts through an LDS ring: each wavefront lags
+// the previous one by kVitLag extra columns, so a workgroup barrier every kVitLag steps is enough.  The last row of a stripe is kept in a global boundary buffer for the next stripe
 // (ping-pong).  Same arithmetic, candidate order and 4-bit traceback records as k_viterbi_fill.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   constexpr int G = kVitLanes, B = 8, S = kVitStripe, NW = kVitWaves;
-  __shared__ double s_x[NW][4][3];      // [wave][step & 3][M, I, D] of the wave's lane 63, last row
+  constexpr int K = kVitLag, R = 2 * K + 4;
+  __shared__ double s_x[NW][R][3];      // [wave][step % R][M, I, D] of the wave's lane 63, last row
   __shared__ double s_best[NW];
   __shared__ uint32_t s_bi[NW];
   const uint32_t uidx = blockIdx.x;
@@ -1493,13 +1494,14 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       int jlo, jhi;
       row_stripe_cols(g, s, dlo, dhi, yLen, jlo, jhi, S);
       stripe_off[s] = w;
-      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + G - 1) * G;
+      if (jhi >= jlo) w += (unsigned long long)(jhi - jlo + 1 + kVitSkewMax) * G;
     }
     stripe_off[g.nStripes] = w;
   }
   for (size_t c = L; c < bndStride; c += G) bnd[c] = QF_NEG_INF;
   __threadfence();
   __syncthreads();
+  const int skew = vit_skew(L);
 
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
   const double* __restrict__ ematch = a.dp.ematch;
@@ -1520,7 +1522,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
     const double* __restrict__ bprev = bnd + (size_t)(s & 1) * bndStride;      // last row of the previous stripe
     double* __restrict__ bnext = bnd + (size_t)((s + 1) & 1) * bndStride;
     for (size_t c = L; c < bndStride; c += G) bnext[c] = QF_NEG_INF;
-    if (L < NW * 4 * 3) (&s_x[0][0][0])[L] = QF_NEG_INF;
+    if (L < NW * R * 3) (&s_x[0][0][0])[L] = QF_NEG_INF;
     __threadfence();
     __syncthreads();
     if (jhi < jlo) continue;  // no cell of this stripe is inside the band: its last row is all -inf
@@ -1533,9 +1535,9 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
     double p1M = QF_NEG_INF, p1D = QF_NEG_INF;                     // last row, column of the previous step
     double p2M = QF_NEG_INF, p2I = QF_NEG_INF, p2D = QF_NEG_INF;   // last row, column of two steps ago
     double p1I = QF_NEG_INF;
-    const int steps = jhi - jlo + 1 + G - 1;
+    const int steps = jhi - jlo + 1 + kVitSkewMax;
     for (int t = 0; t < steps; ++t) {
-      const int j = jlo + t - L;
+      const int j = jlo + t - skew;
       const bool colvalid = j >= jlo && j <= jhi;
       const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
       const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
@@ -1552,8 +1554,9 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
           upM = bprev[jc]; upD = bprev[2 * (yLen + 2) + jc];
           dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
         } else {
-          const double* x1 = s_x[wv - 1][(t + 3) & 3];   // published at the end of step t-1
-          const double* x2 = s_x[wv - 1][(t + 2) & 3];   // ... of step t-2
+          // the previous wavefront's last lane was on column j at step t-K-1 and on column j-1 at step t-K-2
+          const double* x1 = s_x[wv - 1][(t + 2 * R - K - 1) % R];
+          const double* x2 = s_x[wv - 1][(t + 2 * R - K - 2) % R];
           upM = x1[0]; upD = x1[2];
           dgM = x2[0]; dgI = x2[1]; dgD = x2[2];
         }
@@ -1592,13 +1595,14 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       }
       p2M = p1M; p2I = p1I; p2D = p1D;
       p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
-      if (l == 63) { double* xo = s_x[wv][t & 3]; xo[0] = p1M; xo[1] = p1I; xo[2] = p1D; }
+      if (l == 63) { double* xo = s_x[wv][t % R]; xo[0] = p1M; xo[1] = p1I; xo[2] = p1D; }
       if (colvalid) {
         tbw[woff + (unsigned long long)t * G + L] = tbword;
         if (L == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
       }
-      __syncthreads();
+      if (t % K == K - 1) __syncthreads();   // ring slots are read K+1 / K+2 steps after they are written
     }
+    __syncthreads();   // everybody is done with the ring and the boundary row before the next stripe resets them
     woff += (unsigned long long)steps * G;
   }
   // end cell of the unit: max value, largest row on ties
@@ -1789,7 +1793,7 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
           row_stripe_cols(rg, s, u.dlo, u.dhi, (int)yLen, jlo, jhi, kVitStripe);
           const unsigned long long* so = (const unsigned long long*)tb;
           const uint32_t* words = tb + row_header_words(rg, (int)yLen);
-          nib = (words[so[s] + (unsigned long long)(j - jlo + li) * kVitLanes + li] >> (4 * b)) & 0xFu;
+          nib = (words[so[s] + (unsigned long long)(j - jlo + vit_skew(li)) * kVitLanes + li] >> (4 * b)) & 0xFu;
         } else {
           const int dd = (i - j) - u.dlo, l = dd / B, b = dd % B, t = j - 1 + l;
           nib = (tb[((uint64_t)t * G + l) * 2 + (b >> 3)] >> (4 * (b & 7))) & 0xFu;
