@@ -1466,8 +1466,17 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
 // the previous one by kVitLag extra columns, so a workgroup barrier every kVitLag steps is enough.  The last row of a stripe is kept in a global boundary buffer for the next stripe
 // (ping-pong).  Same arithmetic, candidate order and 4-bit traceback records as k_viterbi_fill.
 // ------------------------------------------------------------------------------------------------
+template <bool EMLDS>
 __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   constexpr int G = kVitLanes, B = 8, S = kVitStripe, NW = kVitWaves;
+  // EMLDS: emission tables in LDS (see k_viterbi_fill2): the eight emission fetches of a step are gathers
+  extern __shared__ double lds_tab[];
+  const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
+  if (EMLDS) {
+    for (uint32_t q = threadIdx.x; q < n_em; q += G) lds_tab[q] = a.dp.ematch[q];
+    for (uint32_t q = threadIdx.x; q < kInsRows; q += G) lds_tab[n_em + q] = a.dp.eins[q];
+    __syncthreads();
+  }
   constexpr int K = kVitLag, R = 2 * K + 4;
   __shared__ double s_x[NW][R][3];      // [wave][step % R][M, I, D] of the wave's lane 63, last row
   __shared__ double s_best[NW];
@@ -1504,8 +1513,8 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   const int skew = vit_skew(L);
 
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
-  const double* __restrict__ ematch = a.dp.ematch;
-  const double* __restrict__ eins = a.dp.eins;
+  const double* __restrict__ ematch = EMLDS ? lds_tab : a.dp.ematch;
+  const double* __restrict__ eins = EMLDS ? lds_tab + n_em : a.dp.eins;
   const double* __restrict__ trans = a.dp.trans;
   const uint32_t Kg = a.dp.Kg;
   const bool local = a.dp.local != 0;
@@ -1859,7 +1868,12 @@ void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s)
     case 10: launch_fill_gb<64, 8>(a, gapctx, s); break;
     case 11: launch_fill_gb<64, 12>(a, gapctx, s); break;
     case 12: launch_fill_gb<64, 16>(a, gapctx, s); break;
-    case 13: hipLaunchKernelGGL(k_viterbi_rows, dim3(a.n_cls_units), dim3(kVitLanes), 0, s, a); break;
+    case 13: {
+      const uint32_t lds_bytes = a.dp.ematch_ninf_off + 32 + kInsRows * 8;
+      if (lds_bytes <= 52 * 1024 && !a.no_lds_tables) hipLaunchKernelGGL(k_viterbi_rows<true>, dim3(a.n_cls_units), dim3(kVitLanes), lds_bytes, s, a);
+      else hipLaunchKernelGGL(k_viterbi_rows<false>, dim3(a.n_cls_units), dim3(kVitLanes), 0, s, a);
+      break;
+    }
   }
 }
 
