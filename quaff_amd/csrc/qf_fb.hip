@@ -16,9 +16,6 @@ namespace qf {
 #ifndef QF_BWD_WAVES
 #define QF_BWD_WAVES 3
 #endif
-#ifndef QF_FB_EXP
-#define QF_FB_EXP 0
-#endif
 
 // log_sum_exp, src/logsumexp.cpp:34-50 + log_sum_exp_unary :84-103 (x >= 10, NaN, inf -> 0).
 // n = (int)(x / 1e-4) is evaluated as x * 1e4: at worst the neighbouring interval of the same piecewise-
@@ -29,11 +26,7 @@ __device__ __forceinline__ double lse2(const double* __restrict__ tab, double a,
   if (!(diff < 10.0)) return a == b ? mx + tab[0] : mx;
   const int n = (int)(diff * 10000.0);
   const double dx = diff - n * .0001;
-#if QF_FB_EXP == 1
-  const double f0 = 0.3, f1 = 0.31;
-#else
   const double f0 = tab[n], f1 = tab[n + 1];
-#endif
   return mx + (f0 + (f1 - f0) * (dx * 10000.0));
 }
 
@@ -398,7 +391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
         // emission rows belong to the destination column j+1 (context word index j); column yLen has no destination
         const uint32_t er = wNext & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
         const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
-        if (QF_FB_EXP != 2 && q < (uint32_t)kNQualDev) {
+        if (q < (uint32_t)kNQualDev) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             if (colsum[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], colsum[c]);

@@ -1083,15 +1083,6 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
 //    reference's M, I, D order) instead of value/flag select chains.
 //  * Lane exchange by DPP row/wave shifts (a -inf "old" value fills the group's edge lane) instead of ds_bpermute.
 // ------------------------------------------------------------------------------------------------
-#ifndef QF_EXP
-#define QF_EXP 0
-#endif
-#ifndef QF_STEP_UNROLL
-#define QF_STEP_UNROLL 4
-#endif
-#ifndef QF_FILL2_OCC
-#define QF_FILL2_OCC
-#endif
 // ZERO: the group's edge lane receives 0.0 (both dwords zero-filled by bound_ctrl) instead of -inf
 template <int G, bool ZERO>
 __device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf (or 0) in the group's lane 0
@@ -1121,7 +1112,7 @@ __device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y
 }
 
 template <int G, int B, bool GAPCTX, bool EMLDS>
-__global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) {
+__global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
   // EMLDS: the match-emission table (+ its -inf row) and the insert-emission table are copied to LDS once per workgroup.
   // Every lane of a wavefront is on a different read column, so the B emission fetches of a step are 64-way gathers;
   // through the vector L1 those gathers, not the arithmetic, bound the kernel (measured), LDS serves them far faster.
@@ -1251,14 +1242,6 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
         const bool colvalid = active && j >= 1 && j <= yLen;
         const uint32_t w = wN;
         double e[B];
-#if QF_EXP == 4   // A/B: fetch this step's emissions now instead of one step ahead
-        const double insE = eins[(w >> 15) & 0x1FFu];
-#pragma unroll
-        for (int b = 0; b < B; ++b) e[b] = emis(w, winN, b);
-        wN = s < 3 ? cw.v[s + 1] : cwn.v[0];
-        winN = (winN >> 2) | (((uint32_t)(xpair >> (sh0 + 2 * (s4 + s + 1))) & 3u) << (2 * (B - 1)));
-        (void)eN; (void)insEN;
-#else
         const double insE = insEN;
 #pragma unroll
         for (int b = 0; b < B; ++b) e[b] = eN[b];
@@ -1268,7 +1251,6 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
         insEN = eins[(wN >> 15) & 0x1FFu];
 #pragma unroll
         for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b);
-#endif
         const uint32_t gk = w >> 24;
         double m2m, m2i, m2d;
         if (GAPCTX) {
@@ -1302,12 +1284,10 @@ __global__ __launch_bounds__(256) QF_FILL2_OCC void k_viterbi_fill2(FillArgs a) 
             const double gM = prevM + ((EDGE && b == 0) ? m2dEdge : m2d), gD = prevD + ((EDGE && b == 0) ? d2dEdge : d2d);
             const double ndl = fmax(gM, gD);
             uint32_t& acc = b < 8 ? acc0 : acc1;
-#if QF_EXP != 1
             acc = shift_in_gt(acc, tI, tM);
             acc = shift_in_gt(acc, tD, m1);
             acc = shift_in_gt(acc, cI, cM);
             acc = shift_in_gt(acc, gD, gM);
-#endif
             M[b] = nm; I[b] = ni; D[b] = ndl;
             prevM = nm; prevD = ndl;
             if (b == 0) {
@@ -1572,6 +1552,32 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       }
       uint32_t tbword = 0;
       double aboveM = upM, aboveD = upD;
+      // FAST step (wave-uniform): every lane is on an inner column (not the first or last read column) and all eight of
+      // its cells are inside the band and the matrix: no start candidate, no end tracking, no masking; values by
+      // v_max_f64, flags as raw compare bits (see k_viterbi_fill2)
+      const bool laneFast = colvalid && j > 1 && j < yLen && i0 >= 1 && i0 + B - 1 <= xLen && i0 - j >= dlo && i0 + B - 1 - j <= dhi;
+      if (__builtin_amdgcn_ballot_w64(!laneFast) == 0) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const double e = ematch[erow4 + tk[b]];
+          const double oM = M[b], oI = I[b], oD = D[b];   // (i, j-1)
+          const double tM = (dgM + m2m) + e, tI = (dgI + i2m) + e, tD = (dgD + d2m) + e;
+          const double m1 = fmax(tM, tI), nm = fmax(m1, tD);
+          const double cM = (oM + m2i) + insE, cI = (oI + i2i) + insE;
+          const double ni = fmax(cM, cI);
+          const double gM = aboveM + m2d, gD = aboveD + d2d;
+          const double ndl = fmax(gM, gD);
+          acc = shift_in_gt(acc, tI, tM);
+          acc = shift_in_gt(acc, tD, m1);
+          acc = shift_in_gt(acc, cI, cM);
+          acc = shift_in_gt(acc, gD, gM);
+          M[b] = nm; I[b] = ni; D[b] = ndl;
+          dgM = oM; dgI = oI; dgD = oD;
+          aboveM = nm; aboveD = ndl;
+        }
+        tbword = __builtin_bitreverse32(acc);
+      } else {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         const int i = i0 + b, dgl = i - j;
@@ -1601,6 +1607,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
           const double ev = nm + trans[3 * Kg + gk];
           if (ev >= bestEnd) { bestEnd = ev; bestI = (uint32_t)i; }
         }
+      }
       }
       p2M = p1M; p2I = p1I; p2D = p1D;
       p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
