@@ -21,8 +21,10 @@ WORKER = textwrap.dedent("""
     dist.barrier()
     mx = dist.allreduce_max(1.5 + rank)
     n = dist.allreduce_sum(np.array([hi - lo], dtype=np.float64))[0]
-    print(json.dumps({"rank": rank, "world": world, "lo": lo, "hi": hi, "sum_ok": bool(np.array_equal(tot, np.arange(1888) * 3.0)),
-                      "ll": ll, "max": mx, "n": n}))
+    # one file per rank: two processes printing to one pipe can interleave inside a line
+    open(sys.argv[1] + "/rank%%d.json" %% rank, "w").write(json.dumps(
+        {"rank": rank, "world": world, "lo": lo, "hi": hi, "sum_ok": bool(np.array_equal(tot, np.arange(1888) * 3.0)),
+         "ll": ll, "max": mx, "n": n}))
     dist.finalize()
 """) % ROOT
 
@@ -32,11 +34,11 @@ def test_two_rank_gloo(tmp_path):
     script.write_text(WORKER)
     port = 29500 + (os.getpid() % 2000)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(tmp_path)],
                          capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stderr[-2000:]
     import json
-    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    rows = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(2)]
     assert sorted(r["rank"] for r in rows) == [0, 1]
     rows.sort(key=lambda r: r["rank"])
     assert rows[0]["lo"] == 0 and rows[0]["hi"] == rows[1]["lo"] and rows[1]["hi"] == 1001
