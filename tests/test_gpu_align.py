@@ -227,6 +227,23 @@ def synth_params_json(rng, match_len, gap_len):
     return o + ",\n".join(blocks) + " } }\n"
 
 
+def test_align_order1_contexts_lds_tables(ctx):
+    """-order 1 parameters (match context 2, gap context 1): the largest emission tables that still live in LDS (51.7 KB per
+    workgroup) together with per-step gap-context transitions; also full DP through the row-space kernel."""
+    rng = np.random.default_rng(26)
+    pj = synth_params_json(rng, 2, 1)
+    sc = O.Scores(O.Params.from_json(pj))
+    null = O.NullParams.from_json(NULL_JSON)
+    ctx.set_params_json(pj)
+    try:
+        ref = rand_seq(rng, 1500)
+        reads = make_reads(rng, ref, 8, 280)
+        check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
+        check_against_oracle(ctx, [O.FastSeq("ref", ref)], reads[:3], dict(sparse=False), sc, null)
+    finally:
+        ctx.set_params_json(None)
+
+
 def test_align_order2_contexts(ctx):
     """-order 2 style parameters (match context 3, gap context 2): exercises context k-mers + GAPCTX kernels."""
     rng = np.random.default_rng(25)
