@@ -96,7 +96,7 @@ struct Slot {
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
-      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws;
+      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws, d_align_out;
   HostBuf<AlignRec> h_recs;
   HostBuf<uint32_t> h_runs;
   std::string err;
@@ -115,7 +115,7 @@ struct Slot {
   }
   void destroy() {
     for (DevBuf* b : {&d_units, &d_cls_list, &d_pair_head, &d_pair_bands, &d_pair_nbands, &d_ovf, &d_pair_ndiag, &d_pair_cells,
-                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws})
+                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws, &d_align_out})
       b->release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_ev) if (e) (void)hipEventDestroy(e);
@@ -163,7 +163,9 @@ struct qf_ctx : Slot {
   HostBuf<double> h_viterbi, h_nll;
   HostBuf<uint64_t> h_cells;
   HostBuf<uint32_t> h_ndiag;
-  std::vector<qf_alignment> h_align;
+  HostBuf<qf_alignment> h_align;
+  struct DenseChunk { uint32_t lo, hi; size_t runs0; bool second; };
+  std::vector<DenseChunk> dense_chunks;   // best-per-read mode: where each chunk's records and runs went
   std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
@@ -754,17 +756,25 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   HIPCHK(S, hipMemcpyAsync(c->h_viterbi.data() + p0, S->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->aux[2]));
   HIPCHK(S, hipMemcpyAsync(c->h_cells.data() + p0, S->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->aux[2]));
   HIPCHK(S, hipMemcpyAsync(c->h_ndiag.data() + p0, S->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, S->aux[2]));
-  uint32_t n_recs = 0;
+  uint32_t n_recs = 0, n_valid = 0;
   uint64_t total_runs = 0;
+  const bool dense = !(flags & QF_ALIGN_ALL) && !(flags & QF_ALIGN_NO_TRACEBACK);
   if (!(flags & QF_ALIGN_NO_TRACEBACK)) {
     const size_t max_recs = fin.all ? n_pairs : n_reads;
     HIPCHK(S, S->d_recs.reserve(max_recs * sizeof(AlignRec)));
     fin.recs = S->d_recs.as<AlignRec>();
+    fin.dense = !fin.all;
+    fin.read_base = lo;
+    if (fin.dense) {
+      HIPCHK(S, S->d_align_out.reserve((size_t)n_reads * sizeof(AlignOut)));
+      fin.out_align = S->d_align_out.as<AlignOut>();
+    }
     launch_select(fin, S->stream);
     HIPCHK(S, hipGetLastError());
     if (int rc = read_counters(S, bc)) return rc;
     if (token.owns_lock()) token.unlock();  // the fill has drained
-    n_recs = bc.n_align;
+    n_recs = fin.dense ? n_reads : bc.n_align;
+    n_valid = bc.n_align;
     HIPCHK(S, S->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
     HIPCHK(S, S->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
     fin.n_recs = n_recs;
@@ -774,24 +784,33 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     HIPCHK(S, hipGetLastError());
     if (int rc = read_counters(S, bc)) return rc;
     total_runs = bc.total_runs_out;
+    if (bc.error & 16u) return fail(S, QF_ERR_DEVICE, "traceback did not reach the start state");
   }
   HIPCHK(S, hipEventRecord(S->ev[4], S->stream));
 
   // ---- results to the host, at the chunk's offsets
   const size_t recs0 = S->h_recs.size(), runs0 = S->h_runs.size();
-  S->h_recs.resize(recs0 + n_recs);
+  if (!dense) S->h_recs.resize(recs0 + n_recs);
   S->h_runs.resize(runs0 + total_runs);
-  if (n_recs) HIPCHK(S, hipMemcpyAsync(S->h_recs.data() + recs0, S->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, S->stream));
+  static_assert(sizeof(AlignOut) == sizeof(qf_alignment), "AlignOut mirrors qf_alignment");
+  if (dense) {  // final records, in read order, straight into the result array
+    if (n_recs) HIPCHK(S, hipMemcpyAsync(c->h_align.data() + lo, S->d_align_out.p, (size_t)n_recs * sizeof(AlignOut), hipMemcpyDeviceToHost, S->stream));
+  } else if (n_recs) HIPCHK(S, hipMemcpyAsync(S->h_recs.data() + recs0, S->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, S->stream));
   if (total_runs) HIPCHK(S, hipMemcpyAsync(S->h_runs.data() + runs0, S->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(S, hipEventRecord(S->ev[5], S->stream));
   HIPCHK(S, hipStreamSynchronize(S->stream));
   HIPCHK(S, hipStreamSynchronize(S->aux[2]));
-  for (size_t a = recs0; a < recs0 + n_recs; ++a) {
-    S->h_recs[a].read += lo;
-    S->h_recs[a].run_off += runs0;
-  }
+  if (!dense)
+    for (size_t a = recs0; a < recs0 + n_recs; ++a) {
+      S->h_recs[a].read += lo;
+      S->h_recs[a].run_off += runs0;
+    }
   {
     std::lock_guard<std::mutex> lk(out_mu);
+    if (dense) {
+      c->dense_chunks.push_back({lo, hi, runs0, S != static_cast<Slot*>(c)});
+      out->n_alignments += n_valid;
+    }
     out->total_cells += seed_bc.total_cells;
     out->n_units += seed_bc.n_units;
     out->traceback_bytes += tb_bytes;
@@ -837,6 +856,9 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   c->h_nll.resize(n_reads);
   c->h_recs.clear();
   c->h_runs.clear();
+  c->dense_chunks.clear();
+  const bool dense = !(flags & QF_ALIGN_ALL) && !(flags & QF_ALIGN_NO_TRACEBACK);
+  if (dense) c->h_align.resize(n_reads);
   HIPCHK(c, hipMemcpyAsync(c->h_nll.data(), c->d_nll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   {
@@ -909,6 +931,29 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   // then order the few reads that have several (QF_ALIGN_ALL).
   const size_t runs_first = c->h_runs.size();
   c->h_runs.append(c->second.h_runs.data(), c->second.h_runs.size());
+  if (dense) {
+    // best alignment per read: the device wrote final records at their read's index.  One piece: nothing to do.  Several
+    // pieces: rebase the run offsets.  Reads without any alignment (holes) are squeezed out.
+    if (c->dense_chunks.size() > 1 || runs_first != c->h_runs.size())
+      for (const auto& dc : c->dense_chunks) {
+        const size_t add = dc.runs0 + (dc.second ? runs_first : 0);
+        if (add) for (uint32_t r = dc.lo; r < dc.hi; ++r) c->h_align[r].run_offset += add;
+      }
+    if (out->n_alignments != n_reads) {
+      uint32_t w = 0;
+      for (uint32_t r = 0; r < n_reads; ++r)
+        if (c->h_align[r].n_runs != kAlignHole) c->h_align[w++] = c->h_align[r];
+    }
+    out->viterbi = c->h_viterbi.data();
+    out->cells = c->h_cells.data();
+    out->n_diagonals = c->h_ndiag.data();
+    out->null_loglike = c->h_nll.data();
+    out->alignments = c->h_align.data();
+    out->cigar_runs = c->h_runs.data();
+    out->n_fill_classes = kNumClasses;
+    out->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return QF_OK;
+  }
   const uint32_t n_first = (uint32_t)c->h_recs.size(), n_recs = n_first + (uint32_t)c->second.h_recs.size();
   auto rec_at = [&](uint32_t k) -> const AlignRec& { return k < n_first ? c->h_recs[k] : c->second.h_recs[k - n_first]; };
   std::vector<uint32_t> start(n_reads + 1, 0), order(n_recs);

@@ -1688,7 +1688,16 @@ __global__ void k_select(FinalArgs a) {
     const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
     AlignRec rec{r, bestX, a.pair_end_unit[p], 0, a.pair_score[p], bestAdj,
                  atomicAdd(&a.bc->n_runs, (unsigned long long)cap), 0, 0, 0, 0};
-    a.recs[idx] = rec;
+    a.recs[a.dense ? r : idx] = rec;   // dense: record r is read r's, so the results need no ordering on the host
+  } else if (!a.all && a.dense) {
+    AlignRec rec{};
+    rec.read = r;
+    rec.unit = kNoUnit;
+    a.recs[r] = rec;
+    AlignOut o{};
+    o.read = r + a.read_base;
+    o.n_runs = kAlignHole;
+    a.out_align[r] = o;
   }
 }
 
@@ -1718,6 +1727,9 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
   int xLenR = 0;
   if (live) {
     rec = a.recs[idx];
+    live = rec.unit != kNoUnit;   // dense mode: a read without any alignment
+  }
+  if (live) {
     u = a.units[rec.unit];
     const bool win_cls = u.cls != 0 && u.cls != (uint32_t)kRowClass && fill_class((int)u.cls).B <= 8;
     live = win_cls == WINDOWED;
@@ -1835,6 +1847,15 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
   rec.run_off = off;
   rec.ok = state == 0;
   a.recs[idx] = rec;
+  if (!rec.ok) atomicOr(&a.bc->error, 16u);   // the traceback did not reach the start state
+  if (a.out_align) {
+    AlignOut o;
+    o.read = rec.read + a.read_base; o.ref = rec.ref;
+    o.viterbi = rec.viterbi; o.score = rec.score;
+    o.x_start = rec.x_start; o.x_end = rec.x_end; o.n_columns = ncol; o.n_runs = n;
+    o.run_offset = off;
+    a.out_align[idx] = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

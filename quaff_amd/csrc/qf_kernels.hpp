@@ -163,9 +163,21 @@ struct AlignRec {
   uint32_t y_start, y_end;
 };
 
+// Device image of qf_alignment (include/quaff_hip.h): best-alignment records are written in their final form and order
+struct AlignOut {
+  uint32_t read, ref;
+  double viterbi, score;
+  uint32_t x_start, x_end, n_columns, n_runs;
+  unsigned long long run_offset;
+};
+constexpr uint32_t kAlignHole = 0xFFFFFFFFu;   // n_runs of a read without any alignment
+
 struct FinalArgs {
   uint32_t n_pairs, n_reads, n_refs, n_recs;
   int all;
+  int dense;            // best-per-read mode: record r belongs to read r (holes marked), results go to out_align
+  uint32_t read_base;   // index of the chunk's first read in the batch
+  AlignOut* out_align;
   Unit* units;
   const uint32_t* pair_head;
   double* pair_score;
