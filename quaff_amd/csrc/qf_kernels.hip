@@ -693,6 +693,7 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
       if (((hv >> (16 * c)) & 0xFFFFu) >= thr) {
         const uint32_t slot = atomicAdd(&misc[0], 1u);
         if (slot < 0xFFFFu) outv = (outv & ~(0xFFFFu << (16 * c))) | (slot << (16 * c));
+        if (slot < (uint32_t)kCand) misc[1 + slot] = (uint32_t)(2 * w + c);   // first round's bins, for the seed scan
       }
     if (w < coarseWords) coarse[w] = outv;
   }
@@ -717,12 +718,23 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
     });
     wave_lds_sync();
     // seeds: diagonals of this round's candidate bins reaching the threshold (diagenv.cpp:68-96)
-    for (int cb = lane; cb < nCoarse; cb += 64) {
-      const uint32_t slot = slotOf(cb) - base;
-      if (slot >= (uint32_t)kCand) continue;
-      for (int c = 0; c < 32; ++c) {
+    if (base == 0) {
+      // one lane per (candidate bin, diagonal): the first round's bins are listed in misc[1..]
+      const uint32_t nslots = min(ncand, (uint32_t)kCand);
+      for (uint32_t idx = lane; idx < nslots * 32; idx += 64) {
+        const uint32_t slot = idx >> 5, c = idx & 31;
+        const int cb = (int)misc[1 + slot];
         const uint32_t cnt = (fine[slot * 16 + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
-        if (cnt >= thr && cb * 32 + c < nd) mark(cb * 32 + c);
+        if (cnt >= thr && cb * 32 + (int)c < nd) mark(cb * 32 + (int)c);
+      }
+    } else {
+      for (int cb = lane; cb < nCoarse; cb += 64) {
+        const uint32_t slot = slotOf(cb) - base;
+        if (slot >= (uint32_t)kCand) continue;
+        for (int c = 0; c < 32; ++c) {
+          const uint32_t cnt = (fine[slot * 16 + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
+          if (cnt >= thr && cb * 32 + c < nd) mark(cb * 32 + c);
+        }
       }
     }
     wave_lds_sync();
@@ -743,8 +755,17 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
     while (st) {
       const int b = w * 32 + __ffs(st) - 1;
       st &= st - 1;
-      int e2 = b;
-      while (e2 + 1 < nd && member(e2 + 1)) ++e2;
+      // end of the run: the first clear bit after b, a word at a time
+      int e2;
+      {
+        int ww = b >> 5;
+        uint32_t clr = ~bm[ww] & (0xFFFFFFFEu << (b & 31));   // clear bits above b in its word (0 if b is bit 31)
+        if ((b & 31) == 31) clr = 0;
+        while (clr == 0 && ww + 1 < bmWords) { ++ww; clr = ~bm[ww]; }
+        e2 = clr ? ww * 32 + __ffs(clr) - 2 : nd - 1;
+        if (e2 > nd - 1) e2 = nd - 1;
+      }
+      (void)member;
       record_band(a, pair, b + minD, e2 + minD);
     }
   }
