@@ -272,7 +272,7 @@ def main():
         dist.finalize()
         return
 
-    dom = max(cls_ms, key=lambda k: cls_ms[k])
+    dom = max(cls_cells, key=lambda k: cls_cells[k])   # the class that does most of the work (the others run beside it)
     dom_ms = cls_ms[dom] / a.steps
     dom_name = ctx.L.qf_fill_class_name(dom).decode()
     achieved = BYTES_PER_CELL * cls_cells[dom] / (dom_ms * 1e-3) / 1e9
