@@ -130,6 +130,7 @@ struct qf_ctx : Slot {
   int device = 0;
   Slot second;             // created on first use
   bool second_ready = false;
+  hipEvent_t ev_tok = nullptr, ev_nll = nullptr;   // read tokens ready / null log-likelihoods ready
   uint32_t pipeline_chunks = 0;  // 0 = automatic
   bool byte_prep = false;        // QUAFF_HIP_BYTE_PREP=1: first-generation read-preparation kernel (A/B)
   std::string devname;
@@ -222,6 +223,8 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
     delete c;
     return QF_ERR_DEVICE;
   }
+  (void)hipEventCreateWithFlags(&c->ev_tok, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_nll, hipEventDisableTiming);
   *out = c;
   return QF_OK;
 }
@@ -240,6 +243,8 @@ void qf_ctx_destroy(qf_ctx* c) {
                     &c->d_vals_tmp, &c->d_off32, &c->d_rskeys, &c->d_roff32})
     b->release();
   if (c->sort_temp) (void)hipFree(c->sort_temp);
+  if (c->ev_tok) (void)hipEventDestroy(c->ev_tok);
+  if (c->ev_nll) (void)hipEventDestroy(c->ev_nll);
   if (c->second_ready) {
     (void)hipStreamSynchronize(c->second.stream);
     c->second.destroy();
@@ -521,7 +526,9 @@ int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t
 }
 
 // tokens / context words / seeding k-mers / null log-likelihoods for the resident reads
-static int prep_reads(qf_ctx* c, int seed_k) {
+// `side`: run the null log-likelihoods (a serial sum per read, needed only when pairs are finalised) on that stream, beside
+// whatever the caller launches next on the main stream; c->ev_nll is recorded behind them.
+static int prep_reads(qf_ctx* c, int seed_k, hipStream_t side = nullptr) {
   PrepArgs a{};
   a.seq = c->d_seq.as<char>();
   a.qual = c->reads_have_qual ? c->d_qual.as<char>() : nullptr;
@@ -547,6 +554,12 @@ static int prep_reads(qf_ctx* c, int seed_k) {
   a.bc = c->d_bc.as<BatchCounters>();
   a.byte_kernel = c->byte_prep;
   launch_prep_reads(a, c->n_reads, c->stream);
+  if (side) {
+    HIPCHK(c, hipEventRecord(c->ev_tok, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(side, c->ev_tok, 0));
+  }
+  launch_null_ll(a, c->n_reads, side ? side : c->stream);
+  HIPCHK(c, hipEventRecord(c->ev_nll, side ? side : c->stream));
   HIPCHK(c, hipGetLastError());
   return QF_OK;
 }
@@ -748,6 +761,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   fin.ref_off = c->d_ref_off.as<uint64_t>();
   fin.tb = S->d_tb.as<uint32_t>();
   fin.bc = S->d_bc.as<BatchCounters>();
+  HIPCHK(S, hipStreamWaitEvent(S->stream, c->ev_nll, 0));   // null log-likelihoods (side stream) before the scores
   launch_finalize(fin, S->stream);
   // per-pair results are final: copy them out on a side stream while the alignments are selected and traced
   const size_t p0 = (size_t)lo * n_refs;
@@ -848,7 +862,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
   HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
-  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0, c->aux[1])) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->h_viterbi.resize(n_pairs);
   c->h_cells.resize(n_pairs);
@@ -859,8 +873,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   c->dense_chunks.clear();
   const bool dense = !(flags & QF_ALIGN_ALL) && !(flags & QF_ALIGN_NO_TRACEBACK);
   if (dense) c->h_align.resize(n_reads);
-  HIPCHK(c, hipMemcpyAsync(c->h_nll.data(), c->d_nll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_nll.data(), c->d_nll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->aux[1]));   // behind k_null_ll
   {
     BatchCounters pb;
     if (int rc = read_counters(c, pb)) return rc;
@@ -925,6 +938,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   } else {
     worker(c);
   }
+  HIPCHK(c, hipStreamSynchronize(c->aux[1]));   // null log-likelihoods on the host
   if (rc_all != QF_OK) return rc_all;
   // Output order: by read; within a read by descending score, earlier reference first on ties (the reference's multiset
   // order, src/qmodel.cpp:2773-2775).  Records arrive in device order from two slots: bucket them by read (one pass),

@@ -1947,7 +1947,9 @@ void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (a.byte_kernel) hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
   else if (a.skmer64) hipLaunchKernelGGL(k_prep_reads2<true>, dim3(n_reads), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_prep_reads2<false>, dim3(n_reads), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_null_ll, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, n_reads);
+}
+void launch_null_ll(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
+  if (n_reads) hipLaunchKernelGGL(k_null_ll, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, n_reads);
 }
 size_t seed_lds_bytes(int max_nd, bool mem) {
   const size_t hist = (size_t)((max_nd + 1) / 2) * 4;

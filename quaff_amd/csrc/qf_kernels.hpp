@@ -198,6 +198,7 @@ void launch_pack_ref(const uint8_t* tok, const uint64_t* off, const uint64_t* wo
 void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, uint64_t max_len, uint32_t k,
                       uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s);
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s);
+void launch_null_ll(const PrepArgs& a, uint32_t n_reads, hipStream_t s);   // needs the token bytes of launch_prep_reads
 // Emission counts of one read column go to the accumulator table with one global fp64 atomic each; workgroups spread over
 // this many copies of the table (summed at the end) so that popular (context, quality) entries are not serialised in L2.
 constexpr int kCountReplicas = 16;
