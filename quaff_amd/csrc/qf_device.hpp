@@ -8,7 +8,7 @@ namespace qf {
 
 constexpr int kMaxRefK = 8;        // direct-addressed k-mer index up to 4^8 buckets per sequence
 constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
-constexpr int kMaxBandsPerPair = 8;  // disjoint diagonal runs recorded per (read, ref) pair
+constexpr int kMaxBandsPerPair = 2;  // diagonal runs recorded in per-pair slots; further runs of a pair go to the overflow list
 constexpr int kCtxPad = 128;       // junk words before/after the per-column context array
 
 // Packed per-column read context word (one per read base), built by the prep kernel:
