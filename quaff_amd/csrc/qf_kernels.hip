@@ -1812,20 +1812,23 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
+      // eight moves from the window.  A path that leaves the window early (8 same-direction indels in a row) just waits for
+      // the next refill, so the loop has no global-memory fallback; the window index of (lane l, step t) is
+      // ((l - cl + 1) * 2 + ct - t/8) * 8 + t%8  =  16 l + kw - t + 2 (t % 8)
+      const int kw = (1 - cl) * 16 + 8 * ct;
+#pragma unroll
       for (int mv = 0; mv < 8; ++mv) {
-        if (!walking()) continue;
-        uint32_t nib = 0;
-        if (i >= 1 && j >= 1) {
-          const int t = j - 1 + l, dl = l - cl + 1, q = ct - (t >> 3);
-          if ((unsigned)dl < 3u && (unsigned)q < 2u) nib = (win[(dl * 2 + q) * 8 + (t & 7)] >> (4 * b)) & 0xFu;
-          else nib = (tb[tb_word_index(max(t, 0), min(max(l, 0), G - 1), G)] >> (4 * b)) & 0xFu;   // left the window (rare)
+        const int t = j - 1 + l;
+        const bool cell = i >= 1 && j >= 1;
+        const bool inwin = (unsigned)(l - cl + 1) < 3u && (unsigned)(ct - (t >> 3)) < 2u;
+        const uint32_t wv = win[(cell && inwin) ? 16 * l + kw - t + 2 * (t & 7) : 0];
+        if (walking() && (inwin || !cell)) {
+          int db;
+          step(cell ? (wv >> (4 * b)) & 0xFu : 0u, db);
+          b += db;
+          if (b == B) { b = 0; ++l; }
+          if (b < 0) { b = B - 1; --l; }
         }
-        int db;
-        step(nib, db);
-        b += db;
-        if (b == B) { b = 0; ++l; }
-        if (b < 0) { b = B - 1; --l; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
