@@ -96,7 +96,9 @@ struct Slot {
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
-      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws, d_align_out;
+      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws, d_align_out, d_cls_key, d_sort_k, d_sort_v;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_cap = 0;
   HostBuf<AlignRec> h_recs;
   HostBuf<uint32_t> h_runs;
   std::string err;
@@ -115,8 +117,10 @@ struct Slot {
   }
   void destroy() {
     for (DevBuf* b : {&d_units, &d_cls_list, &d_pair_head, &d_pair_bands, &d_pair_nbands, &d_ovf, &d_pair_ndiag, &d_pair_cells,
-                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws, &d_align_out})
+                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws, &d_align_out, &d_cls_key, &d_sort_k, &d_sort_v})
       b->release();
+    if (sort_tmp) (void)hipFree(sort_tmp);
+    sort_tmp = nullptr;
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_end) if (e) (void)hipEventDestroy(e);
@@ -132,6 +136,7 @@ struct qf_ctx : Slot {
   bool second_ready = false;
   hipEvent_t ev_tok = nullptr, ev_nll = nullptr;   // read tokens ready / null log-likelihoods ready
   uint32_t pipeline_chunks = 0;  // 0 = automatic
+  bool ragged_reads = false;     // resident read lengths differ by more than 25 %: class lists are sorted by length
   bool byte_prep = false;        // QUAFF_HIP_BYTE_PREP=1: first-generation read-preparation kernel (A/B)
   std::string devname;
   // model
@@ -500,10 +505,13 @@ int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t
   c->read_off.assign(offsets, offsets + n_reads + 1);
   c->read_total = n_reads ? offsets[n_reads] : 0;
   c->read_maxlen = 0;
+  uint64_t minlen = ~0ull;
   for (uint32_t r = 0; r < n_reads; ++r) {
     if (offsets[r + 1] <= offsets[r]) return fail(c, QF_ERR_ARG, "empty read (the reference drops zero-length sequences on load)");
     c->read_maxlen = std::max(c->read_maxlen, offsets[r + 1] - offsets[r]);
+    minlen = std::min(minlen, offsets[r + 1] - offsets[r]);
   }
+  c->ragged_reads = n_reads > 64 && c->read_maxlen * 4 > minlen * 5 && !getenv("QUAFF_HIP_NO_LENGTH_SORT");   // (A/B switch)
   if (c->read_maxlen > 0xFFFFu * 16ull) return fail(c, QF_ERR_UNSUPPORTED, "read longer than 1M bases");
   const uint64_t tot = c->read_total;
   HIPCHK(c, c->d_seq.reserve(tot + 16));
@@ -596,6 +604,7 @@ static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs
   s.units = S.d_units.as<Unit>();
   s.max_units = max_units;
   s.cls_list = S.d_cls_list.as<uint32_t>();
+  s.cls_key = c->ragged_reads ? S.d_cls_key.as<uint32_t>() : nullptr;
   s.pair_head = S.d_pair_head.as<uint32_t>();
   s.pair_bands = S.d_pair_bands.as<int2>();
   s.pair_nbands = S.d_pair_nbands.as<uint32_t>();
@@ -625,8 +634,25 @@ static int reserve_seed_workspace(Slot* c, SeedArgs& sa, bool mem, uint64_t n_pa
   return QF_OK;
 }
 
+// Ragged read lengths: a wavefront's bands run in lockstep for as long as the longest of them, so each class list is sorted
+// by read length (longest first) before the fills.
+static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_t max_units) {
+  if (!c->ragged_reads) return QF_OK;
+  HIPCHK(S, S->d_sort_k.reserve((size_t)max_units * 4));
+  HIPCHK(S, S->d_sort_v.reserve((size_t)max_units * 4));
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    if (cls == kRowClass || bc.cls_count[cls] <= 64) continue;
+    const int rc = sort_class_list(S->d_cls_key.as<uint32_t>() + (size_t)cls * max_units, S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units,
+                                   bc.cls_count[cls], S->d_sort_k.as<uint32_t>(), S->d_sort_v.as<uint32_t>(), &S->sort_tmp, &S->sort_tmp_cap,
+                                   S->stream);
+    if (rc) return fail(S, QF_ERR_DEVICE, "class-list sort failed");
+  }
+  return QF_OK;
+}
+
 static int reserve_pair_buffers(Slot* c, uint64_t n_pairs, uint32_t max_units) {
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
+  HIPCHK(c, c->d_cls_key.reserve((size_t)kNumClasses * max_units * 4));
   HIPCHK(c, c->d_units.reserve((size_t)max_units * sizeof(Unit)));
   HIPCHK(c, c->d_cls_list.reserve((size_t)kNumClasses * max_units * 4));
   HIPCHK(c, c->d_pair_head.reserve(n_pairs * 4));
@@ -695,6 +721,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     return QF_OK;
   }
   HIPCHK(S, S->d_tb.reserve(tb_bytes + 64));
+  if (int rc = sort_class_lists(c, S, bc, max_units)) return rc;
   FillArgs fa{};
   fa.n_refs = n_refs;
   fa.units = S->d_units.as<Unit>();
@@ -1087,6 +1114,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
     return QF_OK;
   }
   HIPCHK(c, c->d_fw.reserve(fw_bytes + 64));
+  if (int rc = sort_class_lists(c, c, bc, max_units)) return rc;
   HIPCHK(c, c->d_weight.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_fwd_out.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_order_out.reserve((size_t)n_pairs * 4));

@@ -897,6 +897,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
     return;
   }
   a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
+  if (a.cls_key) a.cls_key[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = (uint32_t)yLen;
   Unit u;
   u.pair = pair;
   u.dlo = dlo;

@@ -61,6 +61,7 @@ struct SeedArgs {
   uint32_t* pair_ndiag;        // [n_pairs]
   unsigned long long* pair_cells;  // [n_pairs] (zero-initialised)
   uint8_t* dump_cover;         // optional [nd] membership of a single pair
+  uint32_t* cls_key;           // optional [kNumClasses][max_units]: read length of each class-list entry (sort key)
   uint32_t* ws;                // global-memory seeding workspaces (sequences too long for the LDS histogram)
   uint64_t ws_words;           // 4-byte words per workspace
   uint32_t ws_slots;
@@ -203,6 +204,10 @@ void launch_null_ll(const PrepArgs& a, uint32_t n_reads, hipStream_t s);   // ne
 // this many copies of the table (summed at the end) so that popular (context, quality) entries are not serialised in L2.
 constexpr int kCountReplicas = 16;
 void launch_sum_count_replicas(double* counts, uint32_t n, uint64_t stride, hipStream_t s);
+// Sorts one class list by descending key (read length): the bands a wavefront takes together then have similar lengths
+// (a wavefront runs for its longest band) and the longest start first.  Returns 0 or a hipError_t.
+int sort_class_list(uint32_t* keys, uint32_t* list, uint32_t n, uint32_t* keys_tmp, uint32_t* list_tmp, void** temp,
+                    size_t* temp_cap, hipStream_t s);
 size_t seed_lds_bytes(int max_nd, bool mem);
 bool seed_needs_workspace(const SeedArgs& a, bool mem);
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);

@@ -47,4 +47,21 @@ int sort_kmer_index(const uint8_t* tok, const uint64_t* d_off, const int* d_off3
   return (int)e;
 }
 
+int sort_class_list(uint32_t* keys, uint32_t* list, uint32_t n, uint32_t* keys_tmp, uint32_t* list_tmp, void** temp,
+                    size_t* temp_cap, hipStream_t s) {
+  size_t need = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, keys, keys_tmp, list, list_tmp, (int)n, 0, 24, s);
+  if (e != hipSuccess) return (int)e;
+  if (need > *temp_cap) {
+    if (*temp) (void)hipFree(*temp);
+    *temp = nullptr;
+    *temp_cap = 0;
+    if ((e = hipMalloc(temp, need + 256)) != hipSuccess) return (int)e;
+    *temp_cap = need + 256;
+  }
+  e = hipcub::DeviceRadixSort::SortPairsDescending(*temp, need, keys, keys_tmp, list, list_tmp, (int)n, 0, 24, s);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemcpyAsync(list, list_tmp, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+}
+
 }  // namespace qf

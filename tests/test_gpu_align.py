@@ -363,3 +363,22 @@ def test_long_reference_global_seeding(ctx):
                 got = ctx.envelope(r, x, Q.DPConfig(**kw))
                 want = O.envelope(O.tokens(rf.seq), O.tokens(reads[r].seq), ocfg, 24)
                 assert np.array_equal(got, want), (nb, r, x, len(got), len(want))
+
+
+def test_ragged_batch_sorted_class_lists(ctx):
+    """More than 64 reads of very different lengths: the class lists are sorted by read length before the fills (the bands
+    a wavefront takes together run in lockstep); results must not care."""
+    rng = np.random.default_rng(31)
+    ref = rand_seq(rng, 2500)
+    sc, null = oracle_model()
+    reads = []
+    for n in range(72):
+        L = int(rng.integers(60, 700))
+        s = int(rng.integers(0, len(ref) - L))
+        src = ref[s:s + L]
+        if n & 1:
+            src = O.revcomp_str(src)
+        seq = mutate(rng, src)
+        reads.append(O.FastSeq("r%d" % n, seq, rand_qual(rng, len(seq))))
+    res = check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
+    assert len(res["alignments"]) == 72
