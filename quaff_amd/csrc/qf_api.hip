@@ -1403,6 +1403,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     return QF_OK;
   }
   HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
+  if (int rc = sort_class_lists(c, c, bc, max_units)) return rc;
   HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));

@@ -149,3 +149,17 @@ def test_overlap_wide_bands_row_space(ctx):
     g = reads[0].seq
     reads.append(O.FastSeq("short", g[100:135], rand_qual(rng, 35)))        # 35 < 2 * (6 + 14)
     check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
+
+
+def test_overlap_ragged_lengths_sorted_lists(ctx):
+    """More than 64 sequences of very different lengths: class lists are sorted by length before the fills."""
+    rng = np.random.default_rng(47)
+    g = rand_seq(rng, 1500)
+    reads = []
+    for k in range(34):
+        L = int(rng.integers(80, 500))
+        s = int(rng.integers(0, len(g) - L))
+        seq = mutate(rng, g[s:s + L], sub=0.04, ins=0.02, dele=0.02)
+        reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+    res, nfinite = check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
+    assert nfinite == len(O.overlap_task_pairs(34, 68))
