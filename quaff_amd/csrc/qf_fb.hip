@@ -103,6 +103,13 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
 #pragma unroll
   for (int b = 0; b < B; ++b) endTerm[b] = QF_NEG_INF;
   uint32_t gkPrev = 0;
+  // reference tokens of the lane's B rows as a sliding 2-bit window: the rows move down by one per step, so one new token
+  // per step (fetched a step ahead) instead of B byte gathers
+  auto xtok = [&](int idx0) -> uint32_t { return (idx0 >= 0 && idx0 < xLen) ? (uint32_t)xt[idx0] : 0u; };
+  unsigned long long win = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) win |= (unsigned long long)xtok(d0 + b + (0 - l + 1) - 1) << (2 * b);
+  uint32_t tokNext = xtok(d0 + B - 1 + (0 - l + 1));   // slot B-1's token at the next step
   for (int t = 0; t < T; ++t) {
     const int j = t - l + 1;
     const bool colvalid = active && j >= 1 && j <= yLen;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
     for (int b = 0; b < B; ++b) {
       const int d = d0 + b, i = d + j;
       const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
-      const uint32_t tok = valid ? xt[i - 1] : 0u;
+      const uint32_t tok = (uint32_t)(win >> (2 * b)) & 3u;
       const double e = ematch[erow4 + tok];
       // mat(i,j) = lse(lse(mat' + m2m, del' + d2m), ins' + i2m) [lse with start at column 1] + emit
       double nm = lseh(hs, lseh(hs, M[b] + m2m, D[b] + d2m), I[b] + i2m);
@@ -143,6 +150,8 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
       }
     }
     pubM = prevM; pubD = prevD;
+    win = (win >> 2) | ((unsigned long long)tokNext << (2 * (B - 1)));
+    tokNext = xtok(d0 + B - 1 + j + 1);
   }
   // end = lse(end, mat(i,yLen) + m2e) accumulated over rows in ascending order (src/qmodel.cpp:1379-1381): chain the
   // lanes one after the other
@@ -290,6 +299,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   uint32_t wNext = 0;           // context word of column j+1 (this lane's previous step)
   uint32_t gkEnd = 0;
 
+  // tokens of rows i+1 of the lane's B slots as a sliding 2-bit window (the rows move up by one per step)
+  auto xtok = [&](int idx0) -> uint32_t { return (idx0 >= 0 && idx0 < xLen) ? (uint32_t)xt[idx0] : 0u; };
+  unsigned long long win = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) win |= (unsigned long long)xtok(d0 + b + (yLen + rl)) << (2 * b);
+  uint32_t tokNext = xtok(d0 + (yLen + rl) - 1);   // slot 0's token at the next step
   for (int t = 0; t < T; ++t) {
     const int j = yLen - (t - rl);
     const bool colvalid = active && j >= 1 && j <= yLen;
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
     for (int b = B - 1; b >= 0; --b) {
       const int d = d0 + b, i = d + j;
       const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
-      const uint32_t tokN = (i >= 0 && i < xLen) ? xt[i] : 0u;  // token of row i+1
+      const uint32_t tokN = (uint32_t)(win >> (2 * b)) & 3u;   // token of row i+1
       const double eN = ematch[erowN4 + tokN];
       const double BmN = Bm[b];                                   // Bm(i+1, j+1), own diagonal, previous step
       const double BiN = b > 0 ? Bi[b - 1] : loI;                 // Bi(i, j+1), diagonal d-1 (not yet overwritten)
@@ -400,6 +415,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
       }
     }
     wNext = w;
+    win = ((win << 2) | tokNext) & ((B < 32 ? (1ull << (2 * B)) : 0ull) - 1ull);
+    tokNext = xtok(d0 + j - 2);
   }
   // context-free transitions, m2e and the Backward result (start), reduced over the unit's lanes
   for (int o = 1; o < G; o <<= 1) {
