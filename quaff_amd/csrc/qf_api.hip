@@ -823,6 +823,10 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     fin.runs_out = S->d_runs_out.as<uint32_t>();
     launch_traceback(fin, S->stream);
     HIPCHK(S, hipGetLastError());
+    // the final records do not wait for the run count: their copy is queued before the counters are read back
+    static_assert(sizeof(AlignOut) == sizeof(qf_alignment), "AlignOut mirrors qf_alignment");
+    if (dense && n_recs)
+      HIPCHK(S, hipMemcpyAsync(c->h_align.data() + lo, S->d_align_out.p, (size_t)n_recs * sizeof(AlignOut), hipMemcpyDeviceToHost, S->stream));
     if (int rc = read_counters(S, bc)) return rc;
     total_runs = bc.total_runs_out;
     if (bc.error & 16u) return fail(S, QF_ERR_DEVICE, "traceback did not reach the start state");
@@ -833,10 +837,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   const size_t recs0 = S->h_recs.size(), runs0 = S->h_runs.size();
   if (!dense) S->h_recs.resize(recs0 + n_recs);
   S->h_runs.resize(runs0 + total_runs);
-  static_assert(sizeof(AlignOut) == sizeof(qf_alignment), "AlignOut mirrors qf_alignment");
-  if (dense) {  // final records, in read order, straight into the result array
-    if (n_recs) HIPCHK(S, hipMemcpyAsync(c->h_align.data() + lo, S->d_align_out.p, (size_t)n_recs * sizeof(AlignOut), hipMemcpyDeviceToHost, S->stream));
-  } else if (n_recs) HIPCHK(S, hipMemcpyAsync(S->h_recs.data() + recs0, S->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, S->stream));
+  if (!dense && n_recs) HIPCHK(S, hipMemcpyAsync(S->h_recs.data() + recs0, S->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, S->stream));
   if (total_runs) HIPCHK(S, hipMemcpyAsync(S->h_runs.data() + runs0, S->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(S, hipEventRecord(S->ev[5], S->stream));
   HIPCHK(S, hipStreamSynchronize(S->stream));
