@@ -1382,7 +1382,16 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
 
 // Single-diagonal units (the lone diagonal 0, wrong-strand pairs): no neighbours, so ins = del = -inf and
 // the match state is a serial chain.  One lane per unit, 8 traceback nibbles per word.
+template <bool EMLDS>
 __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
+  // EMLDS: match-emission table in LDS (see k_viterbi_fill2).  The chain of a lane is serial, so what a round costs is the
+  // latency of its eight emission gathers: ~100 cycles from LDS against ~800 from L2.
+  extern __shared__ double lds_tab[];
+  if (EMLDS) {
+    const uint32_t n_em = a.dp.ematch_ninf_off / 8;
+    for (uint32_t q = threadIdx.x; q < n_em; q += 256) lds_tab[q] = a.dp.ematch[q];
+    __syncthreads();
+  }
   const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = uidx < a.n_cls_units;
   uint32_t uid = 0;
@@ -1398,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
   }
   int T = active ? yLen : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
-  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ ematch = EMLDS ? lds_tab : a.dp.ematch;
   const double* __restrict__ trans = a.dp.trans;
   const uint32_t Kg = a.dp.Kg;
   const bool local = a.dp.local != 0;
@@ -1908,7 +1917,13 @@ static void launch_fill_gb(const FillArgs& a, bool gapctx, hipStream_t s) {
 void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s) {
   if (a.n_cls_units == 0) return;
   switch (cls) {
-    case 0: hipLaunchKernelGGL(k_viterbi_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a); break;
+    case 0: {
+      const uint32_t lds_bytes = a.dp.ematch_ninf_off;
+      if (lds_bytes <= 52 * 1024 && !a.no_lds_tables)
+        hipLaunchKernelGGL(k_viterbi_single<true>, dim3((a.n_cls_units + 255) / 256), dim3(256), lds_bytes, s, a);
+      else hipLaunchKernelGGL(k_viterbi_single<false>, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a);
+      break;
+    }
     case 1: launch_fill_gb<16, 2>(a, gapctx, s); break;
     case 2: launch_fill_gb<16, 3>(a, gapctx, s); break;
     case 3: launch_fill_gb<16, 4>(a, gapctx, s); break;
