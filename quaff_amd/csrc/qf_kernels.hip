@@ -1415,50 +1415,63 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
   uint32_t* __restrict__ tb = a.tb + tb_off;
   double M = QF_NEG_INF, bestEnd = QF_NEG_INF;
   uint32_t bestI = 0, gkPrev = 0;
-  // Eight columns per round: the context words, reference tokens (2-bit packed) and emission scores of a round do not
-  // depend on the DP chain, so they are fetched as batches of independent loads one round ahead of the serial adds.
+  // Thirty-two columns per round.  The context words and reference tokens of a round do not depend on the DP chain: they are
+  // fetched a whole round (eight 16-byte loads + three token words per lane) ahead of the serial adds, so the global-memory
+  // latency is paid once per 32 columns; the emission scores of eight columns at a time come from the table (LDS).
   const uint32_t* __restrict__ xp = a.ref_packed + (active ? a.ref_woff[a.units[uid].pair % a.n_refs] : 0);
   const int nxw = (xLen + 15) / 16 + 2;
   auto xword = [&](int q) -> uint32_t { return xp[min(max(q, 0), nxw - 1)]; };
-  auto loadCtx = [&](int j0, U32x4& lo, U32x4& hi) {
-    const int base = min(j0 - 1, yLen);  // ctx is padded: indices up to yLen + kCtxPad are readable
-    lo = *(const U32x4*)(ctx + base);
-    hi = *(const U32x4*)(ctx + base + 4);
+  U32x4 cur[8], nxt[8];
+  uint32_t nx0, nx1, nx2;
+  auto fetch = [&](int j0) {   // columns j0 .. j0+31
+    const int base = min(j0 - 1, yLen);   // ctx is padded: indices up to yLen + kCtxPad are readable
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nxt[q] = *(const U32x4*)(ctx + min(base + 4 * q, yLen + 4));
+    const int r0 = d + j0 - 1;            // 0-based reference index of row i-1 at column j0
+    nx0 = xword(r0 >> 4); nx1 = xword((r0 >> 4) + 1); nx2 = xword((r0 >> 4) + 2);
   };
-  U32x4 cA, cB, nA, nB;
-  loadCtx(1, nA, nB);
-  int r0n = d;  // 0-based reference index of row i-1 at column j0 = 1
-  uint32_t nx0 = xword(r0n >> 4), nx1 = xword((r0n >> 4) + 1);
-  for (int j0 = 1; j0 <= T; j0 += 8) {
-    cA = nA; cB = nB;
-    const unsigned long long xpair = (((unsigned long long)nx1 << 32) | nx0) >> (2 * (r0n & 15));
-    loadCtx(j0 + 8, nA, nB);
-    r0n = d + j0 + 8 - 1;
-    nx0 = xword(r0n >> 4); nx1 = xword((r0n >> 4) + 1);
-    uint32_t w[8];
-    double e[8];
+  fetch(1);
+  for (int j0 = 1; j0 <= T; j0 += 32) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      w[c] = c < 4 ? cA.v[c] : cB.v[c - 4];
-      e[c] = ematch[(w[c] & 0x7FFFu) * 4u + ((uint32_t)(xpair >> (2 * c)) & 3u)];
-    }
-    uint32_t word = 0;
+    for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+    const int sh = 2 * ((d + j0 - 1) & 15);
+    const unsigned long long xlo = (((unsigned long long)nx1 << 32) | nx0) >> sh;   // tokens of columns j0 .. j0+15
+    const unsigned long long xhi = (((unsigned long long)nx2 << 32) | nx1) >> sh;   // ... j0+16 .. j0+31
+    fetch(j0 + 32);
+    U32x4 words4;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int j = j0 + c, i = d + j;
-      const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
-      const uint32_t gk = w[c] >> 24;
-      const double tM = (M + trans[j <= 1 ? 0u : gkPrev]) + e[c];
-      gkPrev = gk;
-      double nm = tM;
-      uint32_t sm = 0;
-      if (j == 1 && (i == 1 || local) && e[c] > nm) { nm = e[c]; sm = 3; }
-      if (!valid) nm = QF_NEG_INF;
-      M = nm;
-      word |= sm << (4 * c);
-      if (j == yLen && valid && (local || i == xLen)) { bestEnd = nm + trans[3 * Kg + gk]; bestI = (uint32_t)i; }
+    for (int g8 = 0; g8 < 4; ++g8) {
+      uint32_t w[8];
+      double e[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int cc = g8 * 8 + c;
+        w[c] = cur[cc >> 2].v[cc & 3];
+        const uint32_t tok = (uint32_t)((cc < 16 ? xlo : xhi) >> (2 * (cc & 15))) & 3u;
+        e[c] = ematch[(w[c] & 0x7FFFu) * 4u + tok];
+      }
+      uint32_t word = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int j = j0 + g8 * 8 + c, i = d + j;
+        const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
+        const uint32_t gk = w[c] >> 24;
+        const double tM = (M + trans[j <= 1 ? 0u : gkPrev]) + e[c];
+        gkPrev = gk;
+        double nm = tM;
+        uint32_t sm = 0;
+        if (j == 1 && (i == 1 || local) && e[c] > nm) { nm = e[c]; sm = 3; }
+        if (!valid) nm = QF_NEG_INF;
+        M = nm;
+        word |= sm << (4 * c);
+        if (j == yLen && valid && (local || i == xLen)) { bestEnd = nm + trans[3 * Kg + gk]; bestI = (uint32_t)i; }
+      }
+      words4.v[g8] = word;
     }
-    if (active && j0 <= yLen) tb[(j0 - 1) >> 3] = word;
+    // four traceback words (one per eight columns); the unit's words are allocated in whole rounds
+#pragma unroll
+    for (int g8 = 0; g8 < 4; ++g8)
+      if (active && j0 + 8 * g8 <= yLen) tb[((j0 - 1) >> 3) + g8] = words4.v[g8];
   }
   if (active) {
     a.units[uid].end_val = bestEnd;
