@@ -1844,13 +1844,38 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
         const int t = j - 1 + l;
         const bool cell = i >= 1 && j >= 1;
         const bool inwin = (unsigned)(l - cl + 1) < 3u && (unsigned)(ct - (t >> 3)) < 2u;
-        const uint32_t wv = win[(cell && inwin) ? 16 * l + kw - t + 2 * (t & 7) : 0];
+        const int widx = (cell && inwin) ? 16 * l + kw - t + 2 * (t & 7) : 0;
+        const uint32_t wv = win[widx];
         if (walking() && (inwin || !cell)) {
-          int db;
-          step(cell ? (wv >> (4 * b)) & 0xFu : 0u, db);
-          b += db;
-          if (b == B) { b = 0; ++l; }
-          if (b < 0) { b = B - 1; --l; }
+          // A match run: if every remaining step of this tile (t, t-1, ... down to the tile's first) came from the match
+          // state, take them all at once (the words of one fill lane's tile are consecutive in the window).
+          bool skipped = false;
+          if (state == 1 && cell && inwin) {
+            const int tt = t & 7;
+            uint32_t orw = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+              const uint32_t wm = win[widx - tt + m];
+              orw |= m <= tt ? wm : 0u;
+            }
+            const int kk = tt + 1;
+            if (kk > 1 && ((orw >> (4 * b)) & 3u) == 0u && kk <= i && kk <= j) {
+              i -= kk; j -= kk; ncol += (uint32_t)kk;
+              if (curOp == 0u) curLen += (uint32_t)kk;
+              else {
+                if (curLen) tmp[n++] = (curLen << 2) | curOp;
+                curOp = 0u; curLen = (uint32_t)kk;
+              }
+              skipped = true;
+            }
+          }
+          if (!skipped) {
+            int db;
+            step(cell ? (wv >> (4 * b)) & 0xFu : 0u, db);
+            b += db;
+            if (b == B) { b = 0; ++l; }
+            if (b < 0) { b = B - 1; --l; }
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
