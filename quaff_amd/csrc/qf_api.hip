@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -1063,6 +1064,29 @@ uint32_t qf_counts_size(const qf_ctx* c) {
   return (uint32_t)((4 + 4 * c->scores.Km) * kNQual + 4 * c->scores.Kg + 4);
 }
 
+// Classes of one phase on concurrent streams (the class with the most cells on the main stream, the others on the low-
+// priority side streams), joined back into the main stream: small classes fill the tail of the big one.
+static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool serial,
+                                       const std::function<void(int, hipStream_t)>& launch) {
+  int order[kNumClasses], n_used = 0;
+  for (int cls = 1; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
+  std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
+  if (n_used > 1 && !serial) {   // side streams start after everything queued on the main stream so far
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    for (auto& s : c->aux) HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
+  }
+  for (int k = 0; k < n_used; ++k) {
+    const int cls = order[k], lane = serial ? 0 : (k < 4 ? k : 1 + (k - 1) % 3);
+    hipStream_t s = lane == 0 ? c->stream : c->aux[lane - 1];
+    launch(cls, s);
+    if (lane) {
+      HIPCHK(c, hipEventRecord(c->cls_end[cls], s));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[cls], 0));
+    }
+  }
+  return QF_OK;
+}
+
 // Forward-Backward over reads [lo, hi) of the resident set; counts accumulate in d_counts, per-read / per-pair results go to
 // the host arrays at the chunk's offsets.  Sets *too_big (and does nothing) when the Forward matrices exceed the budget.
 static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
@@ -1147,11 +1171,14 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.counts = c->d_counts.as<double>();
   fa.counts_stride = (csize + 31) & ~31ull;
   fa.Km = sc.Km;
-  for (int cls = kNumClasses - 1; cls >= 1; --cls) {
-    fa.n_cls_units = bc.cls_count[cls];
-    fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-    launch_forward_fill(cls, fa, c->stream);
-  }
+  const bool serial_classes = (cfg->reserved & 4) != 0;
+  if (int rc = launch_classes_concurrently(c, bc, serial_classes, [&](int cls, hipStream_t s) {
+        FbArgs f2 = fa;
+        f2.n_cls_units = bc.cls_count[cls];
+        f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+        launch_forward_fill(cls, f2, s);
+      }))
+    return rc;
   FinalArgs fin{};
   fin.n_pairs = n_pairs;
   fin.n_reads = n_reads;
@@ -1183,11 +1210,13 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
 
   // ---- Backward + counts
-  for (int cls = kNumClasses - 1; cls >= 1; --cls) {
-    fa.n_cls_units = bc.cls_count[cls];
-    fa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-    launch_backward_fill(cls, fa, c->stream);
-  }
+  if (int rc = launch_classes_concurrently(c, bc, serial_classes, [&](int cls, hipStream_t s) {
+        FbArgs f2 = fa;
+        f2.n_cls_units = bc.cls_count[cls];
+        f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+        launch_backward_fill(cls, f2, s);
+      }))
+    return rc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
 
