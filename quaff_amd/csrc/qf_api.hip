@@ -1067,9 +1067,9 @@ uint32_t qf_counts_size(const qf_ctx* c) {
 // Classes of one phase on concurrent streams (the class with the most cells on the main stream, the others on the low-
 // priority side streams), joined back into the main stream: small classes fill the tail of the big one.
 static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool serial,
-                                       const std::function<void(int, hipStream_t)>& launch) {
+                                       const std::function<void(int, hipStream_t)>& launch, int first_cls = 1) {
   int order[kNumClasses], n_used = 0;
-  for (int cls = 1; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
+  for (int cls = first_cls; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
   std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
   if (n_used > 1 && !serial) {   // side streams start after everything queued on the main stream so far
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
@@ -1467,12 +1467,14 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
   oa.recs = c->d_recs.as<AlignRec>();
   oa.bc = c->d_bc.as<BatchCounters>();
-  for (int cls = kNumClasses - 1; cls >= 0; --cls) {
-    if (cls > 10 && cls != kRowClass) continue;
-    oa.n_cls_units = bc.cls_count[cls];
-    oa.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-    launch_overlap_fill(cls, oa, c->stream);
-  }
+  if (int rc = launch_classes_concurrently(c, bc, (cfg->reserved & 4) != 0, [&](int cls, hipStream_t s) {
+        if (cls > 10 && cls != kRowClass) return;
+        OvArgs o2 = oa;
+        o2.n_cls_units = bc.cls_count[cls];
+        o2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+        launch_overlap_fill(cls, o2, s);
+      }, 0))
+    return rc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   launch_overlap_finalize(oa, c->stream);
