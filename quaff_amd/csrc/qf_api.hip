@@ -615,6 +615,7 @@ static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs
   s.pair_cells = S.d_pair_cells.as<unsigned long long>();
   s.force_block_kernel = cfg->reserved & 1;  // debug/testing: workgroup-per-pair seeding kernel
   s.max_ref_len = (uint32_t)std::min<uint64_t>(c->ref_maxlen, 0xFFFFFFFFull);
+  s.max_read_len = (uint32_t)std::min<uint64_t>(c->read_maxlen, 0xFFFFFFFFull);
   s.no_lds_index = (cfg->reserved >> 4) & 1;
   s.bc = S.d_bc.as<BatchCounters>();
 }

@@ -597,7 +597,8 @@ struct __attribute__((packed, aligned(4))) U32x4u { uint32_t v[4]; };
 
 // LDSIDX: the reference's k-mer index (bucket starts and positions, 16 bits each) sits in LDS (sb, sp) instead of being
 // gathered from global memory.
-template <bool LDSIDX>
+// WIDE: 32-bit coarse counters (a 32-diagonal bin of a read of 2 048+ bases can collect 65 536 matches and wrap 16 bits)
+template <bool LDSIDX, bool WIDE>
 __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair, uint32_t r, uint32_t x, uint32_t* wlds,
                                                const uint16_t* sb, const uint16_t* sp) {
   // Two-level histogram.  Pass 1 counts k-mer matches per COARSE bin of 32 diagonals; a diagonal can reach
@@ -620,9 +621,9 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
       for (int b = lane; b < nd; b += 64) a.dump_cover[b] = 1;
     return;
   }
-  const int nCoarse = (nd + 31) >> 5, coarseWords = (nCoarse + 1) / 2, bmWords = nCoarse;
-  uint32_t* coarse = wlds;                                   // two 16-bit counters per dword; later: slot map
-  uint32_t* bm = coarse + (((a.max_nd + 31) / 32 + 1) / 2 + 1);  // membership bitmap, one bit per diagonal
+  const int nCoarse = (nd + 31) >> 5, coarseWords = WIDE ? nCoarse : (nCoarse + 1) / 2, bmWords = nCoarse;
+  uint32_t* coarse = wlds;                                   // two 16-bit counters per dword (one if WIDE); later: slot map
+  uint32_t* bm = coarse + (WIDE ? ((a.max_nd + 31) / 32 + 2) : (((a.max_nd + 31) / 32 + 1) / 2 + 1));  // membership bitmap, one bit per diagonal
   uint32_t* fine = bm + ((a.max_nd + 31) / 32 + 1);          // [kCand][16] dwords = 32 x 16-bit counters each
   uint32_t* misc = fine + kCand * 16;                        // [0] candidate count, [1..kCand] candidate bins
 
@@ -679,7 +680,10 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
       }
     }
   };
-  walk([&](int bin) { atomicAdd(&coarse[bin >> 6], 1u << (16 * ((bin >> 5) & 1))); });
+  walk([&](int bin) {
+    if (WIDE) atomicAdd(&coarse[bin >> 5], 1u);
+    else atomicAdd(&coarse[bin >> 6], 1u << (16 * ((bin >> 5) & 1)));
+  });
   wave_lds_sync();
 
   // candidate coarse bins; afterwards the coarse array holds each bin's candidate slot (0xFFFF = none)
@@ -688,13 +692,21 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
   for (int w0 = 0; w0 < coarseWords; w0 += 64) {
     const int w = w0 + (int)lane;
     uint32_t hv = w < coarseWords ? coarse[w] : 0u, outv = 0xFFFFFFFFu;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-      if (((hv >> (16 * c)) & 0xFFFFu) >= thr) {
+    if (WIDE) {
+      if (hv >= thr) {
         const uint32_t slot = atomicAdd(&misc[0], 1u);
-        if (slot < 0xFFFFu) outv = (outv & ~(0xFFFFu << (16 * c))) | (slot << (16 * c));
-        if (slot < (uint32_t)kCand) misc[1 + slot] = (uint32_t)(2 * w + c);   // first round's bins, for the seed scan
-      }
+        if (slot < 0xFFFFu) outv = slot;
+        if (slot < (uint32_t)kCand) misc[1 + slot] = (uint32_t)w;
+      } else outv = 0xFFFFu;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (((hv >> (16 * c)) & 0xFFFFu) >= thr) {
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < 0xFFFFu) outv = (outv & ~(0xFFFFu << (16 * c))) | (slot << (16 * c));
+          if (slot < (uint32_t)kCand) misc[1 + slot] = (uint32_t)(2 * w + c);   // first round's bins, for the seed scan
+        }
+    }
     if (w < coarseWords) coarse[w] = outv;
   }
   wave_lds_sync();
@@ -708,7 +720,7 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
       atomicOr(&bm[w], (0xFFFFFFFFu >> (31 - bhi)) & (0xFFFFFFFFu << blo));
     }
   };
-  auto slotOf = [&](int cb) -> uint32_t { return (coarse[cb >> 1] >> (16 * (cb & 1))) & 0xFFFFu; };
+  auto slotOf = [&](int cb) -> uint32_t { return WIDE ? (coarse[cb] & 0xFFFFu) : (coarse[cb >> 1] >> (16 * (cb & 1))) & 0xFFFFu; };
   for (uint32_t base = 0; base < ncand; base += kCand) {  // almost always one round
     for (int w = lane; w < kCand * 16; w += 64) fine[w] = 0;
     wave_lds_sync();
@@ -776,6 +788,7 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
 
 // One wavefront per (read, ref) pair, four pairs per workgroup; the index is gathered from global memory (any reference
 // set, explicit pair lists).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words) {
   extern __shared__ uint32_t lds[];
   const uint32_t wv = threadIdx.x >> 6;
@@ -785,13 +798,14 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   if (a.pair_skip && a.pair_skip[pair]) return;
   uint32_t r, x;
   pair_rx(a, pair, r, x);
-  seed_wave_pair<false>(a, pair, r, x, lds + (size_t)wv * wave_lds_words, nullptr, nullptr);
+  seed_wave_pair<false, WIDE>(a, pair, r, x, lds + (size_t)wv * wave_lds_words, nullptr, nullptr);
 }
 
 // Short references (k-mer index of one reference <= 48 KB as 16-bit entries): a workgroup of eight wavefronts copies one
 // reference's index to LDS and seeds kSeedReadsPerBlock reads against it.  The global-memory version spends two thirds
 // of its cycles waiting on L1 misses of those gathers (measured); here the only global traffic is the reads' k-mers.
 constexpr uint32_t kSeedReadsPerBlock = 64;
+template <bool WIDE>
 __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_reads, uint32_t wave_lds_words, uint32_t idx_words) {
   extern __shared__ uint32_t lds[];
   const uint32_t wv = threadIdx.x >> 6;
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_re
   for (uint32_t r = r0 + wv; r < min(r0 + kSeedReadsPerBlock, n_reads); r += 8) {
     const uint32_t pair = a.pair_base + r * a.n_refs + x;
     if (a.pair_skip && a.pair_skip[pair]) continue;
-    seed_wave_pair<true>(a, pair, r, x, wlds, sb, sp);
+    seed_wave_pair<true, WIDE>(a, pair, r, x, wlds, sb, sp);
     wave_lds_sync();
   }
 }
@@ -2016,7 +2030,7 @@ bool seed_needs_workspace(const SeedArgs& a, bool mem) {
   if (!a.sparse) return false;
   if (!mem && a.threshold >= 0 && !a.force_block_kernel) {
     const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
-    const uint32_t words = ((nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
+    const uint32_t words = (a.max_read_len >= 2040 ? nc + 2 : (nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
     if ((size_t)words * 4 * 4 <= 150 * 1024) return false;
   }
   return seed_lds_bytes(a.max_nd, mem) > 150 * 1024;
@@ -2026,7 +2040,8 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!mem && a.sparse && a.threshold >= 0 && !a.force_block_kernel) {
     // one wavefront per pair, four pairs per workgroup; LDS per wave: coarse counters + bitmap + fine counters
     const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
-    const uint32_t words = ((nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
+    const bool wide = a.max_read_len >= 2040;   // 32 diagonals x (read length - k + 1) matches could wrap a 16-bit counter
+    const uint32_t words = (wide ? nc + 2 : (nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
     const size_t lds = (size_t)words * 4 * 4;
     // LDS-resident index: bucket-indexed (k <= 8), implicit read x ref pair order, 16-bit positions, <= 48 KB
     if (!a.pair_x && !a.ref_skeys && a.nbuckets && a.max_ref_len && a.max_ref_len + 4 < 65536 && !a.dump_cover && !a.no_lds_index) {
@@ -2035,14 +2050,24 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
       if ((size_t)idx_words * 4 <= 48 * 1024 && lds2 <= 80 * 1024 && n_pairs % a.n_refs == 0) {
         const uint32_t n_reads = n_pairs / a.n_refs;
         const uint32_t blocks = ((n_reads + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock) * a.n_refs;
-        if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        hipLaunchKernelGGL(k_seed_wave_lds, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
+        if (wide) {
+          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+          hipLaunchKernelGGL(k_seed_wave_lds<true>, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
+        } else {
+          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+          hipLaunchKernelGGL(k_seed_wave_lds<false>, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
+        }
         return 0;
       }
     }
     if (lds <= 150 * 1024) {
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_seed_wave, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
+      if (wide) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_seed_wave<true>, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
+      } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_seed_wave<false>, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
+      }
       return 0;
     }
   }

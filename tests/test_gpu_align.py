@@ -382,3 +382,17 @@ def test_ragged_batch_sorted_class_lists(ctx):
         reads.append(O.FastSeq("r%d" % n, seq, rand_qual(rng, len(seq))))
     res = check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
     assert len(res["alignments"]) == 72
+
+
+def test_long_reads_wide_seed_counters(ctx):
+    """Reads of 2 048+ bases switch the seeding to 32-bit coarse counters (a 32-diagonal bin could otherwise wrap 16 bits);
+    a low-complexity pair puts ~95 000 matches into single bins."""
+    rng = np.random.default_rng(33)
+    ref = rand_seq(rng, 5000)
+    sc, null = oracle_model()
+    reads = make_reads(rng, ref, 3, 2600)
+    check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
+    lowc = "A" * 1500 + rand_seq(rng, 300) + "A" * 1500
+    rd = O.FastSeq("polyA", "A" * 1400 + lowc[1500:1800] + "A" * 1400, rand_qual(rng, 3100))
+    res = check_against_oracle(ctx, [O.FastSeq("lowc", lowc)], [rd], dict(), sc, null)
+    assert res["n_diagonals"].max() > 3000
