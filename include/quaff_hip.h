@@ -121,7 +121,9 @@ void qf_ctx_destroy(qf_ctx *ctx);
 const char *qf_last_error(const qf_ctx *ctx);   /* ctx may be NULL: last creation error */
 int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
 /* Device bytes one internal chunk may use for traceback / Forward storage (default 160 GiB; 0 restores it).  Larger
- * batches are processed in halves transparently. */
+ * batches are processed in halves transparently.  (The reference bounds DP memory per thread through -kmatchmb /
+ * -kmatchmax, src/qmodel.cpp:788-813,1058-1060, and runs reads one at a time; here whole batches are resident, so the
+ * bound is on the batch.) */
 int qf_set_memory_budget(qf_ctx *ctx, uint64_t bytes);
 /* qf_align_* cuts a batch into this many pieces and keeps two in flight (one piece's seeding and traceback overlap the
  * other's fill).  0 = default (1: the whole batch at once).  Results do not depend on it. */
