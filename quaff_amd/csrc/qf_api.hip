@@ -673,6 +673,32 @@ static int reserve_pair_buffers(Slot* c, uint64_t n_pairs, uint32_t max_units) {
   return QF_OK;
 }
 
+// Seeds the slot's pairs and bins their bands.  The unit table and the band overflow list are provisioned for four bands per
+// pair; a batch with more (low thresholds, narrow bands, repeats) gets them grown to what it asked for and is seeded again.
+static int seed_pairs(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t n_pairs, bool mem, int max_nd,
+                      const std::function<void(SeedArgs&)>& customize, uint32_t& max_units, SeedArgs& sa, BatchCounters& bc) {
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = reserve_pair_buffers(S, n_pairs, max_units)) return rc;
+    fill_seed_args(c, *S, cfg, sa, max_units, max_nd);
+    customize(sa);
+    if (int rc = reserve_seed_workspace(S, sa, mem, n_pairs)) return rc;
+    if (launch_seed(sa, n_pairs, mem, S->stream) != 0)
+      return fail(S, QF_ERR_UNSUPPORTED, "sequence pair of " + std::to_string(max_nd) + " diagonals: no seeding workspace");
+    launch_bin_units(sa, n_pairs, 0, S->stream);
+    HIPCHK(S, hipGetLastError());
+    if (int rc = read_counters(S, bc)) return rc;
+    if (bc.n_ovf && !(bc.error & 8u)) {  // pairs with more than kMaxBandsPerPair bands: second binning pass
+      launch_bin_units(sa, n_pairs, bc.n_ovf, S->stream);
+      HIPCHK(S, hipGetLastError());
+      if (int rc = read_counters(S, bc)) return rc;
+    }
+    if (!(bc.error & 9u)) return QF_OK;
+    const uint64_t want = std::max<uint64_t>({2ull * max_units, (uint64_t)bc.n_ovf + 1024, (uint64_t)bc.n_units + bc.n_ovf + 1024});
+    if (attempt == 5 || want > 0x3FFFFFFFull) return fail(S, QF_ERR_MEMORY, "more envelope bands than the unit table can hold");
+    max_units = (uint32_t)want;
+  }
+}
+
 // Reads [lo, hi) of the resident set against every reference.  Results go to the context's host arrays at the chunk's
 // offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
 // *too_big is set (the caller splits the range).
@@ -683,8 +709,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   const uint32_t n_pairs = n_reads * n_refs;
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
-  const uint32_t max_units = n_pairs * 4 + 1024;
-  if (int rc = reserve_pair_buffers(S, n_pairs, max_units)) return rc;
+  uint32_t max_units = n_pairs * 4 + 1024;
   const uint64_t* d_roff = c->d_roff.as<uint64_t>() + lo;   // the chunk's reads: offsets stay absolute, indices local
   const double* d_nll = c->d_nll.as<double>() + lo;
   HIPCHK(S, hipEventRecord(S->ev[1], S->stream));
@@ -692,28 +717,11 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   // ---- seeding
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
-  fill_seed_args(c, *S, cfg, sa, max_units, sparse ? max_nd : 2);
-  sa.read_off = d_roff;
-  if (int rc = reserve_seed_workspace(S, sa, mem, n_pairs)) return rc;
-  if (launch_seed(sa, n_pairs, mem, S->stream) != 0)
-    return fail(S, QF_ERR_UNSUPPORTED, "reference + read length " + std::to_string(max_nd) +
-                                           " exceeds the LDS diagonal histogram (global-memory histogram not built yet)");
-  launch_bin_units(sa, n_pairs, 0, S->stream);
-  HIPCHK(S, hipGetLastError());
-  HIPCHK(S, hipEventRecord(S->ev[2], S->stream));
   BatchCounters bc;
-  if (int rc = read_counters(S, bc)) return rc;
-  if (bc.n_ovf && !(bc.error & 8u)) {  // pairs with more than kMaxBandsPerPair bands: second binning pass
-    launch_bin_units(sa, n_pairs, bc.n_ovf, S->stream);
-    HIPCHK(S, hipGetLastError());
-    HIPCHK(S, hipEventRecord(S->ev[2], S->stream));
-    if (int rc = read_counters(S, bc)) return rc;
-  }
+  if (int rc = seed_pairs(c, S, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) { s.read_off = d_roff; }, max_units, sa, bc)) return rc;
+  HIPCHK(S, hipEventRecord(S->ev[2], S->stream));
   if (bc.error & 4u) return fail(S, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u) return fail(S, QF_ERR_UNSUPPORTED, "unsupported band of " + std::to_string(bc.error_detail) + " diagonals");
-  if (bc.error & 8u)
-    return fail(S, QF_ERR_MEMORY, "band overflow list exhausted");
-  if (bc.error & 1u) return fail(S, QF_ERR_MEMORY, "unit table overflow");
 
   // ---- fill
   const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
@@ -1098,9 +1106,8 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   const size_t p0 = (size_t)lo * n_refs;
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
-  const uint32_t max_units = n_pairs * 4 + 1024;
+  uint32_t max_units = n_pairs * 4 + 1024;
   const uint32_t csize = qf_counts_size(c);
-  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
   const uint64_t* d_roff = c->d_roff.as<uint64_t>() + lo;
   const uint8_t* d_skip = have_sort ? c->d_skip.as<uint8_t>() + p0 : nullptr;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1108,29 +1115,18 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   // ---- seeding (cellSize = 2 * 24 for counting, qmodel.cpp:2249; only matters in memory mode)
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
-  fill_seed_args(c, *c, cfg, sa, max_units, sparse ? max_nd : 2);
-  sa.read_off = d_roff;
-  sa.cell_size = 48;
-  sa.storage_mode = 1;
-  sa.pair_skip = d_skip;
-  if (int rc = reserve_seed_workspace(c, sa, mem, n_pairs)) return rc;
-  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
-    return fail(c, QF_ERR_UNSUPPORTED, "reference + read length exceeds the LDS diagonal histogram");
-  launch_bin_units(sa, n_pairs, 0, c->stream);
-  HIPCHK(c, hipGetLastError());
   BatchCounters bc;
-  if (int rc = read_counters(c, bc)) return rc;
-  if (bc.n_ovf && !(bc.error & 8u)) {
-    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (int rc = read_counters(c, bc)) return rc;
-  }
+  if (int rc = seed_pairs(c, c, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
+        s.read_off = d_roff;
+        s.cell_size = 48;
+        s.storage_mode = 1;
+        s.pair_skip = d_skip;
+      }, max_units, sa, bc))
+    return rc;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u)
     return fail(c, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels");
-  if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
-  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
 
   // ---- Forward
   const uint64_t fw_bytes = (uint64_t)bc.tb_words * 8;
@@ -1392,39 +1388,27 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
   const Scores& sc = c->scores;
-  const uint32_t max_units = n_pairs * 4 + 1024;
-  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  uint32_t max_units = n_pairs * 4 + 1024;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
   // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
   const int max_nd = (int)(2 * c->read_maxlen - 1);
   SeedArgs sa;
-  fill_seed_args(c, *c, cfg, sa, max_units, sparse ? max_nd : 2);
-  sa.pair_x = c->d_px.as<uint32_t>() + lo;
-  sa.pair_y = c->d_py.as<uint32_t>() + lo;
-  sa.ref_off = c->d_roff.as<uint64_t>();
-  sa.ref_bucket = c->d_rbucket.as<uint32_t>();
-  sa.ref_pos = c->d_rpos.as<uint32_t>();
-  sa.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
-  sa.storage_mode = 2;
-  if (int rc = reserve_seed_workspace(c, sa, mem, n_pairs)) return rc;
-  if (launch_seed(sa, n_pairs, mem, c->stream) != 0)
-    return fail(c, QF_ERR_UNSUPPORTED, "read + read length exceeds the LDS diagonal histogram");
-  launch_bin_units(sa, n_pairs, 0, c->stream);
-  HIPCHK(c, hipGetLastError());
   BatchCounters bc;
-  if (int rc = read_counters(c, bc)) return rc;
-  if (bc.n_ovf && !(bc.error & 8u)) {
-    launch_bin_units(sa, n_pairs, bc.n_ovf, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (int rc = read_counters(c, bc)) return rc;
-  }
+  if (int rc = seed_pairs(c, c, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
+        s.pair_x = c->d_px.as<uint32_t>() + lo;
+        s.pair_y = c->d_py.as<uint32_t>() + lo;
+        s.ref_off = c->d_roff.as<uint64_t>();
+        s.ref_bucket = c->d_rbucket.as<uint32_t>();
+        s.ref_pos = c->d_rpos.as<uint32_t>();
+        s.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
+        s.storage_mode = 2;
+      }, max_units, sa, bc))
+    return rc;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u)
     return fail(c, QF_ERR_UNSUPPORTED, "unsupported overlap band of " + std::to_string(bc.error_detail) + " diagonals");
-  if (bc.error & 8u) return fail(c, QF_ERR_MEMORY, "band overflow list exhausted");
-  if (bc.error & 1u) return fail(c, QF_ERR_MEMORY, "unit table overflow");
 
   // ---- fill
   const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;

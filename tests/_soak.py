@@ -1,0 +1,37 @@
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+import quaff_amd as Q
+from oracle import oracle as O
+from tests.helpers import rand_seq, mutate, rand_qual
+from tests.test_gpu_align import check_against_oracle, both_strands, oracle_model, NULL_JSON
+c = Q.Context(0); c.set_params_json(None); c.set_null_json(NULL_JSON)
+sc, null = oracle_model()
+t0 = time.time()
+n_ok = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(1000 + seed)
+    ref = rand_seq(rng, int(rng.integers(1500, 12000)))
+    if rng.random() < 0.3:   # repeats
+        p = int(rng.integers(0, len(ref) - 400)); ref = ref[:p] + ref[p:p + 300] * 2 + ref[p + 300:]
+    n = int(rng.integers(3, 90))
+    reads = []
+    for k in range(n):
+        L = int(rng.integers(30, min(2600, len(ref) - 10)))
+        s = int(rng.integers(0, len(ref) - L)); src = ref[s:s + L]
+        if rng.random() < 0.5: src = O.revcomp_str(src)
+        seq = mutate(rng, src, sub=rng.uniform(0, .1), ins=rng.uniform(0, .06), dele=rng.uniform(0, .06))
+        if len(seq) == 0: seq = "A"
+        reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+    kw = dict(kmer_len=int(rng.integers(4, 9)), kmer_threshold=int(rng.integers(2, 30)), band_size=int(rng.integers(4, 140)),
+              local=bool(rng.random() < 0.8))
+    if rng.random() < 0.15: kw = dict(kmer_threshold=-1, max_size=int(rng.integers(1, 300)) * 600 * 24)
+    if rng.random() < 0.08: kw = dict(sparse=False)
+    quals = rng.random() < 0.85
+    pall = rng.random() < 0.3
+    try:
+        check_against_oracle(c, both_strands(ref), reads, kw, sc, null, quals=quals, print_all=pall)
+        n_ok += 1
+    except Exception as e:
+        print("FAIL seed", seed, kw, "n", n, "quals", quals, "printall", pall, type(e).__name__, str(e)[:300]); sys.stdout.flush()
+    if seed % 5 == 0: print("seed", seed, "ok so far", n_ok, "elapsed %.0fs" % (time.time() - t0)); sys.stdout.flush()
+print("done", n_ok)

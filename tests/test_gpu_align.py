@@ -396,3 +396,14 @@ def test_long_reads_wide_seed_counters(ctx):
     rd = O.FastSeq("polyA", "A" * 1400 + lowc[1500:1800] + "A" * 1400, rand_qual(rng, 3100))
     res = check_against_oracle(ctx, [O.FastSeq("lowc", lowc)], [rd], dict(), sc, null)
     assert res["n_diagonals"].max() > 3000
+
+
+def test_many_bands_grow_unit_tables(ctx):
+    """Low threshold + short k-mers + narrow bands: dozens of bands per pair, far more than the four per pair the unit table
+    and the overflow list are provisioned for; the seeding is repeated with grown tables (found by a randomized soak)."""
+    rng = np.random.default_rng(34)
+    ref = rand_seq(rng, 2500)
+    sc, null = oracle_model()
+    reads = make_reads(rng, ref, 10, 350)
+    res = check_against_oracle(ctx, both_strands(ref), reads, dict(kmer_len=4, kmer_threshold=3, band_size=6), sc, null)
+    assert res["n_units"] > 4 * 20 + 1024
