@@ -213,12 +213,12 @@ __global__ void k_count_plan(CountPlanArgs a) {
     const double ll = listed ? a.pair_fwd[p] : QF_NEG_INF;
     if (!listed) a.pair_fwd_out[p] = QF_NEG_INF; else a.pair_fwd_out[p] = ll;
     a.weight[p] = (a.weight[p] != 0.0 && ll > QF_NEG_INF) ? exp(ll - ylog) : 0.0;
-    if (!(ll < ylog - 20.0)) {  // insertion sort, LL descending (ties: lower index first)
+    if (!(ll < ylog - 20.0)) {  // insertion sort, LL descending
       uint32_t k = n++;
       while (k > 0) {
         const uint32_t y = out[k - 1];
         const double lly = a.pair_fwd_out[(uint64_t)r * a.n_refs + y];
-        if (lly >= ll) break;
+        if (lly > ll) break;   // ties: the later reference first (ascending stable sort, then reversed: util.h:115-124, qmodel.cpp:2264-2265)
         out[k] = y;
         --k;
       }

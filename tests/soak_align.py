@@ -1,3 +1,7 @@
+"""Randomized GPU-vs-oracle soak for the align path (not collected by pytest): `python tests/soak_align.py FIRST LAST` runs
+seeds FIRST..LAST-1, each a random reference (sometimes with a tandem repeat), 3-90 ragged reads on both strands, random
+-kmatch / -kmatchn / -kmatchband (or memory mode, or -kmatchoff), local or global, with or without qualities, best or
+-printall, and compares everything check_against_oracle compares.  This is how the unit-table growth was found."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import quaff_amd as Q

@@ -1,0 +1,44 @@
+"""Randomized GPU-vs-oracle soak for count (even seeds) and overlap (odd seeds), parameter orders 0..2 (not collected by
+pytest): `python tests/soak_count_overlap.py FIRST LAST`.  Found the tie order of the next-iteration reference list."""
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+import quaff_amd as Q
+from oracle import oracle as O
+from tests.helpers import rand_seq, mutate, rand_qual
+from tests.test_gpu_align import both_strands, NULL_JSON, DEFAULT_JSON, synth_params_json
+from tests.test_gpu_count import run_case
+from tests.test_gpu_overlap import check_overlap
+c = Q.Context(0); c.set_params_json(None); c.set_null_json(NULL_JSON)
+null = O.NullParams.from_json(NULL_JSON)
+t0 = time.time(); ok = 0; bad = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(5000 + seed)
+    order = int(rng.integers(0, 3))
+    pj = DEFAULT_JSON if order == 0 else synth_params_json(rng, order + 1, order)
+    c.set_params_json(None if order == 0 else pj)
+    sc = O.Scores(O.Params.from_json(pj))
+    ref = rand_seq(rng, int(rng.integers(600, 3000)))
+    n = int(rng.integers(2, 70))
+    reads = []
+    for k in range(n):
+        L = int(rng.integers(25, min(700, len(ref) - 10)))
+        s = int(rng.integers(0, len(ref) - L)); src = ref[s:s + L]
+        if rng.random() < 0.5: src = O.revcomp_str(src)
+        seq = mutate(rng, src, sub=rng.uniform(0, .08), ins=rng.uniform(0, .05), dele=rng.uniform(0, .05)) or "A"
+        reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+    try:
+        if seed % 2 == 0:
+            kw = dict(kmer_len=int(rng.integers(4, 8)), kmer_threshold=int(rng.integers(3, 25)), band_size=int(rng.integers(6, 100)),
+                      local=bool(rng.random() < 0.8))
+            if rng.random() < 0.1: kw = dict(sparse=False)
+            run_case(c, both_strands(ref), reads, sc, null, cfg_kw=kw, force=bool(rng.random() < 0.3))
+        else:
+            kw = dict(kmer_len=int(rng.integers(4, 8)), kmer_threshold=int(rng.integers(3, 20)), band_size=int(rng.integers(6, 100)))
+            if rng.random() < 0.1: kw = dict(sparse=False)
+            check_overlap(c, reads[:min(n, 14)], pj, kw)
+        ok += 1
+    except Exception as e:
+        bad += 1
+        print("FAIL seed", seed, "count" if seed % 2 == 0 else "overlap", "order", order, kw, "n", n, type(e).__name__, str(e)[:300]); sys.stdout.flush()
+    if seed % 5 == 0: print("seed", seed, "ok", ok, "bad", bad, "%.0fs" % (time.time() - t0)); sys.stdout.flush()
+print("done ok", ok, "bad", bad)
