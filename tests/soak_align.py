@@ -7,14 +7,18 @@ sys.path.insert(0, '.')
 import quaff_amd as Q
 from oracle import oracle as O
 from tests.helpers import rand_seq, mutate, rand_qual
-from tests.test_gpu_align import check_against_oracle, both_strands, oracle_model, NULL_JSON
+from tests.test_gpu_align import check_against_oracle, run_both, both_strands, oracle_model, NULL_JSON, DEFAULT_JSON, synth_params_json
 c = Q.Context(0); c.set_params_json(None); c.set_null_json(NULL_JSON)
 sc, null = oracle_model()
 t0 = time.time()
 n_ok = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(1000 + seed)
-    ref = rand_seq(rng, int(rng.integers(1500, 12000)))
+    order = int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
+    pj = DEFAULT_JSON if order == 0 else synth_params_json(rng, order + 1, order)
+    c.set_params_json(None if order == 0 else pj)
+    sc = O.Scores(O.Params.from_json(pj))
+    ref = rand_seq(rng, int(rng.integers(1500, 12000)) if rng.random() < 0.93 else int(rng.integers(200000, 280000)))
     if rng.random() < 0.3:   # repeats
         p = int(rng.integers(0, len(ref) - 400)); ref = ref[:p] + ref[p:p + 300] * 2 + ref[p + 300:]
     n = int(rng.integers(3, 90))
@@ -26,16 +30,22 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         seq = mutate(rng, src, sub=rng.uniform(0, .1), ins=rng.uniform(0, .06), dele=rng.uniform(0, .06))
         if len(seq) == 0: seq = "A"
         reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
-    kw = dict(kmer_len=int(rng.integers(4, 9)), kmer_threshold=int(rng.integers(2, 30)), band_size=int(rng.integers(4, 140)),
+    kw = dict(kmer_len=int(rng.integers(4, 9)) if rng.random() < 0.85 else int(rng.integers(9, 20)), kmer_threshold=int(rng.integers(2, 30)), band_size=int(rng.integers(4, 140)),
               local=bool(rng.random() < 0.8))
     if rng.random() < 0.15: kw = dict(kmer_threshold=-1, max_size=int(rng.integers(1, 300)) * 600 * 24)
-    if rng.random() < 0.08: kw = dict(sparse=False)
+    if rng.random() < 0.08 and len(ref) < 20000: kw = dict(sparse=False)   # (full DP of a 250 kb reference: minutes of oracle)
+    gpu_only = len(ref) >= 20000 and kw.get('kmer_len', 6) < 8 and kw.get('kmer_threshold', 0) >= 0
     quals = rng.random() < 0.85
     pall = rng.random() < 0.3
     try:
+        if gpu_only:   # short k-mers on a 250 kb reference: ~1e9 oracle cells (minutes); the GPU leg alone must still finish
+            t1 = time.time()
+            res, _ = run_both(c, both_strands(ref), reads, kw, sc, null, flags=1 if pall else 0, quals=quals)
+            print("seed", seed, "gpu only: %d records, %d cells in %.1fs" % (len(res["alignments"]), res["total_cells"], time.time() - t1)); sys.stdout.flush()
+            continue
         check_against_oracle(c, both_strands(ref), reads, kw, sc, null, quals=quals, print_all=pall)
         n_ok += 1
     except Exception as e:
         print("FAIL seed", seed, kw, "n", n, "quals", quals, "printall", pall, type(e).__name__, str(e)[:300]); sys.stdout.flush()
-    if seed % 5 == 0: print("seed", seed, "ok so far", n_ok, "elapsed %.0fs" % (time.time() - t0)); sys.stdout.flush()
+    print("seed", seed, "ok so far", n_ok, "elapsed %.0fs" % (time.time() - t0)); sys.stdout.flush()
 print("done", n_ok)
