@@ -179,7 +179,8 @@ struct qf_ctx : Slot {
   uint64_t tb_budget = 160ull << 30;   // per-chunk device storage budget (traceback / Forward matrices)
   bool ov_scores[2] = {false, false};
   int read_index_k = 0;
-  std::vector<double> h_ov_result, h_ov_score;
+  HostBuf<double> h_ov_result, h_ov_score;
+  std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
 };
 
@@ -1627,12 +1628,16 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     }
   }
   const uint32_t n_recs = (uint32_t)c->h_recs.size();
-  std::sort(c->h_recs.begin(), c->h_recs.end(), [](const AlignRec& p, const AlignRec& q) { return p.read < q.read; });
+  // records arrive in the device's completion order; a pair has at most one, so pair order is one scatter + one sweep
+  c->h_ov_slot.assign(n_pairs, ~0u);
+  for (uint32_t a = 0; a < n_recs; ++a) c->h_ov_slot[c->h_recs[a].read] = a;
   c->h_ov_align.resize(n_recs);
-  for (uint32_t a = 0; a < n_recs; ++a) {
-    const AlignRec& r = c->h_recs[a];
+  uint32_t n_out = 0;
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    if (c->h_ov_slot[p] == ~0u) continue;
+    const AlignRec& r = c->h_recs[c->h_ov_slot[p]];
     if (!r.ok) return fail(c, QF_ERR_DEVICE, "overlap traceback did not reach the start state (pair " + std::to_string(r.read) + ")");
-    qf_overlap_alignment& o = c->h_ov_align[a];
+    qf_overlap_alignment& o = c->h_ov_align[n_out++];
     o.pair = r.read;
     o.viterbi = r.viterbi;
     o.score = r.score;
@@ -1641,6 +1646,7 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     o.n_runs = r.n_runs;
     o.run_offset = r.run_off;
   }
+  if (n_out != n_recs) return fail(c, QF_ERR_DEVICE, "overlap records do not map one-to-one onto pairs");
   out->viterbi = c->h_ov_result.data();
   out->score = c->h_ov_score.data();
   out->cells = c->h_cells.data();

@@ -140,26 +140,25 @@ __global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
   double colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
   uint32_t colI = 0, rowJ = 0;
   // x-side context words of the rows this lane's slots are on; slides by one row per step
-  uint32_t xw[B + 1];  // xw[b] = word of row i-1 (1-based row i-1 -> index i-2) ... see below
+  // xw[b] = context word of row d0 + b + j - 1 (slot b is on row i = d0 + b + j: xw[b] is row i-1, xw[b+1] row i).  The
+  // rows slide down by one per step, so a step shifts the window and loads one new word (fetched a step ahead).
+  auto xword = [&](int row) -> uint32_t { return (row >= 1 && row <= xLen) ? xc[row - 1] : 0u; };
+  auto yword = [&](int j) -> uint32_t { return yc[min(max(j - 1, -kCtxPad + 1), yLen + 4)]; };
+  uint32_t xw[B + 1];
 #pragma unroll
-  for (int b = 0; b <= B; ++b) xw[b] = 0;
+  for (int b = 0; b <= B; ++b) xw[b] = xword(d0 + b - l);
   uint32_t gkyPrev = 0;
+  uint32_t wyNext = yword(1 - l);
 
   for (int t = 0; t < T; ++t) {
     const int j = t - l + 1;
     const bool colvalid = active && j >= 1 && j <= yLen;
-    const uint32_t wy = yc[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+    const uint32_t wy = wyNext;
+    wyNext = yword(j + 1);
+    const uint32_t xwNext = xword(d0 + B + j);
     const uint32_t erowY = wy & 0x7FFFu, gky = wy >> 24;
     const uint32_t gkyP = j > 1 ? gkyPrev : 0u;   // yIndelKmer[j-1], padded with a leading 0
     gkyPrev = gky;
-    // rows of this step: slot b is row i = d0 + b + j; xw[b] must hold the context word of row i-1 (for the padded
-    // indel k-mer of the diagonal / upper neighbour) and xw[b+1] that of row i.  Refill by direct loads: the words of
-    // rows d0+j-1 .. d0+j+B-1.
-#pragma unroll
-    for (int b = 0; b <= B; ++b) {
-      const int row = d0 + b + j - 1;  // 1-based row whose word goes to xw[b]
-      xw[b] = (row >= 1 && row <= xLen) ? xc[row - 1] : 0u;
-    }
     double lowM = __shfl_up(pubM, 1, G), lowI = __shfl_up(pubI, 1, G), lowD = __shfl_up(pubD, 1, G);
     if (l == 0) { lowM = QF_NEG_INF; lowI = QF_NEG_INF; lowD = QF_NEG_INF; }
     double upM = 0, upI = 0, upD = 0;
@@ -213,6 +212,9 @@ __global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
       }
     }
     pubM = prevM; pubI = prevI; pubD = prevD;
+#pragma unroll
+    for (int b = 0; b < B; ++b) xw[b] = xw[b + 1];
+    xw[B] = xwNext;
     if (colvalid) {
       tb[((uint64_t)t * G + l) * 2] = tbw0;
       tb[((uint64_t)t * G + l) * 2 + 1] = tbw1;
