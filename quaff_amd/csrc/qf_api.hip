@@ -627,7 +627,7 @@ static int reserve_seed_workspace(Slot* c, SeedArgs& sa, bool mem, uint64_t n_pa
   sa.ws = nullptr;
   sa.ws_slots = 0;
   sa.ws_words = 0;
-  const size_t per = (seed_lds_bytes(sa.max_nd, mem) + 15) & ~(size_t)15;
+  const size_t per = (seed_lds_bytes(sa.max_nd, mem, seed_needs_deep_counters(sa)) + 15) & ~(size_t)15;
   if (!seed_needs_workspace(sa, mem)) return QF_OK;
   const uint64_t slots = std::max<uint64_t>(1, std::min<uint64_t>({n_pairs, 1024, (4ull << 30) / per}));
   HIPCHK(c, c->d_seed_ws.reserve(per * slots));
@@ -1404,6 +1404,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         s.ref_pos = c->d_rpos.as<uint32_t>();
         s.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
         s.storage_mode = 2;
+        s.max_ref_len = s.max_read_len;   // the x side is a read too
       }, max_units, sa, bc))
     return rc;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));

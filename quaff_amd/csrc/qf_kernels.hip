@@ -421,7 +421,9 @@ __device__ __forceinline__ void record_band(const SeedArgs& a, uint32_t pair, in
 
 // One 256-thread workgroup per (read, ref) pair.  LDS: a dense histogram of k-mer matches per diagonal
 // (two 16-bit counters per dword) and a per-diagonal membership array.
-template <bool MEM>
+// W32: one 32-bit counter per diagonal instead of two 16-bit halves per word (a diagonal can collect 65 536+ matches only
+// when both sequences are that long; the reference counts in int, diagenv.cpp:33-40)
+template <bool MEM, bool W32 = false>
 __device__ void seed_pair(const SeedArgs& a, uint32_t pair, uint32_t* lds, uint32_t* s_red) {
   const uint32_t tid = threadIdx.x;
   if (a.pair_skip && a.pair_skip[pair]) return;
@@ -447,14 +449,14 @@ __device__ void seed_pair(const SeedArgs& a, uint32_t pair, uint32_t* lds, uint3
     return;
   }
 
-  const int histWords = (a.max_nd + 1) / 2;
+  const int histWords = W32 ? a.max_nd : (a.max_nd + 1) / 2;
   uint32_t* hist = lds;
   // threshold mode: cover = u8[nd]; memory mode: cover = u16[nd] level stamps, st = u16[nd+2] storage stamps
   uint8_t* cover8 = (uint8_t*)(lds + histWords);
   uint16_t* cover16 = (uint16_t*)(lds + histWords);
   uint16_t* st16 = cover16 + ((a.max_nd + 3) & ~1);
 
-  for (int w = tid; w < (nd + 1) / 2; w += 256) hist[w] = 0;
+  for (int w = tid; w < (W32 ? nd : (nd + 1) / 2); w += 256) hist[w] = 0;
   if (MEM) {
     for (int b = tid; b < nd; b += 256) cover16[b] = 0;
     for (int b = tid; b < nd + 2; b += 256) st16[b] = 0;
@@ -473,12 +475,13 @@ __device__ void seed_pair(const SeedArgs& a, uint32_t pair, uint32_t* lds, uint3
       bucket_range(a, x, xb, xLen, km, s, e);
       for (uint32_t p = s; p < e; ++p) {
         const int bin = (int)pos[p] - j + yLen - 1;
-        atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
+        if (W32) atomicAdd(&hist[bin], 1u);
+        else atomicAdd(&hist[bin >> 1], 1u << (16 * (bin & 1)));
       }
     }
   }
   __syncthreads();
-  auto count = [&](int bin) -> uint32_t { return (hist[bin >> 1] >> (16 * (bin & 1))) & 0xFFFFu; };
+  auto count = [&](int bin) -> uint32_t { return W32 ? hist[bin] : (hist[bin >> 1] >> (16 * (bin & 1))) & 0xFFFFu; };
   const int half = a.band / 2;
 
   uint32_t accepted = 1;  // highest accepted level stamp (memory mode)
@@ -571,12 +574,12 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a) {
 }
 // The same per-pair procedure with the histogram and membership arrays in a global-memory workspace (one per resident
 // workgroup, reused pair after pair): references too long for the LDS histogram (genome scale).
-template <bool MEM>
+template <bool MEM, bool W32>
 __global__ __launch_bounds__(256) void k_seed_global(SeedArgs a, uint32_t n_pairs) {
   __shared__ uint32_t s_red[256];
   uint32_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_words;
   for (uint32_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
-    seed_pair<MEM>(a, a.pair_base + p, ws, s_red);
+    seed_pair<MEM, W32>(a, a.pair_base + p, ws, s_red);
     __threadfence();
     __syncthreads();
   }
@@ -2022,21 +2025,34 @@ void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
 void launch_null_ll(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (n_reads) hipLaunchKernelGGL(k_null_ll, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, n_reads);
 }
-size_t seed_lds_bytes(int max_nd, bool mem) {
-  const size_t hist = (size_t)((max_nd + 1) / 2) * 4;
+// A diagonal holds at most min(xLen, yLen) - k + 1 matches: 16-bit counters are exact below 65 536 of them.
+bool seed_needs_deep_counters(const SeedArgs& a) {
+  const uint32_t m = a.max_ref_len < a.max_read_len ? a.max_ref_len : a.max_read_len;
+  return a.sparse && (a.max_ref_len == 0 ? a.max_read_len : m) >= 65535u + (uint32_t)a.kmer_len;
+}
+size_t seed_lds_bytes(int max_nd, bool mem, bool deep) {
+  const size_t hist = deep ? (size_t)max_nd * 4 : (size_t)((max_nd + 1) / 2) * 4;
   return mem ? hist + (size_t)((max_nd + 3) & ~1) * 2 + (size_t)(max_nd + 4) * 2 : hist + (size_t)max_nd + 4;
 }
 bool seed_needs_workspace(const SeedArgs& a, bool mem) {
   if (!a.sparse) return false;
+  if (seed_needs_deep_counters(a)) return true;
   if (!mem && a.threshold >= 0 && !a.force_block_kernel) {
     const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
     const uint32_t words = (a.max_read_len >= 2040 ? nc + 2 : (nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
     if ((size_t)words * 4 * 4 <= 150 * 1024) return false;
   }
-  return seed_lds_bytes(a.max_nd, mem) > 150 * 1024;
+  return seed_lds_bytes(a.max_nd, mem, false) > 150 * 1024;
 }
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
+  if (seed_needs_deep_counters(a)) {  // 65 536+ matches on one diagonal are possible: 32-bit counters, global workspaces
+    if (!a.ws || !a.ws_slots || a.ws_words * 4 < seed_lds_bytes(a.max_nd, mem, true)) return -1;
+    const uint32_t grid = n_pairs < a.ws_slots ? n_pairs : a.ws_slots;
+    if (mem) hipLaunchKernelGGL((k_seed_global<true, true>), dim3(grid), dim3(256), 0, s, a, n_pairs);
+    else hipLaunchKernelGGL((k_seed_global<false, true>), dim3(grid), dim3(256), 0, s, a, n_pairs);
+    return 0;
+  }
   if (!mem && a.sparse && a.threshold >= 0 && !a.force_block_kernel) {
     // one wavefront per pair, four pairs per workgroup; LDS per wave: coarse counters + bitmap + fine counters
     const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
@@ -2071,12 +2087,12 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
       return 0;
     }
   }
-  const size_t lds = seed_lds_bytes(a.max_nd, mem);
+  const size_t lds = seed_lds_bytes(a.max_nd, mem, false);
   if (lds > 150 * 1024) {  // too long for LDS: global-memory workspaces
     if (!a.ws || !a.ws_slots || a.ws_words * 4 < lds) return -1;
     const uint32_t grid = n_pairs < a.ws_slots ? n_pairs : a.ws_slots;
-    if (mem) hipLaunchKernelGGL(k_seed_global<true>, dim3(grid), dim3(256), 0, s, a, n_pairs);
-    else hipLaunchKernelGGL(k_seed_global<false>, dim3(grid), dim3(256), 0, s, a, n_pairs);
+    if (mem) hipLaunchKernelGGL((k_seed_global<true, false>), dim3(grid), dim3(256), 0, s, a, n_pairs);
+    else hipLaunchKernelGGL((k_seed_global<false, false>), dim3(grid), dim3(256), 0, s, a, n_pairs);
     return 0;
   }
   if (mem) {

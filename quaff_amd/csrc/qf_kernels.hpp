@@ -209,7 +209,8 @@ void launch_sum_count_replicas(double* counts, uint32_t n, uint64_t stride, hipS
 // (a wavefront runs for its longest band) and the longest start first.  Returns 0 or a hipError_t.
 int sort_class_list(uint32_t* keys, uint32_t* list, uint32_t n, uint32_t* keys_tmp, uint32_t* list_tmp, void** temp,
                     size_t* temp_cap, hipStream_t s);
-size_t seed_lds_bytes(int max_nd, bool mem);
+size_t seed_lds_bytes(int max_nd, bool mem, bool deep);
+bool seed_needs_deep_counters(const SeedArgs& a);
 bool seed_needs_workspace(const SeedArgs& a, bool mem);
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
 void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s);

@@ -398,6 +398,19 @@ def test_long_reads_wide_seed_counters(ctx):
     assert res["n_diagonals"].max() > 3000
 
 
+def test_diagonal_with_65536_matches_deep_counters(ctx):
+    """An exact 65 550-base copy of the reference puts 65 541 10-mer matches on one diagonal: a 16-bit counter would wrap to
+    5 (below the threshold, and the lowest level in memory mode); sequences this long get 32-bit counters."""
+    rng = np.random.default_rng(35)
+    ref = rand_seq(rng, 66000)
+    sc, null = oracle_model()
+    rd = O.FastSeq("copy", ref[200:200 + 65550], rand_qual(rng, 65550))
+    res = check_against_oracle(ctx, both_strands(ref), [rd], dict(kmer_len=10, kmer_threshold=20, band_size=8), sc, null)
+    assert res["n_diagonals"][0, 0] == 10 and res["alignments"][0]["cigar"] == "M65550"
+    res = check_against_oracle(ctx, [O.FastSeq("ref", ref)], [rd], dict(kmer_len=10, kmer_threshold=-1, band_size=8, max_size=40 * 65550 * 24), sc, null)
+    assert res["alignments"][0]["cigar"] == "M65550"
+
+
 def test_many_bands_grow_unit_tables(ctx):
     """Low threshold + short k-mers + narrow bands: dozens of bands per pair, far more than the four per pair the unit table
     and the overflow list are provisioned for; the seeding is repeated with grown tables (found by a randomized soak)."""
