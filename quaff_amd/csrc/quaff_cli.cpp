@@ -3,7 +3,8 @@
 // 2485-2529), its input formats (FASTA/FASTQ, optionally gzipped; params / null / counts JSON) and its output
 // formats (Stockholm, gapped FASTA, SAM, refseq; params / counts JSON), so that it is a drop-in for the hot path.
 // All DP runs on the GPU through the C ABI (include/quaff_hip.h); this file is host plumbing only.  Not provided:
-// remote/ssh/EC2/qsub execution, logging levels (-v* are accepted and ignored), -threads (accepted, ignored).
+// remote/ssh/EC2/qsub execution, logging levels (-v* are accepted and ignored); -threads only divides -kmatchmax's memory.
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -17,6 +18,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/quaff_hip.h"
@@ -251,6 +253,8 @@ struct Opts {
   deque<string> implicit;
   qf_dp_config cfg{1, 1, 6, 14, 64, 0, 0};
   bool autoMem = false;
+  uint64_t memTotal = 0;
+  unsigned threads = 1;
   vector<string> refFiles, readFiles;
   bool fwdstrand = false, noquals = false;
   string paramsFile, nullFile, saveNull;
@@ -268,15 +272,33 @@ struct Opts {
     if (arg == "-kmatchn") { cfg.kmer_threshold = atoi(val().c_str()); return true; }
     if (arg == "-kmatchmb") {
       cfg.max_size = (uint64_t)atoi(val().c_str()) << 20;
-      Require(cfg.max_size > 0, "-kmatchmb needs a size (the GPU build does not size by system RAM)");
+      if (cfg.max_size == 0) cfg.max_size = hostMemory();   // "-kmatchmb 0": all of system RAM, src/qmodel.cpp:790-793
       cfg.kmer_threshold = -1;
+      autoMem = false;
       return true;
     }
-    if (arg == "-kmatchmax") Fail("-kmatchmax (size by system RAM) is not supported by the GPU build; use -kmatchmb <M>");
+    if (arg == "-kmatchmax") {   // system RAM shared by the worker threads, src/qmodel.cpp:801-807,1058-1060
+      memTotal = hostMemory();
+      cfg.kmer_threshold = -1;
+      autoMem = true;
+      av.pop_front();
+      return true;
+    }
     if (arg == "-kmatchoff") { cfg.sparse = 0; av.pop_front(); return true; }
-    if (arg == "-threads") { val(); return true; }           // accepted, ignored: the GPU batches instead
-    if (arg == "-maxthreads") { av.pop_front(); return true; }
+    // the GPU batches instead of threading; the count only divides -kmatchmax's memory, as in the reference
+    if (arg == "-threads") { threads = (unsigned)atoi(val().c_str()); return true; }
+    if (arg == "-maxthreads") { threads = std::max(1u, std::thread::hardware_concurrency()); av.pop_front(); return true; }
     return false;
+  }
+  static uint64_t hostMemory() {   // getMemorySize(), src/memsize.cpp (the sysconf branch)
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+    Require(pages > 0 && psz > 0, "Can't figure out available system memory; you will need to specify a size");
+    return (uint64_t)pages * (uint64_t)psz;
+  }
+  void finishConfig() {   // QuaffDPConfig::effectiveMaxSize, src/qmodel.cpp:1058-1060
+    if (!autoMem) return;
+    Require(threads > 0, "Please allocate at least one thread");
+    cfg.max_size = memTotal / threads;
   }
   bool parseLog() {  // Logger::parseLogArgs, src/logger.cpp:48-83: accepted and ignored
     if (av.empty()) return false;
@@ -438,6 +460,7 @@ static int cmdAlign(Opts& o) {
          pr.parse(o.av) || o.parseConfig(true) || o.parseFiles(true) ||
          [&] { if (!o.av.empty() && o.av[0] == "-noquals") { o.noquals = true; o.av.pop_front(); return true; } return false; }() ||
          o.parseUnknown()) {}
+  o.finishConfig();
   SeqSet reads, refs;
   reads.load(o.readFiles, "read", "-read", !o.noquals, false, true);
   refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, true);
@@ -544,6 +567,7 @@ static int cmdTrainOrCount(Opts& o, bool training) {
   };
   while (o.parseLog() || parseTrainArgs(o, training, maxIter, minInc, maxReadBases, allowNull, rawCounts, countsWithPriorFile, saveParams) ||
          o.parseConfig(true) || o.parseFiles(true) || parsePrior() || o.parseUnknown()) {}
+  o.finishConfig();
   SeqSet reads, refs;
   reads.load(o.readFiles, "read", "-read", true, false, false);
   refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, false);
@@ -656,6 +680,7 @@ static int cmdOverlap(Opts& o) {
   while (o.parseLog() || pr.parse(o.av) || o.parseConfig(false) || o.parseFiles(false) ||
          [&] { if (!o.av.empty() && o.av[0] == "-noquals") { o.noquals = true; o.av.pop_front(); return true; } return false; }() ||
          o.parseUnknown()) {}
+  o.finishConfig();
   SeqSet reads;
   reads.load(o.readFiles, "read", "-read", !o.noquals, !o.fwdstrand, true);
   Session s;

@@ -27,6 +27,21 @@ def test_align_self_golden():
     assert run("align", C8, C8, "-kmatchmb", "10", "-fwdstrand") == open(os.path.join(GOLDEN, "c8f30-self-align.json")).read()
 
 
+def test_kmatchmax_divides_system_memory_by_threads(tmp_path):
+    """-kmatchmax = system RAM / -threads per matrix (src/qmodel.cpp:801-807,1058-1060): with an absurd thread count the
+    budget admits no band (the -kmatchmb 10 golden: diagonal 0 only); with one thread it equals `-kmatchmb 0` (all RAM)."""
+    assert run("align", C8, C8, "-kmatchmax", "-threads", "100000000", "-fwdstrand") == open(os.path.join(GOLDEN, "c8f30-self-align.json")).read()
+    rng = np.random.default_rng(52)
+    ref = rand_seq(rng, 1500)
+    fa, fq = tmp_path / "ref.fasta", tmp_path / "reads.fastq"
+    fa.write_text(">ref\n%s\n" % ref)
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in make_reads(rng, ref, 6, 300)))
+    whole = run("align", str(fa), str(fq), "-kmatchmb", "0")
+    assert run("align", str(fa), str(fq), "-kmatchmax") == whole
+    assert run("align", str(fa), str(fq), "-kmatchmax", "-threads", "1") == whole
+    assert whole.count("#=GF Score") == 6
+
+
 def test_count_self_golden():
     got = run("count", C8, C8, "-kmatchmb", "10", "-fwdstrand")
     want = open(os.path.join(GOLDEN, "c8f30-self-counts.json")).read()
