@@ -116,6 +116,9 @@ typedef struct qf_align_result {
 } qf_align_result;
 
 /* ---- context ---------------------------------------------------------------------- */
+/* Number of HIP devices visible to this process (0 if none or on error).  The reference spreads tasks over `-threads`
+ * host threads (src/qmodel.cpp:2870-2882); a caller of this library spreads read batches over one context per device. */
+int qf_device_count(void);
 int qf_ctx_create(int device_id, qf_ctx **ctx);
 void qf_ctx_destroy(qf_ctx *ctx);
 const char *qf_last_error(const qf_ctx *ctx);   /* ctx may be NULL: last creation error */

@@ -83,7 +83,8 @@ class _OverlapResult(C.Structure):
 EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
-           "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks"]
+           "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks",
+           "qf_device_count"]
 
 
 def load_library():
@@ -97,6 +98,8 @@ def load_library():
         L.qf_last_error.restype = C.c_char_p
         L.qf_last_error.argtypes = [C.c_void_p]
         L.qf_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.qf_device_count.argtypes = []
+        L.qf_device_count.restype = C.c_int
         L.qf_ctx_destroy.argtypes = [C.c_void_p]
         L.qf_ctx_destroy.restype = None
         L.qf_set_params_json.argtypes = [C.c_void_p, C.c_char_p]

@@ -202,6 +202,11 @@ static int fail(Slot* c, int code, const std::string& msg) {
 
 extern "C" {
 
+int qf_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 int qf_ctx_create(int device_id, qf_ctx** out) {
   if (!out) return QF_ERR_ARG;
   *out = nullptr;

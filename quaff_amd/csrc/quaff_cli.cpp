@@ -17,6 +17,7 @@
 #include <iostream>
 #include <set>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -255,6 +256,7 @@ struct Opts {
   bool autoMem = false;
   uint64_t memTotal = 0;
   unsigned threads = 1;
+  int gpus = 1;   // -gpus <n|all>: devices the read batches are spread over (this build's counterpart of -threads)
   vector<string> refFiles, readFiles;
   bool fwdstrand = false, noquals = false;
   string paramsFile, nullFile, saveNull;
@@ -285,6 +287,7 @@ struct Opts {
       return true;
     }
     if (arg == "-kmatchoff") { cfg.sparse = 0; av.pop_front(); return true; }
+    if (arg == "-gpus") { const string v = val(); gpus = v == "all" ? -1 : atoi(v.c_str()); Require(gpus == -1 || gpus >= 1, "-gpus needs a positive count or 'all'"); return true; }
     // the GPU batches instead of threading; the count only divides -kmatchmax's memory, as in the reference
     if (arg == "-threads") { threads = (unsigned)atoi(val().c_str()); return true; }
     if (arg == "-maxthreads") { threads = std::max(1u, std::thread::hardware_concurrency()); av.pop_front(); return true; }
@@ -366,6 +369,21 @@ struct SeqSet {  // SeqList::loadSequences, t/quaff.cpp:610-636
 };
 
 #define QF(ctx, call) do { if ((call) != QF_OK) Fail(string("libquaffhip: ") + qf_last_error(ctx)); } while (0)
+// inside a per-device worker thread: reported by the main thread once every worker has finished
+#define QFT(ctx, call) do { if ((call) != QF_OK) throw std::runtime_error(string("libquaffhip: ") + qf_last_error(ctx)); } while (0)
+
+// fn(k) for k < n, one host thread per device context (the reference runs one task loop per -threads thread,
+// src/qmodel.cpp:2870-2882; here a "thread" owns a GPU and takes whole batches)
+template <class F>
+static void onDevices(size_t n, F&& fn) {
+  vector<string> err(n);
+  vector<std::thread> th;
+  auto guarded = [&](size_t k) { try { fn(k); } catch (const std::exception& e) { err[k] = e.what(); } };
+  for (size_t k = 1; k < n; ++k) th.emplace_back(guarded, k);
+  guarded(0);
+  for (auto& t : th) t.join();
+  for (const auto& e : err) if (e.size()) Fail(e);
+}
 
 static void packSeqs(const vector<FastSeq>& v, size_t lo, size_t hi, string& seq, string& qual, vector<uint64_t>& off, bool& allQual) {
   seq.clear(); qual.clear(); off.assign(1, 0);
@@ -379,24 +397,45 @@ static void packSeqs(const vector<FastSeq>& v, size_t lo, size_t hi, string& seq
 }
 
 struct Session {
-  qf_ctx* ctx = nullptr;
+  qf_ctx* ctx = nullptr;       // ctxs[0]
+  vector<qf_ctx*> ctxs;        // one per device; models and references are replicated, read batches are spread
   Params params;
   NullParams null;
-  Session() { if (qf_ctx_create(0, &ctx) != QF_OK) Fail(string("libquaffhip: ") + qf_last_error(nullptr)); }
-  ~Session() { qf_ctx_destroy(ctx); }
+  explicit Session(const Opts& o) {
+    vector<int> dev;
+    if (const char* e = getenv("QUAFF_HIP_DEVICES")) {   // explicit ids, e.g. "0,2,3" (an id may repeat: two contexts on one GPU)
+      std::istringstream in(e);
+      for (string f; std::getline(in, f, ',');) if (f.size()) dev.push_back(atoi(f.c_str()));
+    } else {
+      const int have = qf_device_count();
+      const int n = o.gpus < 0 ? have : o.gpus;
+      Require(n >= 1 && n <= std::max(have, 1), "-gpus " + to_string(n) + ": only " + to_string(have) + " HIP device(s) visible");
+      for (int d = 0; d < n; ++d) dev.push_back(d);
+    }
+    Require(!dev.empty(), "no device selected");
+    for (int d : dev) {
+      qf_ctx* c = nullptr;
+      if (qf_ctx_create(d, &c) != QF_OK) Fail(string("libquaffhip: ") + qf_last_error(nullptr));
+      ctxs.push_back(c);
+    }
+    ctx = ctxs[0];
+  }
+  ~Session() { for (qf_ctx* c : ctxs) qf_ctx_destroy(c); }
+  size_t devices() const { return ctxs.size(); }
   void loadParams(const Opts& o) {  // requireParamsOrUseDefaults, t/quaff.cpp:362-368
     const string text = o.paramsFile.size() ? slurp(o.paramsFile) : string(kDefaultParamsJson);
     Json j;
     string err;
     if (!parse_json(text, j, err) || !params.read_json(j, err)) Fail("Couldn't read parameters: " + err);
-    QF(ctx, qf_set_params_json(ctx, text.c_str()));
+    for (qf_ctx* c : ctxs) QF(c, qf_set_params_json(c, text.c_str()));
   }
   void setParams(const Params& p) {
     params = p;
     vector<double> ipqr(12), mpqr((size_t)4 * p.Km() * 3);
     for (int i = 0; i < 4; ++i) { ipqr[i * 3] = p.insert[i].p; ipqr[i * 3 + 1] = p.insert[i].q; ipqr[i * 3 + 2] = p.insert[i].r; }
     for (size_t m = 0; m < p.match.size(); ++m) { mpqr[m * 3] = p.match[m].p; mpqr[m * 3 + 1] = p.match[m].q; mpqr[m * 3 + 2] = p.match[m].r; }
-    QF(ctx, qf_set_params_raw(ctx, p.match_len, p.gap_len, p.refBase, p.beginInsert.data(), p.beginDelete.data(), p.extendInsert,
+    for (qf_ctx* c : ctxs)
+      QF(c, qf_set_params_raw(c, p.match_len, p.gap_len, p.refBase, p.beginInsert.data(), p.beginDelete.data(), p.extendInsert,
                               p.extendDelete, ipqr.data(), mpqr.data()));
   }
   void loadNull(const Opts& o, const vector<FastSeq>& reads) {  // requireNullModelOrFit, t/quaff.cpp:419-429
@@ -405,14 +444,14 @@ struct Session {
       Json j;
       string err;
       if (!parse_json(text, j, err) || !null.read_json(j, err)) Fail("Couldn't read null model parameters: " + err);
-      QF(ctx, qf_set_null_json(ctx, text.c_str()));
+      for (qf_ctx* c : ctxs) QF(c, qf_set_null_json(c, text.c_str()));
     } else {
       vector<string> s, q;
       for (const auto& r : reads) { s.push_back(r.seq); q.push_back(r.qual); }
       null = fit_null(s, q);
       double pqr[12];
       for (int i = 0; i < 4; ++i) { pqr[i * 3] = null.null[i].p; pqr[i * 3 + 1] = null.null[i].q; pqr[i * 3 + 2] = null.null[i].r; }
-      QF(ctx, qf_set_null_raw(ctx, null.nullEmit, pqr));
+      for (qf_ctx* c : ctxs) QF(c, qf_set_null_raw(c, null.nullEmit, pqr));
     }
     if (o.saveNull.size()) { ofstream out(o.saveNull); out << null.write_json(); }
   }
@@ -420,7 +459,7 @@ struct Session {
     string s;
     vector<uint64_t> off(1, 0);
     for (const auto& fs : x) { s += fs.seq; off.push_back(s.size()); }
-    QF(ctx, qf_set_refs(ctx, s.data(), off.data(), (uint32_t)x.size()));
+    for (qf_ctx* c : ctxs) QF(c, qf_set_refs(c, s.data(), off.data(), (uint32_t)x.size()));
   }
 };
 
@@ -464,25 +503,33 @@ static int cmdAlign(Opts& o) {
   SeqSet reads, refs;
   reads.load(o.readFiles, "read", "-read", !o.noquals, false, true);
   refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, true);
-  Session s;
+  Session s(o);
   s.loadParams(o);
   s.loadNull(o, reads.seqs);
   s.setRefs(refs.seqs);
   pr.header(cout, refs.seqs, false);
-  const size_t batch = 65536;
-  for (size_t lo = 0; lo < reads.seqs.size(); lo += batch) {
-    const size_t hi = min(reads.seqs.size(), lo + batch);
-    string seq, qual;
-    vector<uint64_t> off;
-    bool allQual;
-    packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
-    qf_align_result res;
-    QF(s.ctx, qf_align_batch(s.ctx, &o.cfg, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo),
-                             printAll ? QF_ALIGN_ALL : QF_ALIGN_BEST, &res));
-    for (uint32_t a = 0; a < res.n_alignments; ++a) {
-      const qf_alignment& al = res.alignments[a];
-      pr.write(cout, makeAlignment(refs.seqs[al.ref], reads.seqs[lo + al.read], al, res.cigar_runs + al.run_offset, o.cfg.local));
-    }
+  // contiguous blocks of reads, one per device at a time; printed in read order whatever the device count
+  const size_t G = s.devices(), n = reads.seqs.size();
+  const size_t batch = max<size_t>(1, min<size_t>(65536, (n + G - 1) / G));
+  for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
+    const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
+    vector<vector<Alignment>> got(nrun);
+    onDevices(nrun, [&](size_t k) {
+      const size_t lo = lo0 + k * batch, hi = min(n, lo + batch);
+      qf_ctx* c = s.ctxs[k];
+      string seq, qual;
+      vector<uint64_t> off;
+      bool allQual;
+      packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
+      qf_align_result res;
+      QFT(c, qf_align_batch(c, &o.cfg, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo),
+                            printAll ? QF_ALIGN_ALL : QF_ALIGN_BEST, &res));
+      for (uint32_t a = 0; a < res.n_alignments; ++a) {
+        const qf_alignment& al = res.alignments[a];
+        got[k].push_back(makeAlignment(refs.seqs[al.ref], reads.seqs[lo + al.read], al, res.cigar_runs + al.run_offset, o.cfg.local));
+      }
+    });
+    for (const auto& block : got) for (const Alignment& a : block) pr.write(cout, a);
   }
   return EXIT_SUCCESS;
 }
@@ -491,33 +538,47 @@ static int cmdAlign(Opts& o) {
 static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_refs, bool useNull, vector<vector<uint32_t>>& sortOrder, double& logLike) {
   ParamCounts total(s.params.match_len, s.params.gap_len);
   logLike = 0;
-  const size_t batch = 16384;
-  for (size_t lo = 0; lo < reads.seqs.size(); lo += batch) {
-    const size_t hi = min(reads.seqs.size(), lo + batch);
-    string seq, qual;
-    vector<uint64_t> off;
-    bool allQual;
-    packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
-    QF(s.ctx, qf_upload_reads(s.ctx, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo)));
-    vector<uint32_t> sin, snin;
-    if (!sortOrder.empty()) {
-      for (size_t r = lo; r < hi; ++r) {
-        vector<uint32_t> row = sortOrder[r];
-        snin.push_back((uint32_t)row.size());
-        row.resize(n_refs, 0);
-        sin.insert(sin.end(), row.begin(), row.end());
+  // read blocks spread over the devices; block sums are added in read order (QuaffParamCounts::operator+ over tasks,
+  // src/qmodel.cpp:2416-2422), so the result does not depend on the device count
+  const size_t G = s.devices(), n = reads.seqs.size();
+  const size_t batch = max<size_t>(1, min<size_t>(16384, (n + G - 1) / G));
+  const bool haveOrder = !sortOrder.empty();
+  if (!haveOrder) sortOrder.assign(n, vector<uint32_t>());
+  for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
+    const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
+    vector<vector<double>> counts(nrun);
+    vector<double> ll(nrun, 0.);
+    onDevices(nrun, [&](size_t k) {
+      const size_t lo = lo0 + k * batch, hi = min(n, lo + batch);
+      qf_ctx* c = s.ctxs[k];
+      string seq, qual;
+      vector<uint64_t> off;
+      bool allQual;
+      packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
+      QFT(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo)));
+      vector<uint32_t> sin, snin;
+      if (haveOrder) {
+        for (size_t r = lo; r < hi; ++r) {
+          vector<uint32_t> row = sortOrder[r];
+          snin.push_back((uint32_t)row.size());
+          row.resize(n_refs, 0);
+          sin.insert(sin.end(), row.begin(), row.end());
+        }
       }
-    }
-    qf_count_result res;
-    QF(s.ctx, qf_count_resident(s.ctx, &o.cfg, useNull ? 0 : QF_COUNT_FORCE, sin.empty() ? nullptr : sin.data(),
-                                snin.empty() ? nullptr : snin.data(), &res));
-    for (uint32_t c = 0; c < res.counts_size; ++c) total.v[c] += res.counts[c];
-    logLike += res.loglike;
-    if (sortOrder.empty()) { sortOrder.assign(reads.seqs.size(), vector<uint32_t>()); }
-    for (size_t r = lo; r < hi; ++r) {
-      vector<uint32_t>& so = sortOrder[r];
-      so.clear();
-      for (uint32_t k = 0; k < res.sort_count[r - lo]; ++k) so.push_back(res.sort_order[(r - lo) * res.n_refs + k]);
+      qf_count_result res;
+      QFT(c, qf_count_resident(c, &o.cfg, useNull ? 0 : QF_COUNT_FORCE, sin.empty() ? nullptr : sin.data(),
+                               snin.empty() ? nullptr : snin.data(), &res));
+      counts[k].assign(res.counts, res.counts + res.counts_size);
+      ll[k] = res.loglike;
+      for (size_t r = lo; r < hi; ++r) {   // each block owns its reads' rows
+        vector<uint32_t>& so = sortOrder[r];
+        so.clear();
+        for (uint32_t q = 0; q < res.sort_count[r - lo]; ++q) so.push_back(res.sort_order[(r - lo) * res.n_refs + q]);
+      }
+    });
+    for (size_t k = 0; k < nrun; ++k) {
+      for (size_t q = 0; q < counts[k].size(); ++q) total.v[q] += counts[k][q];
+      logLike += ll[k];
     }
   }
   return total;
@@ -571,7 +632,7 @@ static int cmdTrainOrCount(Opts& o, bool training) {
   SeqSet reads, refs;
   reads.load(o.readFiles, "read", "-read", true, false, false);
   refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, false);
-  Session s;
+  Session s(o);
   s.loadNull(o, reads.seqs);
   if (!training) {
     s.loadParams(o);
@@ -683,7 +744,7 @@ static int cmdOverlap(Opts& o) {
   o.finishConfig();
   SeqSet reads;
   reads.load(o.readFiles, "read", "-read", !o.noquals, !o.fwdstrand, true);
-  Session s;
+  Session s(o);
   s.loadParams(o);
   s.loadNull(o, reads.seqs);
   pr.header(cout, reads.seqs, true);
@@ -691,25 +752,36 @@ static int cmdOverlap(Opts& o) {
   vector<uint64_t> off;
   bool allQual;
   packSeqs(reads.seqs, 0, reads.seqs.size(), seq, qual, off, allQual);
-  QF(s.ctx, qf_upload_reads(s.ctx, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
-  // pair order of QuaffOverlapScheduler, src/qoverlap.cpp:475-480,528-547
-  vector<uint32_t> px, py;
-  vector<uint8_t> pc;
-  const size_t N = reads.nOriginals, total = reads.seqs.size(), chunk = 1 << 18;
+  for (qf_ctx* c : s.ctxs) QF(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
+  // pair order of QuaffOverlapScheduler, src/qoverlap.cpp:475-480,528-547; every device holds all reads, consecutive
+  // blocks of the pair list go to the devices in turn and are printed in list order
+  struct Block { vector<uint32_t> px, py; vector<uint8_t> pc; };
+  const size_t N = reads.nOriginals, total = reads.seqs.size(), G = s.devices();
+  size_t chunk = 1 << 21;   // pairs per device call (each call re-derives the reads' context arrays)
+  if (const char* e = getenv("QUAFF_HIP_OVERLAP_CHUNK")) chunk = max<size_t>(1, (size_t)atol(e));   // tests: many small blocks
+  vector<Block> pend(1);
   auto flush = [&]() {
-    if (px.empty()) return;
-    qf_overlap_result res;
-    QF(s.ctx, qf_overlap_resident(s.ctx, &o.cfg, px.data(), py.data(), pc.data(), (uint32_t)px.size(), &res));
-    for (uint32_t a = 0; a < res.n_alignments; ++a) {
-      const qf_overlap_alignment& al = res.alignments[a];
-      pr.write(cout, makeOverlapAlignment(reads.seqs[px[al.pair]], reads.seqs[py[al.pair]], al, res.state_runs + al.run_offset));
-    }
-    px.clear(); py.clear(); pc.clear();
+    if (pend.back().px.empty()) pend.pop_back();
+    if (pend.empty()) { pend.emplace_back(); return; }
+    vector<vector<Alignment>> got(pend.size());
+    onDevices(pend.size(), [&](size_t k) {
+      const Block& b = pend[k];
+      qf_ctx* c = s.ctxs[k];
+      qf_overlap_result res;
+      QFT(c, qf_overlap_resident(c, &o.cfg, b.px.data(), b.py.data(), b.pc.data(), (uint32_t)b.px.size(), &res));
+      for (uint32_t a = 0; a < res.n_alignments; ++a) {
+        const qf_overlap_alignment& al = res.alignments[a];
+        got[k].push_back(makeOverlapAlignment(reads.seqs[b.px[al.pair]], reads.seqs[b.py[al.pair]], al, res.state_runs + al.run_offset));
+      }
+    });
+    for (const auto& block : got) for (const Alignment& a : block) pr.write(cout, a);
+    pend.assign(1, Block());
   };
   for (size_t nx = 0; nx + 1 < N; ++nx)
     for (size_t ny = nx + 1; ny < total; ++ny) {
-      px.push_back((uint32_t)nx); py.push_back((uint32_t)ny); pc.push_back(ny >= N);
-      if (px.size() >= chunk) flush();
+      Block& b = pend.back();
+      b.px.push_back((uint32_t)nx); b.py.push_back((uint32_t)ny); b.pc.push_back(ny >= N);
+      if (b.px.size() >= chunk) { if (pend.size() == G) flush(); else pend.emplace_back(); }
     }
   flush();
   return EXIT_SUCCESS;
@@ -734,8 +806,9 @@ int main(int argc, char** argv) {
             " quaff count refs.fasta reads.fastq                (one E-step; -savecounts)\n\n"
             "Alignment options: -threshold <n> -nothreshold -noquals -savealign <file> -format {fasta,stockholm,sam,refseq}\n"
             "General: -params <file> -ref <file> -read <file> -fwdstrand -global -null <file> -savenull <file>\n"
-            "         -kmatch <k> -kmatchn <n> -kmatchband <n> -kmatchmb <M> -kmatchoff\n"
-            "All dynamic programming runs on GPU 0 through libquaffhip (include/quaff_hip.h).\n";
+            "         -kmatch <k> -kmatchn <n> -kmatchband <n> -kmatchmb <M> -kmatchmax -kmatchoff\n"
+            "         -gpus <n|all>   spread the read batches over n GPUs (default 1; results do not depend on n)\n"
+            "All dynamic programming runs on the GPU(s) through libquaffhip (include/quaff_hip.h).\n";
     return EXIT_SUCCESS;
   }
   if (command == "version" || command == "-V" || command == "--version") { cout << "quaff (hip) 0.1" << endl; return EXIT_SUCCESS; }

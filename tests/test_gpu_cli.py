@@ -17,8 +17,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 C8 = os.path.join(GOLDEN, "c8f30.fastq.gz")
 
 
-def run(*args):
-    out = subprocess.run([QUAFF] + list(args), capture_output=True, text=True, timeout=300)
+def run(*args, devices=None, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    if devices:
+        env["QUAFF_HIP_DEVICES"] = devices
+    out = subprocess.run([QUAFF] + list(args), capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     return out.stdout
 
@@ -94,3 +97,39 @@ def test_train_runs_and_improves(tmp_path):
     assert len(lls) >= 2 and lls[1] > lls[0]
     p = O.Params.from_json(out.stdout)          # parses as a quaff params file
     assert 0 < p.extendInsert < 1 and abs(p.match[0, 0, 0] + p.match[0, 1, 0] + p.match[0, 2, 0] + p.match[0, 3, 0] - 1) < 1e-5
+
+
+def test_batches_spread_over_devices_give_the_same_output(tmp_path):
+    """`-gpus n` spreads read blocks (align, count/train) or pair-list blocks (overlap) over one context per device and
+    prints in input order.  QUAFF_HIP_DEVICES names the device of each context explicitly; "0,0,0" puts three contexts
+    (three host threads) on this box's one GPU, which exercises the same sharding and ordering code."""
+    import re
+    rng = np.random.default_rng(53)
+    ref = rand_seq(rng, 3000)
+    reads = make_reads(rng, ref, 41, 400)
+    (tmp_path / "ref.fa").write_text(">ref\n" + ref + "\n")
+    (tmp_path / "reads.fq").write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+    one = run("align", fa, fq, "-format", "sam")
+    assert one.count("\n") > 41
+    assert run("align", fa, fq, "-format", "sam", devices="0,0,0") == one
+    assert run("align", fa, fq, "-format", "sam", "-gpus", "1") == one
+    (tmp_path / "few.fq").write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in make_reads(rng, ref[:1200], 12, 800, sub=.01, ins=.005, dele=.005)))
+    few = str(tmp_path / "few.fq")
+    ov = run("overlap", few, "-nothreshold")   # (random qualities: the null-adjusted overlap scores are negative)
+    assert ov.count("#=GF Score") > 10 and run("overlap", few, "-nothreshold", devices="0,0") == ov
+    assert run("overlap", few, "-nothreshold", devices="0,0,0", env_extra={"QUAFF_HIP_OVERLAP_CHUNK": "17"}) == ov   # 13 blocks, 5 rounds
+    nums = lambda t: np.array(list(map(float, re.findall(r"-?\d+\.?\d*(?:e[-+]?\d+)?", t))))
+    c1, c3 = run("count", fa, fq), run("count", fa, fq, devices="0,0,0")
+    assert len(nums(c1)) == len(nums(c3)) > 1000
+    np.testing.assert_allclose(nums(c3), nums(c1), rtol=1e-4, atol=1e-6)
+    t1 = subprocess.run([QUAFF, "train", fa, fq, "-maxiter", "2"], capture_output=True, text=True, timeout=300)
+    t3 = subprocess.run([QUAFF, "train", fa, fq, "-maxiter", "2"], capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, QUAFF_HIP_DEVICES="0,0,0"))
+    assert t1.returncode == 0 and t3.returncode == 0, t3.stderr[-1000:]
+    np.testing.assert_allclose(nums(t3.stdout), nums(t1.stdout), rtol=1e-3, atol=1e-6)
+
+
+def test_gpus_flag_rejects_more_devices_than_visible():
+    out = subprocess.run([QUAFF, "align", C8, C8, "-gpus", "99"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "HIP device" in out.stderr
