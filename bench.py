@@ -40,6 +40,12 @@ def parse():
     ap.add_argument("--workload", default="align", choices=["align", "train", "overlap", "fulldp"],
                     help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = scaled "
                          "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
+    ap.add_argument("--overlap-rows", type=int, default=0,
+                    help="overlap workload: only the first R rows of the pair triangle (this rank's block of rows when the "
+                         "50 k-read config 3 is sharded); 0 = all pairs")
+    ap.add_argument("--overlap-threshold", type=float, default=0.0,
+                    help="overlap workload: alignments scoring below it are not traced back (`quaff overlap` prints only "
+                         "score >= 0 by default, -threshold; pass -inf for -nothreshold)")
     ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
     ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
     ap.add_argument("--debug-flags", type=int, default=0, help="developer: extra qf_dp_config.reserved bits (A/B switches)")
@@ -158,10 +164,17 @@ def extra_workload(a, rank, world, local_rank):
         seqs += [api.revcomp(s) for s in seqs]
         quals += [q[::-1] for q in quals]
         ctx.upload_reads(seqs, quals)
-        xs, ys = np.triu_indices(2 * n, 1)       # QuaffOverlapScheduler order: nx < ny, nx an original
-        keep = xs < n - 1
+        if a.overlap_rows:                       # rows [rank*R, rank*R + R) of the triangle: what one rank of the sharded config 3 owns
+            rows = np.arange(rank * a.overlap_rows, min(n - 1, (rank + 1) * a.overlap_rows))
+            xs = np.concatenate([np.full(2 * n - 1 - r, r) for r in rows])
+            ys = np.concatenate([np.arange(r + 1, 2 * n) for r in rows])
+            keep = np.ones(len(xs), bool)
+        else:
+            xs, ys = np.triu_indices(2 * n, 1)   # QuaffOverlapScheduler order: nx < ny, nx an original
+            keep = xs < n - 1
         pairs = (xs[keep].astype(np.uint32), ys[keep].astype(np.uint32), (ys[keep] >= n).astype(np.uint8))
         cfg = Q.DPConfig(kmer_threshold=14, band_size=a.band)
+        ctx.set_score_threshold(a.overlap_threshold)
         for _ in range(a.warmup):
             ctx.overlap_resident(pairs, cfg, raw=True)
         sync_all()
@@ -177,7 +190,7 @@ def extra_workload(a, rank, world, local_rank):
         dt = time.perf_counter() - t0
         desc = "config 3 shape: quaff overlap, %d x 2 kb reads from a %d bp genome, all-vs-all both strands (%d pairs) per GPU" % (n, len(genome), len(pairs[0]))
         metric = "DP cells/sec (overlap Viterbi)"
-        extra = {"pairs": len(pairs[0]), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
+        extra = {"pairs": len(pairs[0]), "score_threshold": a.overlap_threshold, "alignments": int(res.n_alignments), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
     else:
         ctx.set_params_json(None)
         ref_len = a.ref_len if a.ref_len != 10000 else 100000

@@ -123,6 +123,12 @@ int qf_ctx_create(int device_id, qf_ctx **ctx);
 void qf_ctx_destroy(qf_ctx *ctx);
 const char *qf_last_error(const qf_ctx *ctx);   /* ctx may be NULL: last creation error */
 int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
+/* Alignments whose null-adjusted score is below `min_score` are not traced back and not returned by qf_align_* /
+ * qf_overlap_resident (the per-pair score arrays are still complete).  This is the reference printer's `-threshold`
+ * (QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600; default there 0, `-nothreshold` = -inf) applied before the traceback
+ * instead of after it: most read pairs of an all-vs-all overlap run do not overlap and score below 0.  In best-per-read
+ * mode the read's best alignment is chosen first and then tested, as the reference does.  Default: -inf (keep all). */
+int qf_set_score_threshold(qf_ctx *ctx, double min_score);
 /* Device bytes one internal chunk may use for traceback / Forward storage (default 160 GiB; 0 restores it).  Larger
  * batches are processed in halves transparently.  (The reference bounds DP memory per thread through -kmatchmb /
  * -kmatchmax, src/qmodel.cpp:788-813,1058-1060, and runs reads one at a time; here whole batches are resident, so the

@@ -84,7 +84,7 @@ EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
            "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks",
-           "qf_device_count"]
+           "qf_device_count", "qf_set_score_threshold"]
 
 
 def load_library():
@@ -98,6 +98,7 @@ def load_library():
         L.qf_last_error.restype = C.c_char_p
         L.qf_last_error.argtypes = [C.c_void_p]
         L.qf_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.qf_set_score_threshold.argtypes = [C.c_void_p, C.c_double]
         L.qf_device_count.argtypes = []
         L.qf_device_count.restype = C.c_int
         L.qf_ctx_destroy.argtypes = [C.c_void_p]
@@ -214,6 +215,10 @@ class Context:
     def set_memory_budget(self, nbytes):
         self.L.qf_set_memory_budget.argtypes = [C.c_void_p, C.c_uint64]
         self._chk(self.L.qf_set_memory_budget(self.h, nbytes))
+
+    def set_score_threshold(self, min_score):
+        """Alignments scoring below min_score are not traced back / returned (-inf = all; the CLI's -threshold)."""
+        self._chk(self.L.qf_set_score_threshold(self.h, float(min_score)))
 
     def set_pipeline_chunks(self, n):
         self.L.qf_set_pipeline_chunks.argtypes = [C.c_void_p, C.c_uint32]

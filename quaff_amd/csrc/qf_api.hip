@@ -176,6 +176,7 @@ struct qf_ctx : Slot {
   std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
+  double min_score = -INFINITY;   // qf_set_score_threshold
   uint64_t tb_budget = 160ull << 30;   // per-chunk device storage budget (traceback / Forward matrices)
   bool ov_scores[2] = {false, false};
   int read_index_k = 0;
@@ -795,6 +796,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   fin.n_reads = n_reads;
   fin.n_refs = n_refs;
   fin.all = (flags & QF_ALIGN_ALL) != 0;
+  fin.min_score = c->min_score;
   fin.units = S->d_units.as<Unit>();
   fin.pair_head = S->d_pair_head.as<uint32_t>();
   fin.pair_score = S->d_pair_score.as<double>();
@@ -1058,6 +1060,13 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
 int qf_set_pipeline_chunks(qf_ctx* c, uint32_t n_chunks) {
   if (!c) return QF_ERR_ARG;
   c->pipeline_chunks = n_chunks;
+  return QF_OK;
+}
+
+int qf_set_score_threshold(qf_ctx* c, double min_score) {
+  if (!c) return QF_ERR_ARG;
+  if (min_score != min_score) return fail(c, QF_ERR_ARG, "score threshold is NaN");
+  c->min_score = min_score;
   return QF_OK;
 }
 
@@ -1446,6 +1455,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
   oa.lse = c->d_lse.as<double>();
+  oa.min_score = c->min_score;
   oa.Km = sc.Km;
   oa.Kg = sc.Kg;
   oa.pair_head = c->d_pair_head.as<uint32_t>();

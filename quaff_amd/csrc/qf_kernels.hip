@@ -1732,6 +1732,7 @@ __global__ void k_select(FinalArgs a) {
     if (!(v > QF_NEG_INF)) continue;
     const double adj = v - nll;
     if (a.all) {
+      if (!(adj >= a.min_score)) continue;
       const Unit& u = a.units[a.pair_end_unit[p]];
       const uint32_t cap = 2 * yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
       const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
@@ -1742,6 +1743,7 @@ __global__ void k_select(FinalArgs a) {
       bestX = x;
     }
   }
+  if (!a.all && bestX != kNoUnit && !(bestAdj >= a.min_score)) bestX = kNoUnit;   // the read's best alignment is below the threshold
   if (!a.all && bestX != kNoUnit) {
     const uint32_t p = r * a.n_refs + bestX;
     const Unit& u = a.units[a.pair_end_unit[p]];

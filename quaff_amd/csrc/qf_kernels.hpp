@@ -137,6 +137,7 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   const uint32_t* ctxc;     // complemented-strand context words
   uint32_t* tb;
   const double* mmi[2];     // pair-emission tables [plain, yComplemented]
+  double min_score;         // alignments scoring below it are neither traced back nor returned (-inf: keep all)
   const double* gap[2];
   const double* lse;
   uint32_t Km, Kg;
@@ -177,6 +178,7 @@ constexpr uint32_t kAlignHole = 0xFFFFFFFFu;   // n_runs of a read without any a
 struct FinalArgs {
   uint32_t n_pairs, n_reads, n_refs, n_recs;
   int all;
+  double min_score;     // alignments scoring below it are neither traced back nor returned (-inf: keep all)
   int dense;            // best-per-read mode: record r belongs to read r (holes marked), results go to out_align
   uint32_t read_base;   // index of the chunk's first read in the batch
   AlignOut* out_align;

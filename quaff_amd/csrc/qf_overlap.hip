@@ -477,7 +477,7 @@ __global__ void k_overlap_finalize(OvArgs a) {
   a.pair_end_unit[p] = end > QF_NEG_INF ? eu : kNoUnit;
   a.pair_end_ij[2 * p] = ei;
   a.pair_end_ij[2 * p + 1] = ej;
-  if (end > QF_NEG_INF) {
+  if (end > QF_NEG_INF && score >= a.min_score) {
     const Unit& u = a.units[eu];
     const uint32_t cap = xLen + yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
     const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);

@@ -422,6 +422,8 @@ struct Session {
   }
   ~Session() { for (qf_ctx* c : ctxs) qf_ctx_destroy(c); }
   size_t devices() const { return ctxs.size(); }
+  // the printer's -threshold, applied on the device before the traceback (the printer still checks it)
+  void setThreshold(double t) { for (qf_ctx* c : ctxs) QF(c, qf_set_score_threshold(c, t)); }
   void loadParams(const Opts& o) {  // requireParamsOrUseDefaults, t/quaff.cpp:362-368
     const string text = o.paramsFile.size() ? slurp(o.paramsFile) : string(kDefaultParamsJson);
     Json j;
@@ -507,6 +509,7 @@ static int cmdAlign(Opts& o) {
   s.loadParams(o);
   s.loadNull(o, reads.seqs);
   s.setRefs(refs.seqs);
+  s.setThreshold(pr.threshold);
   pr.header(cout, refs.seqs, false);
   // contiguous blocks of reads, one per device at a time; printed in read order whatever the device count
   const size_t G = s.devices(), n = reads.seqs.size();
@@ -747,6 +750,7 @@ static int cmdOverlap(Opts& o) {
   Session s(o);
   s.loadParams(o);
   s.loadNull(o, reads.seqs);
+  s.setThreshold(pr.threshold);
   pr.header(cout, reads.seqs, true);
   string seq, qual;
   vector<uint64_t> off;

@@ -420,3 +420,31 @@ def test_many_bands_grow_unit_tables(ctx):
     reads = make_reads(rng, ref, 10, 350)
     res = check_against_oracle(ctx, both_strands(ref), reads, dict(kmer_len=4, kmer_threshold=3, band_size=6), sc, null)
     assert res["n_units"] > 4 * 20 + 1024
+
+
+def test_score_threshold_filters_before_the_traceback(ctx):
+    """qf_set_score_threshold = the printer's -threshold applied on the device: the surviving alignments are exactly the
+    unfiltered ones with score >= threshold (best-per-read: the best is chosen first, then tested; -printall: each)."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(36)
+    ref = rand_seq(rng, 3000)
+    reads = make_reads(rng, ref, 40, 300) + [O.FastSeq("junk%d" % k, rand_seq(rng, 250), rand_qual(rng, 250)) for k in range(8)]
+    sc, null = oracle_model()
+    key = lambda a: (a["read"], a["ref"], a["score"], a["xStart"], a["xEnd"], a["cigar"])
+    try:
+        for flags in (0, 1):
+            ctx.set_score_threshold(float("-inf"))
+            full, _ = run_both(ctx, both_strands(ref), reads, dict(), sc, null, flags=flags)
+            scores = sorted(a["score"] for a in full["alignments"])
+            thr = scores[len(scores) // 3]
+            ctx.set_score_threshold(thr)
+            cut, _ = run_both(ctx, both_strands(ref), reads, dict(), sc, null, flags=flags)
+            want = [key(a) for a in full["alignments"] if a["score"] >= thr]
+            assert 0 < len(want) < len(full["alignments"])
+            assert [key(a) for a in cut["alignments"]] == want
+            assert np.array_equal(cut["viterbi"], full["viterbi"]) and np.array_equal(cut["null_loglike"], full["null_loglike"])
+        ctx.set_score_threshold(float("inf"))
+        none, _ = run_both(ctx, both_strands(ref), reads, dict(), sc, null)
+        assert none["alignments"] == []
+    finally:
+        ctx.set_score_threshold(float("-inf"))

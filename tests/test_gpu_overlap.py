@@ -163,3 +163,30 @@ def test_overlap_ragged_lengths_sorted_lists(ctx):
         reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
     res, nfinite = check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
     assert nfinite == len(O.overlap_task_pairs(34, 68))
+
+
+def test_overlap_score_threshold_filters_before_the_traceback(ctx):
+    """Most pairs of an all-vs-all run do not overlap and score below the printer's default threshold of 0: with
+    qf_set_score_threshold they are not traced back; the survivors and every per-pair score are unchanged."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(47)
+    reads = overlapping_reads(rng, 6000, 14, 500)
+    seqs = reads + [r.revcomp() for r in reads]
+    pairs = O.overlap_task_pairs(len(reads), len(seqs))
+    ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    cfg = Q.DPConfig(kmer_threshold=14)
+    try:
+        full = ctx.overlap_resident(pairs, cfg)
+        scores = sorted(a["score"] for a in full["alignments"].values())
+        thr = scores[(2 * len(scores)) // 3]
+        ctx.set_score_threshold(thr)
+        cut = ctx.overlap_resident(pairs, cfg)
+        want = {k: a for k, a in full["alignments"].items() if a["score"] >= thr}
+        assert 0 < len(want) < len(full["alignments"]) and set(cut["alignments"]) == set(want)
+        for k, a in want.items():
+            g = cut["alignments"][k]
+            assert (g["score"], g["result"], g["xStart"], g["xEnd"], g["yStart"], g["yEnd"], g["ops"]) == \
+                   (a["score"], a["result"], a["xStart"], a["xEnd"], a["yStart"], a["yEnd"], a["ops"])
+        assert np.array_equal(cut["viterbi"], full["viterbi"]) and np.array_equal(cut["score"], full["score"])
+    finally:
+        ctx.set_score_threshold(float("-inf"))
