@@ -180,6 +180,10 @@ struct qf_ctx : Slot {
   uint64_t tb_budget = 160ull << 30;   // per-chunk device storage budget (traceback / Forward matrices)
   bool ov_scores[2] = {false, false};
   int read_index_k = 0;
+  // the reads' derived arrays (tokens, context words, insert sums, null log-likelihoods) as the overlap path leaves them
+  // stay valid while reads, parameters, null model and k are unchanged and no other entry point re-derives them
+  uint64_t prep_epoch = 1, ov_prep_epoch = 0;
+  int ov_prep_k = -1;
   HostBuf<double> h_ov_result, h_ov_score;
   std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
@@ -325,6 +329,7 @@ static int install_params(qf_ctx* c, const Params& p) {
   HIPCHK(c, hipMemcpy(c->d_trans.p, s.trans.data(), s.trans.size() * 8, hipMemcpyHostToDevice));
   c->have_params = true;
   c->ov_scores[0] = c->ov_scores[1] = false;
+  ++c->prep_epoch;
   return QF_OK;
 }
 
@@ -400,6 +405,7 @@ static int install_null(qf_ctx* c, const NullParams& n) {
   HIPCHK(c, c->d_nullq.reserve(lq.size() * 8));
   HIPCHK(c, hipMemcpy(c->d_nullq.p, lq.data(), lq.size() * 8, hipMemcpyHostToDevice));
   c->have_null = true;
+  ++c->prep_epoch;
   return QF_OK;
 }
 
@@ -537,6 +543,7 @@ int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->reads_have_qual = qual != nullptr;
   c->read_index_k = 0;
+  ++c->prep_epoch;
   c->n_reads = n_reads;
   return QF_OK;
 }
@@ -545,6 +552,7 @@ int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t
 // `side`: run the null log-likelihoods (a serial sum per read, needed only when pairs are finalised) on that stream, beside
 // whatever the caller launches next on the main stream; c->ev_nll is recorded behind them.
 static int prep_reads(qf_ctx* c, int seed_k, hipStream_t side = nullptr) {
+  ++c->prep_epoch;
   PrepArgs a{};
   a.seq = c->d_seq.as<char>();
   a.qual = c->reads_have_qual ? c->d_qual.as<char>() : nullptr;
@@ -1568,7 +1576,10 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
   HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
-  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  const int prep_k = sparse ? cfg->kmer_len : 0;
+  const bool prepped = c->ov_prep_epoch == c->prep_epoch && c->ov_prep_k == prep_k;   // a later block of the same pair list
+  if (!prepped) {
+  if (int rc = prep_reads(c, prep_k)) return rc;
   if (sparse && c->read_index_k != cfg->kmer_len && cfg->kmer_len > kMaxRefK) {
     if (int rc = build_sorted_index(c, c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), c->read_off, c->read_maxlen, cfg->kmer_len,
                                     c->d_roff32, c->d_rskeys, c->d_rpos))
@@ -1610,6 +1621,7 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     launch_prep_overlap(pa, n_seqs, c->stream);
     HIPCHK(c, hipGetLastError());
   }
+  }
   HIPCHK(c, c->d_px.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_py.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_pc.reserve((size_t)n_pairs));
@@ -1623,6 +1635,8 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     if (int rc = read_counters(c, pb)) return rc;
     if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
   }
+  c->ov_prep_epoch = c->prep_epoch;   // (only once the symbols have been checked)
+  c->ov_prep_k = prep_k;
   (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
   out->ms_total = out->ms_prep;
   c->h_ov_result.resize(n_pairs);

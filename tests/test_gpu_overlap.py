@@ -190,3 +190,39 @@ def test_overlap_score_threshold_filters_before_the_traceback(ctx):
         assert np.array_equal(cut["viterbi"], full["viterbi"]) and np.array_equal(cut["score"], full["score"])
     finally:
         ctx.set_score_threshold(float("-inf"))
+
+
+def test_overlap_read_preparation_is_cached_and_invalidated(ctx):
+    """Blocks of one pair list reuse the reads' derived arrays (context words, insert sums, null log-likelihoods); anything
+    that changes them — another entry point re-deriving them for its own k, new parameters, a new k — must not."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(48)
+    reads = overlapping_reads(rng, 1500, 8, 400)
+    seqs = reads + [r.revcomp() for r in reads]
+    pairs = O.overlap_task_pairs(len(reads), len(seqs))
+    up = lambda: ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    cfg = Q.DPConfig(kmer_threshold=14)
+
+    def same(a, b):
+        for key in ("viterbi", "score", "cells", "n_diagonals"):
+            assert np.array_equal(a[key], b[key]), key
+        assert {k: (v["score"], v["ops"]) for k, v in a["alignments"].items()} == {k: (v["score"], v["ops"]) for k, v in b["alignments"].items()}
+
+    up()
+    first = ctx.overlap_resident(pairs, cfg)
+    same(first, ctx.overlap_resident(pairs, cfg))                    # second block: cached
+    ctx.set_refs([seqs[0].seq])
+    ctx.align_resident(Q.DPConfig(kmer_len=8, kmer_threshold=5), 0)  # re-derives the read arrays with 8-mers
+    same(first, ctx.overlap_resident(pairs, cfg))
+    k7 = ctx.overlap_resident(pairs, Q.DPConfig(kmer_threshold=14, kmer_len=7))
+    up()
+    same(k7, ctx.overlap_resident(pairs, Q.DPConfig(kmer_threshold=14, kmer_len=7)))
+    pj = synth_params_json(rng, 2, 1)
+    try:
+        ctx.set_params_json(pj)                                      # same reads, new model: no stale context words
+        changed = ctx.overlap_resident(pairs, cfg)
+        up()
+        same(changed, ctx.overlap_resident(pairs, cfg))
+        assert not np.array_equal(changed["viterbi"], first["viterbi"])
+    finally:
+        ctx.set_params_json(None)
