@@ -831,6 +831,38 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_re
   }
 }
 
+// The same for explicit pair lists (read-vs-read overlap: x is a read too).  The scheduler's list is x-major
+// (src/qoverlap.cpp:528-547), so the 64 consecutive pairs of a workgroup nearly always share their x: its index goes to
+// LDS; a pair with another x takes the global-memory path.
+template <bool WIDE>
+__global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words, uint32_t idx_words) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t p0 = blockIdx.x * kSeedReadsPerBlock;
+  uint32_t r0, x0;
+  pair_rx(a, a.pair_base + p0, r0, x0);
+  const uint64_t xb = a.ref_off[x0];
+  const uint32_t xLen = (uint32_t)(a.ref_off[x0 + 1] - xb), nb1 = a.nbuckets + 1;
+  uint16_t* sb = (uint16_t*)lds;
+  uint16_t* sp = sb + ((nb1 + 1) & ~1u);
+  const uint32_t* gb = a.ref_bucket + (uint64_t)x0 * nb1;
+  const uint32_t* gp = a.ref_pos + xb;
+  for (uint32_t q = threadIdx.x; q < nb1; q += 512) sb[q] = (uint16_t)gb[q];
+  for (uint32_t q = threadIdx.x; q < xLen + 4; q += 512) sp[q] = q < xLen ? (uint16_t)gp[q] : (uint16_t)0;
+  __syncthreads();
+  uint32_t* wlds = lds + idx_words + (size_t)wv * wave_lds_words;
+  const uint32_t pend = min(p0 + kSeedReadsPerBlock, n_pairs);
+  for (uint32_t p = p0 + wv; p < pend; p += 8) {
+    const uint32_t pair = a.pair_base + p;
+    if (a.pair_skip && a.pair_skip[pair]) continue;
+    uint32_t r, x;
+    pair_rx(a, pair, r, x);
+    if (x == x0) seed_wave_pair<true, WIDE>(a, pair, r, x, wlds, sb, sp);
+    else seed_wave_pair<false, WIDE>(a, pair, r, x, wlds, nullptr, nullptr);
+    wave_lds_sync();
+  }
+}
+
 // Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
 // (pair, band slot); one global atomic per workgroup and counter.
 __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs, uint32_t n_ovf) {
@@ -2074,6 +2106,22 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
         } else {
           if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
           hipLaunchKernelGGL(k_seed_wave_lds<false>, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
+        }
+        return 0;
+      }
+    }
+    // explicit pair list (overlap): the shared x's index in LDS, same limits
+    if (a.pair_x && !a.ref_skeys && a.nbuckets && a.max_ref_len && a.max_ref_len + 4 < 65536 && !a.dump_cover && !a.no_lds_index) {
+      const uint32_t idx_words = (((a.nbuckets + 2) & ~1u) + ((a.max_ref_len + 5) & ~1u)) / 2;
+      const size_t lds2 = ((size_t)idx_words + (size_t)words * 8) * 4;
+      if ((size_t)idx_words * 4 <= 48 * 1024 && lds2 <= 80 * 1024) {
+        const uint32_t blocks = (n_pairs + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock;
+        if (wide) {
+          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+          hipLaunchKernelGGL(k_seed_wave_lds_pairs<true>, dim3(blocks), dim3(512), lds2, s, a, n_pairs, words, idx_words);
+        } else {
+          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+          hipLaunchKernelGGL(k_seed_wave_lds_pairs<false>, dim3(blocks), dim3(512), lds2, s, a, n_pairs, words, idx_words);
         }
         return 0;
       }
