@@ -601,14 +601,18 @@ struct __attribute__((packed, aligned(4))) U32x4u { uint32_t v[4]; };
 // LDSIDX: the reference's k-mer index (bucket starts and positions, 16 bits each) sits in LDS (sb, sp) instead of being
 // gathered from global memory.
 // WIDE: 32-bit coarse counters (a 32-diagonal bin of a read of 2 048+ bases can collect 65 536 matches and wrap 16 bits)
-template <bool LDSIDX, bool WIDE>
+// CB: log2 of the coarse bin width (5, 4 or 3).  Unrelated sequences still share length/4^k k-mers per diagonal by
+// chance; when 32 diagonals' worth of those comes close to the threshold (overlap defaults: 2 kb reads, k = 6, n = 14)
+// nearly every pair would have "candidate" bins and pay the second walk, so the host picks narrower bins then.
+template <bool LDSIDX, bool WIDE, int CB>
 __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair, uint32_t r, uint32_t x, uint32_t* wlds,
                                                const uint16_t* sb, const uint16_t* sp) {
-  // Two-level histogram.  Pass 1 counts k-mer matches per COARSE bin of 32 diagonals; a diagonal can reach
+  // Two-level histogram.  Pass 1 counts k-mer matches per COARSE bin of 2^CB diagonals; a diagonal can reach
   // the threshold only inside a coarse bin that does, so pass 2 re-walks the matches and keeps exact
   // per-diagonal counters for those candidate bins alone (none at all for unrelated / wrong-strand pairs).
   // ~4 KB of LDS per wavefront instead of a dense 2 B/diagonal histogram.
   constexpr int kCand = 32;  // candidate coarse bins refined per round
+  constexpr int CW = 1 << CB, FW = CW / 2;  // diagonals per coarse bin; dwords of 16-bit fine counters per candidate bin
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t xb = a.ref_off[x], yb = a.read_off[r];
   const int xLen = (int)(a.ref_off[x + 1] - xb), yLen = (int)(a.read_off[r + 1] - yb);
@@ -624,10 +628,11 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
       for (int b = lane; b < nd; b += 64) a.dump_cover[b] = 1;
     return;
   }
-  const int nCoarse = (nd + 31) >> 5, coarseWords = WIDE ? nCoarse : (nCoarse + 1) / 2, bmWords = nCoarse;
+  const int nCoarse = (nd + CW - 1) >> CB, coarseWords = WIDE ? nCoarse : (nCoarse + 1) / 2, bmWords = (nd + 31) >> 5;
+  const int maxCoarse = (a.max_nd + CW - 1) >> CB;
   uint32_t* coarse = wlds;                                   // two 16-bit counters per dword (one if WIDE); later: slot map
-  uint32_t* bm = coarse + (WIDE ? ((a.max_nd + 31) / 32 + 2) : (((a.max_nd + 31) / 32 + 1) / 2 + 1));  // membership bitmap, one bit per diagonal
-  uint32_t* fine = bm + ((a.max_nd + 31) / 32 + 1);          // [kCand][16] dwords = 32 x 16-bit counters each
+  uint32_t* bm = coarse + (WIDE ? maxCoarse + 2 : (maxCoarse + 1) / 2 + 1);  // membership bitmap, one bit per diagonal
+  uint32_t* fine = bm + ((a.max_nd + 31) / 32 + 1);          // [kCand][FW] dwords = CW x 16-bit counters each (16 dwords reserved)
   uint32_t* misc = fine + kCand * 16;                        // [0] candidate count, [1..kCand] candidate bins
 
   for (int w = lane; w < coarseWords; w += 64) coarse[w] = 0;
@@ -684,8 +689,8 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
     }
   };
   walk([&](int bin) {
-    if (WIDE) atomicAdd(&coarse[bin >> 5], 1u);
-    else atomicAdd(&coarse[bin >> 6], 1u << (16 * ((bin >> 5) & 1)));
+    if (WIDE) atomicAdd(&coarse[bin >> CB], 1u);
+    else atomicAdd(&coarse[bin >> (CB + 1)], 1u << (16 * ((bin >> CB) & 1)));
   });
   wave_lds_sync();
 
@@ -725,30 +730,30 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
   };
   auto slotOf = [&](int cb) -> uint32_t { return WIDE ? (coarse[cb] & 0xFFFFu) : (coarse[cb >> 1] >> (16 * (cb & 1))) & 0xFFFFu; };
   for (uint32_t base = 0; base < ncand; base += kCand) {  // almost always one round
-    for (int w = lane; w < kCand * 16; w += 64) fine[w] = 0;
+    for (int w = lane; w < kCand * FW; w += 64) fine[w] = 0;
     wave_lds_sync();
     walk([&](int bin) {
-      const uint32_t slot = slotOf(bin >> 5) - base;  // 0xFFFF - base is never < kCand
-      if (slot < (uint32_t)kCand) atomicAdd(&fine[slot * 16 + ((bin & 31) >> 1)], 1u << (16 * (bin & 1)));
+      const uint32_t slot = slotOf(bin >> CB) - base;  // 0xFFFF - base is never < kCand
+      if (slot < (uint32_t)kCand) atomicAdd(&fine[slot * FW + ((bin & (CW - 1)) >> 1)], 1u << (16 * (bin & 1)));
     });
     wave_lds_sync();
     // seeds: diagonals of this round's candidate bins reaching the threshold (diagenv.cpp:68-96)
     if (base == 0) {
       // one lane per (candidate bin, diagonal): the first round's bins are listed in misc[1..]
       const uint32_t nslots = min(ncand, (uint32_t)kCand);
-      for (uint32_t idx = lane; idx < nslots * 32; idx += 64) {
-        const uint32_t slot = idx >> 5, c = idx & 31;
+      for (uint32_t idx = lane; idx < nslots * CW; idx += 64) {
+        const uint32_t slot = idx >> CB, c = idx & (CW - 1);
         const int cb = (int)misc[1 + slot];
-        const uint32_t cnt = (fine[slot * 16 + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
-        if (cnt >= thr && cb * 32 + (int)c < nd) mark(cb * 32 + (int)c);
+        const uint32_t cnt = (fine[slot * FW + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
+        if (cnt >= thr && cb * CW + (int)c < nd) mark(cb * CW + (int)c);
       }
     } else {
       for (int cb = lane; cb < nCoarse; cb += 64) {
         const uint32_t slot = slotOf(cb) - base;
         if (slot >= (uint32_t)kCand) continue;
-        for (int c = 0; c < 32; ++c) {
-          const uint32_t cnt = (fine[slot * 16 + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
-          if (cnt >= thr && cb * 32 + c < nd) mark(cb * 32 + c);
+        for (int c = 0; c < CW; ++c) {
+          const uint32_t cnt = (fine[slot * FW + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
+          if (cnt >= thr && cb * CW + c < nd) mark(cb * CW + c);
         }
       }
     }
@@ -791,7 +796,7 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
 
 // One wavefront per (read, ref) pair, four pairs per workgroup; the index is gathered from global memory (any reference
 // set, explicit pair lists).
-template <bool WIDE>
+template <bool WIDE, int CB>
 __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words) {
   extern __shared__ uint32_t lds[];
   const uint32_t wv = threadIdx.x >> 6;
@@ -801,14 +806,14 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
   if (a.pair_skip && a.pair_skip[pair]) return;
   uint32_t r, x;
   pair_rx(a, pair, r, x);
-  seed_wave_pair<false, WIDE>(a, pair, r, x, lds + (size_t)wv * wave_lds_words, nullptr, nullptr);
+  seed_wave_pair<false, WIDE, CB>(a, pair, r, x, lds + (size_t)wv * wave_lds_words, nullptr, nullptr);
 }
 
 // Short references (k-mer index of one reference <= 48 KB as 16-bit entries): a workgroup of eight wavefronts copies one
 // reference's index to LDS and seeds kSeedReadsPerBlock reads against it.  The global-memory version spends two thirds
 // of its cycles waiting on L1 misses of those gathers (measured); here the only global traffic is the reads' k-mers.
 constexpr uint32_t kSeedReadsPerBlock = 64;
-template <bool WIDE>
+template <bool WIDE, int CB>
 __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_reads, uint32_t wave_lds_words, uint32_t idx_words) {
   extern __shared__ uint32_t lds[];
   const uint32_t wv = threadIdx.x >> 6;
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_re
   for (uint32_t r = r0 + wv; r < min(r0 + kSeedReadsPerBlock, n_reads); r += 8) {
     const uint32_t pair = a.pair_base + r * a.n_refs + x;
     if (a.pair_skip && a.pair_skip[pair]) continue;
-    seed_wave_pair<true, WIDE>(a, pair, r, x, wlds, sb, sp);
+    seed_wave_pair<true, WIDE, CB>(a, pair, r, x, wlds, sb, sp);
     wave_lds_sync();
   }
 }
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_re
 // The same for explicit pair lists (read-vs-read overlap: x is a read too).  The scheduler's list is x-major
 // (src/qoverlap.cpp:528-547), so the 64 consecutive pairs of a workgroup nearly always share their x: its index goes to
 // LDS; a pair with another x takes the global-memory path.
-template <bool WIDE>
+template <bool WIDE, int CB>
 __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words, uint32_t idx_words) {
   extern __shared__ uint32_t lds[];
   const uint32_t wv = threadIdx.x >> 6;
@@ -857,8 +862,8 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_
     if (a.pair_skip && a.pair_skip[pair]) continue;
     uint32_t r, x;
     pair_rx(a, pair, r, x);
-    if (x == x0) seed_wave_pair<true, WIDE>(a, pair, r, x, wlds, sb, sp);
-    else seed_wave_pair<false, WIDE>(a, pair, r, x, wlds, nullptr, nullptr);
+    if (x == x0) seed_wave_pair<true, WIDE, CB>(a, pair, r, x, wlds, sb, sp);
+    else seed_wave_pair<false, WIDE, CB>(a, pair, r, x, wlds, nullptr, nullptr);
     wave_lds_sync();
   }
 }
@@ -2068,16 +2073,44 @@ size_t seed_lds_bytes(int max_nd, bool mem, bool deep) {
   const size_t hist = deep ? (size_t)max_nd * 4 : (size_t)((max_nd + 1) / 2) * 4;
   return mem ? hist + (size_t)((max_nd + 3) & ~1) * 2 + (size_t)(max_nd + 4) * 2 : hist + (size_t)max_nd + 4;
 }
+// Coarse bin width of the wavefront seeding (log2): the widest of 32 / 16 / 8 diagonals whose chance k-mer matches between
+// unrelated sequences (min(len) / 4^k per diagonal, Poisson) stay four standard deviations below the threshold.
+static int seed_coarse_bits(const SeedArgs& a) {
+  const double len = a.max_ref_len ? (double)(a.max_ref_len < a.max_read_len ? a.max_ref_len : a.max_read_len) : (double)a.max_read_len;
+  const double per_diag = a.kmer_len < 32 ? len / (double)(1ull << (2 * a.kmer_len)) : 0.0;
+  for (int cb = 5; cb > 3; --cb) {
+    const double lam = per_diag * (1 << cb);
+    if (lam + 4.0 * sqrt(lam) + 1.0 <= (double)a.threshold) return cb;
+  }
+  return 3;
+}
+// LDS words one wavefront of the wavefront seeding needs; `wide` = 32-bit coarse counters (a bin could pass 65 535)
+static uint32_t seed_wave_words(const SeedArgs& a, int cb, bool& wide) {
+  const uint32_t nc = (uint32_t)((a.max_nd + (1 << cb) - 1) >> cb), nb = (uint32_t)((a.max_nd + 31) / 32);
+  wide = ((uint64_t)a.max_read_len << cb) >= 65280u;
+  return (wide ? nc + 2 : (nc + 1) / 2 + 1) + (nb + 1) + 32 * 16 + 40;
+}
 bool seed_needs_workspace(const SeedArgs& a, bool mem) {
   if (!a.sparse) return false;
   if (seed_needs_deep_counters(a)) return true;
   if (!mem && a.threshold >= 0 && !a.force_block_kernel) {
-    const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
-    const uint32_t words = (a.max_read_len >= 2040 ? nc + 2 : (nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
+    bool wide;
+    const uint32_t words = seed_wave_words(a, seed_coarse_bits(a), wide);
     if ((size_t)words * 4 * 4 <= 150 * 1024) return false;
   }
   return seed_lds_bytes(a.max_nd, mem, false) > 150 * 1024;
 }
+namespace {
+template <class F>
+void with_seed_variant(bool wide, int cb, F&& f) {   // f(std::bool_constant<WIDE>, std::integral_constant<int, CB>)
+  auto pick = [&](auto w) {
+    if (cb == 5) f(w, std::integral_constant<int, 5>());
+    else if (cb == 4) f(w, std::integral_constant<int, 4>());
+    else f(w, std::integral_constant<int, 3>());
+  };
+  if (wide) pick(std::true_type()); else pick(std::false_type());
+}
+}  // namespace
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
   if (seed_needs_deep_counters(a)) {  // 65 536+ matches on one diagonal are possible: 32-bit counters, global workspaces
@@ -2088,52 +2121,42 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
     return 0;
   }
   if (!mem && a.sparse && a.threshold >= 0 && !a.force_block_kernel) {
-    // one wavefront per pair, four pairs per workgroup; LDS per wave: coarse counters + bitmap + fine counters
-    const uint32_t nc = (uint32_t)((a.max_nd + 31) / 32);
-    const bool wide = a.max_read_len >= 2040;   // 32 diagonals x (read length - k + 1) matches could wrap a 16-bit counter
-    const uint32_t words = (wide ? nc + 2 : (nc + 1) / 2 + 1) + (nc + 1) + 32 * 16 + 40;
+    // one wavefront per pair; LDS per wave: coarse counters + bitmap + fine counters
+    const int cb = seed_coarse_bits(a);
+    bool wide;
+    const uint32_t words = seed_wave_words(a, cb, wide);
     const size_t lds = (size_t)words * 4 * 4;
-    // LDS-resident index: bucket-indexed (k <= 8), implicit read x ref pair order, 16-bit positions, <= 48 KB
-    if (!a.pair_x && !a.ref_skeys && a.nbuckets && a.max_ref_len && a.max_ref_len + 4 < 65536 && !a.dump_cover && !a.no_lds_index) {
-      const uint32_t idx_words = (((a.nbuckets + 2) & ~1u) + ((a.max_ref_len + 5) & ~1u)) / 2;
-      const size_t lds2 = ((size_t)idx_words + (size_t)words * 8) * 4;
-      if ((size_t)idx_words * 4 <= 48 * 1024 && lds2 <= 80 * 1024 && n_pairs % a.n_refs == 0) {
-        const uint32_t n_reads = n_pairs / a.n_refs;
-        const uint32_t blocks = ((n_reads + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock) * a.n_refs;
-        if (wide) {
-          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-          hipLaunchKernelGGL(k_seed_wave_lds<true>, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
-        } else {
-          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-          hipLaunchKernelGGL(k_seed_wave_lds<false>, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
-        }
-        return 0;
-      }
+    const bool lds_index_ok = !a.ref_skeys && a.nbuckets && a.max_ref_len && a.max_ref_len + 4 < 65536 && !a.dump_cover && !a.no_lds_index;
+    const uint32_t idx_words = (((a.nbuckets + 2) & ~1u) + ((a.max_ref_len + 5) & ~1u)) / 2;
+    const size_t lds2 = ((size_t)idx_words + (size_t)words * 8) * 4;
+    const bool lds_index_fits = (size_t)idx_words * 4 <= 48 * 1024 && lds2 <= 80 * 1024;
+    // LDS-resident index: bucket-indexed (k <= 8), 16-bit positions, <= 48 KB; implicit read x ref pair order ...
+    if (!a.pair_x && lds_index_ok && lds_index_fits && n_pairs % a.n_refs == 0) {
+      const uint32_t n_reads = n_pairs / a.n_refs;
+      const uint32_t blocks = ((n_reads + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock) * a.n_refs;
+      with_seed_variant(wide, cb, [&](auto w, auto c) {
+        auto fn = k_seed_wave_lds<decltype(w)::value, decltype(c)::value>;
+        if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds2, s, a, n_reads, words, idx_words);
+      });
+      return 0;
     }
-    // explicit pair list (overlap): the shared x's index in LDS, same limits
-    if (a.pair_x && !a.ref_skeys && a.nbuckets && a.max_ref_len && a.max_ref_len + 4 < 65536 && !a.dump_cover && !a.no_lds_index) {
-      const uint32_t idx_words = (((a.nbuckets + 2) & ~1u) + ((a.max_ref_len + 5) & ~1u)) / 2;
-      const size_t lds2 = ((size_t)idx_words + (size_t)words * 8) * 4;
-      if ((size_t)idx_words * 4 <= 48 * 1024 && lds2 <= 80 * 1024) {
-        const uint32_t blocks = (n_pairs + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock;
-        if (wide) {
-          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-          hipLaunchKernelGGL(k_seed_wave_lds_pairs<true>, dim3(blocks), dim3(512), lds2, s, a, n_pairs, words, idx_words);
-        } else {
-          if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave_lds_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-          hipLaunchKernelGGL(k_seed_wave_lds_pairs<false>, dim3(blocks), dim3(512), lds2, s, a, n_pairs, words, idx_words);
-        }
-        return 0;
-      }
+    // ... or an explicit pair list (overlap): the shared x's index in LDS
+    if (a.pair_x && lds_index_ok && lds_index_fits) {
+      const uint32_t blocks = (n_pairs + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock;
+      with_seed_variant(wide, cb, [&](auto w, auto c) {
+        auto fn = k_seed_wave_lds_pairs<decltype(w)::value, decltype(c)::value>;
+        if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds2, s, a, n_pairs, words, idx_words);
+      });
+      return 0;
     }
-    if (lds <= 150 * 1024) {
-      if (wide) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_seed_wave<true>, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
-      } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_seed_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_seed_wave<false>, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
-      }
+    if (lds <= 150 * 1024) {   // four pairs per workgroup, index gathered from global memory
+      with_seed_variant(wide, cb, [&](auto w, auto c) {
+        auto fn = k_seed_wave<decltype(w)::value, decltype(c)::value>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(fn, dim3((n_pairs + 3) / 4), dim3(256), lds, s, a, n_pairs, words);
+      });
       return 0;
     }
   }
