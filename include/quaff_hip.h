@@ -71,8 +71,8 @@ typedef struct qf_dp_config {
   int32_t band_size;       /* -kmatchband, default 64 */
   int32_t reserved;        /* debug: bit 0 = workgroup-per-pair seeding kernel, bit 1 = first-generation fill kernel,
                             * bit 2 = run the fill classes one after another on one stream, bit 3 = emission
-                            * tables stay in global memory, bit 4 = reference k-mer index stays in global memory;
-                            * keep 0 */
+                            * tables stay in global memory, bit 4 = reference k-mer index stays in global memory,
+                            * bit 5 = overlap single-diagonal bands gather emissions from global memory; keep 0 */
   uint64_t max_size;       /* memory mode: effectiveMaxSize() in bytes (-kmatchmb M => M<<20) */
 } qf_dp_config;
 

@@ -96,6 +96,7 @@ struct Slot {
   hipEvent_t ev[7] = {};   // [6]: pair results final (their copy to the host overlaps selection and traceback)
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
+  hipStream_t hi[3] = {};                                          // high priority: classes too small to fill the chip (latency-bound chains)
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
       d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws, d_align_out, d_cls_key, d_sort_k, d_sort_v;
   void* sort_tmp = nullptr;
@@ -114,6 +115,7 @@ struct Slot {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (auto& s : aux) (void)hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+    for (auto& s : hi) (void)hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest);
     return 0;
   }
   void destroy() {
@@ -126,6 +128,7 @@ struct Slot {
     for (auto& e : cls_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_end) if (e) (void)hipEventDestroy(e);
     for (auto& s : aux) if (s) (void)hipStreamDestroy(s);
+    for (auto& s : hi) if (s) (void)hipStreamDestroy(s);
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -1099,16 +1102,41 @@ uint32_t qf_counts_size(const qf_ctx* c) {
 // Classes of one phase on concurrent streams (the class with the most cells on the main stream, the others on the low-
 // priority side streams), joined back into the main stream: small classes fill the tail of the big one.
 static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool serial,
-                                       const std::function<void(int, hipStream_t)>& launch, int first_cls = 1) {
+                                       const std::function<void(int, hipStream_t)>& launch, int first_cls = 1,
+                                       bool small_first = false) {
   int order[kNumClasses], n_used = 0;
   for (int cls = first_cls; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
   std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
   if (n_used > 1 && !serial) {   // side streams start after everything queued on the main stream so far
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     for (auto& s : c->aux) HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
+    if (small_first) for (auto& s : c->hi) HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
   }
+  // small_first (overlap): a class with fewer wavefronts than the chip holds cannot hide its own latency — every step of a
+  // band is a chain of dependent table lookups — and behind millions of single-diagonal bands at equal or lower priority it
+  // crawls and ends up setting the length of the phase.  Such classes go to high-priority streams and start first.
+  auto waves_of = [&](int cls) -> uint64_t {
+    const uint64_t n = bc.cls_count[cls];
+    if (cls == 0) return (n + 63) / 64;
+    if (cls == kRowClass) return n;
+    return (n * (uint64_t)fill_class(cls).G + 63) / 64;
+  };
+  int k_big = 0, k_small = 0, joins[kNumClasses], n_join = 0;
+  if (small_first && !serial && n_used > 1)
+    for (int k = 0; k < n_used; ++k) {
+      const int cls = order[k];
+      if (waves_of(cls) > 4096) continue;
+      hipStream_t s = c->hi[k_small++ % 3];
+      launch(cls, s);
+      HIPCHK(c, hipEventRecord(c->cls_end[cls], s));
+      joins[n_join++] = cls;      // the main stream joins them after its own class has been queued
+      order[k] = -1;
+    }
   for (int k = 0; k < n_used; ++k) {
-    const int cls = order[k], lane = serial ? 0 : (k < 4 ? k : 1 + (k - 1) % 3);
+    const int cls = order[k];
+    if (cls < 0) continue;
+    const int lane = serial ? 0 : (k_big < 4 ? k_big : 1 + (k_big - 1) % 3);
+    ++k_big;
     hipStream_t s = lane == 0 ? c->stream : c->aux[lane - 1];
     launch(cls, s);
     if (lane) {
@@ -1116,6 +1144,7 @@ static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool 
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[cls], 0));
     }
   }
+  for (int k = 0; k < n_join; ++k) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[joins[k]], 0));
   return QF_OK;
 }
 
@@ -1464,6 +1493,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
   oa.lse = c->d_lse.as<double>();
   oa.min_score = c->min_score;
+  oa.no_lds_rows = (cfg->reserved >> 5) & 1;
   oa.Km = sc.Km;
   oa.Kg = sc.Kg;
   oa.pair_head = c->d_pair_head.as<uint32_t>();
@@ -1483,7 +1513,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         o2.n_cls_units = bc.cls_count[cls];
         o2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
         launch_overlap_fill(cls, o2, s);
-      }, 0))
+      }, 0, true))
     return rc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -138,6 +138,7 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   uint32_t* tb;
   const double* mmi[2];     // pair-emission tables [plain, yComplemented]
   double min_score;         // alignments scoring below it are neither traced back nor returned (-inf: keep all)
+  int no_lds_rows;          // A/B: single-diagonal bands gather their emissions from global memory (k_overlap_single)
   const double* gap[2];
   const double* lse;
   uint32_t Km, Kg;

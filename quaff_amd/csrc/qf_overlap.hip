@@ -303,6 +303,118 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
   }
 }
 
+// The same with the pair-emission rows staged through LDS.  The class list follows the x-major pair list, so the bands of
+// a workgroup nearly always share x, the diagonal and the strand flag: at column j they all read row (context, quality) of
+// x's base d + j of the emission table and differ only in the column (y's base j).  Per block of kSingleSub columns the
+// workgroup copies those rows (Km * 95 doubles each, coalesced) into LDS and every lane picks its entries there; a lane
+// whose band differs from the first band's (x, diagonal, strand) gathers from global memory as before.  Each lane also
+// takes a whole 128-byte line (32 columns) of its y context words at a time, and stores its traceback nibbles 16 bytes
+// at a time.  (The per-lane gathers of the plain kernel are bound by L1 line fills: one 128-byte line per 8-byte entry.)
+constexpr int kSingleSub = 4;
+__global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
+  struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
+  extern __shared__ double s_rows[];   // [2][kSingleSub][KQ]
+  __shared__ unsigned long long s_xb0;
+  __shared__ int s_d0, s_xLen0, s_T;
+  __shared__ uint32_t s_x0, s_comp0;
+  const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0, comp = 0, x = 0;
+  int d = 0, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, tb_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    x = a.pair_x[u.pair];
+    const uint32_t y = a.pair_y[u.pair];
+    comp = a.pair_comp[u.pair];
+    xb = a.seq_off[x]; xLen = (int)(a.seq_off[x + 1] - xb);
+    yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
+    d = u.dlo; tb_off = u.tb_off;
+  }
+  if (threadIdx.x == 0) { s_x0 = x; s_comp0 = comp; s_d0 = d; s_xb0 = xb; s_xLen0 = xLen; s_T = 0; }   // thread 0 is always active
+  __syncthreads();
+  atomicMax(&s_T, active ? yLen : 0);
+  __syncthreads();
+  const int T = s_T;
+  const bool shared_row = active && x == s_x0 && d == s_d0 && comp == s_comp0;
+  const double* __restrict__ mmi = a.mmi[comp];
+  const double* __restrict__ mmi0 = a.mmi[s_comp0];
+  const double* __restrict__ gap = a.gap[comp];
+  const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
+  const uint32_t* __restrict__ xc = a.ctx + xb;
+  const uint32_t* __restrict__ xc0 = a.ctx + s_xb0;
+  const int d0 = s_d0, xLen0 = s_xLen0;
+  const uint32_t* __restrict__ yc = (comp ? a.ctxc : a.ctx) + yb;
+  uint32_t* __restrict__ tb = a.tb + tb_off;
+  double M = QF_NEG_INF, colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
+  uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0;
+  const uint32_t srow = threadIdx.x >> 6, scol = threadIdx.x & 63;   // staging: one wavefront per row of the block
+  int buf = 0;
+  for (int j0 = 1; j0 <= T; j0 += 32) {
+    const int yi = min(j0 - 1, yLen);                       // both context arrays are padded by kCtxPad words
+    W4 yw[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) yw[q] = *(const W4*)(yc + yi + 4 * q);
+    uint32_t words[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int sub = 0; sub < 32 / kSingleSub; ++sub) {
+      const int js = j0 + sub * kSingleSub;                 // first column of the block
+      if (js <= T) {                                        // (uniform over the workgroup)
+        {  // stage the block's rows of the first band's x: row srow = base d0 + js + srow
+          const int i0 = min(max(d0 + js + (int)srow - 1, -kCtxPad + 8), xLen0);
+          const double* __restrict__ src = mmi0 + (size_t)(xc0[i0] & 0x7FFFu) * KQ;
+          double* dst = s_rows + ((size_t)buf * kSingleSub + srow) * KQ;
+          for (uint32_t q = scol; q < KQ; q += 64) dst[q] = src[q];
+        }
+        __syncthreads();
+        const int xi = min(max(d + js - 1, -kCtxPad + 8), xLen);
+        const W4 xa = *(const W4*)(xc + xi);
+        double e[kSingleSub];
+        uint32_t wyc[kSingleSub];
+#pragma unroll
+        for (int c = 0; c < kSingleSub; ++c) {
+          const int col = sub * kSingleSub + c;             // 0..31 within the line
+          wyc[c] = yw[col >> 2].v[col & 3];
+          const uint32_t ey = wyc[c] & 0x7FFFu;
+          e[c] = shared_row ? s_rows[((size_t)buf * kSingleSub + c) * KQ + ey] : mmi[(size_t)(xa.v[c] & 0x7FFFu) * KQ + ey];
+        }
+        uint32_t nib = 0;
+#pragma unroll
+        for (int c = 0; c < kSingleSub; ++c) {
+          const int j = js + c, i = d + j;
+          const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
+          const uint32_t gxP = i > 1 ? gxPrev : 0u, gyP = j > 1 ? gyPrev : 0u;  // xIndelKmer[i-1], yIndelKmer[j-1] (padded 0)
+          gxPrev = xa.v[c] >> 24; gyPrev = wyc[c] >> 24;
+          const double tM = (M + gap[gxP * Kg + gyP]) + e[c];
+          double nm = tM;
+          uint32_t sm = 0;
+          if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; sm = 3; }
+          if (!valid) nm = QF_NEG_INF;
+          M = nm;
+          nib |= sm << (4 * c);
+          if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
+          if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+        }
+        words[sub >> 1] |= nib << (16 * (sub & 1));
+        buf ^= 1;
+      }
+    }
+    // traceback words of columns j0 .. j0+31 (one per 8 columns, as k_overlap_single writes them); the unit's storage is
+    // (yLen + 7) / 8 words
+    if (active) {
+      const int w0 = (j0 - 1) >> 3, nw = (yLen + 7) >> 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (w0 + q < nw) tb[w0 + q] = words[q];
+    }
+  }
+  if (active) {
+    Unit* u = &a.units[uid];
+    u->end_val = colBest; u->end_i = colI;
+    u->end2_val = rowBest; u->end2_j = rowJ;
+  }
+}
+
 
 // Row-space overlap Viterbi for bands wider than 512 diagonals (-kmatchoff, or a sequence shorter than 2(k+threshold):
 // full envelope).  Geometry of k_viterbi_rows (qf_kernels.hip): one wavefront per unit, stripes of 64 lanes x 8 rows,
@@ -560,7 +672,15 @@ static void launch_ov_gb(const OvArgs& a, hipStream_t s) {
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
   switch (cls) {
-    case 0: hipLaunchKernelGGL(k_overlap_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a); break;
+    case 0: {
+      const size_t row_lds = 2ull * kSingleSub * a.Km * (kNQualDev + 1) * 8;   // order 0 / 1 emission rows fit, longer contexts do not
+      if (row_lds <= 64 * 1024 && !a.no_lds_rows) {
+        if (row_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_overlap_single_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+        hipLaunchKernelGGL(k_overlap_single_lds, dim3((a.n_cls_units + 255) / 256), dim3(256), row_lds, s, a);
+      } else
+        hipLaunchKernelGGL(k_overlap_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a);
+      break;
+    }
     case 1: launch_ov_gb<16, 2>(a, s); break;
     case 2: launch_ov_gb<16, 3>(a, s); break;
     case 3: launch_ov_gb<16, 4>(a, s); break;
