@@ -656,12 +656,13 @@ static int reserve_seed_workspace(Slot* c, SeedArgs& sa, bool mem, uint64_t n_pa
 
 // Ragged read lengths: a wavefront's bands run in lockstep for as long as the longest of them, so each class list is sorted
 // by read length (longest first) before the fills.
-static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_t max_units) {
-  if (!c->ragged_reads) return QF_OK;
+static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_t max_units, bool pair_order_cls0 = false) {
+  if (!c->ragged_reads && !pair_order_cls0) return QF_OK;
   HIPCHK(S, S->d_sort_k.reserve((size_t)max_units * 4));
   HIPCHK(S, S->d_sort_v.reserve((size_t)max_units * 4));
   for (int cls = 0; cls < kNumClasses; ++cls) {
     if (cls == kRowClass || bc.cls_count[cls] <= 64) continue;
+    if (!c->ragged_reads && cls != 0) continue;   // overlap: only the single-diagonal list, into pair order
     const int rc = sort_class_list(S->d_cls_key.as<uint32_t>() + (size_t)cls * max_units, S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units,
                                    bc.cls_count[cls], S->d_sort_k.as<uint32_t>(), S->d_sort_v.as<uint32_t>(), &S->sort_tmp, &S->sort_tmp_cap,
                                    S->stream);
@@ -1456,6 +1457,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         s.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
         s.storage_mode = 2;
         s.max_ref_len = s.max_read_len;   // the x side is a read too
+        s.cls_key = c->d_cls_key.as<uint32_t>();   // (the single-diagonal list is sorted back into pair order)
       }, max_units, sa, bc))
     return rc;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1471,7 +1473,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     return QF_OK;
   }
   HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
-  if (int rc = sort_class_lists(c, c, bc, max_units)) return rc;
+  if (int rc = sort_class_lists(c, c, bc, max_units, true)) return rc;
   HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));

@@ -951,7 +951,9 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
     return;
   }
   a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
-  if (a.cls_key) a.cls_key[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = (uint32_t)yLen;
+  // sort key of the class lists (descending): read length; the overlap path's single-diagonal list is put back into pair
+  // order instead, so that the bands of a workgroup share their x (k_overlap_single_lds)
+  if (a.cls_key) a.cls_key[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = (a.storage_mode == 2 && cls == 0) ? ~pair : (uint32_t)yLen;
   Unit u;
   u.pair = pair;
   u.dlo = dlo;

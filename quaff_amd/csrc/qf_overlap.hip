@@ -311,8 +311,10 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
 // takes a whole 128-byte line (32 columns) of its y context words at a time, and stores its traceback nibbles 16 bytes
 // at a time.  (The per-lane gathers of the plain kernel are bound by L1 line fills: one 128-byte line per 8-byte entry.)
 constexpr int kSingleSub = 4;
+template <bool GAPCTX>
 __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
+  typedef double D2 __attribute__((ext_vector_type(2)));
   extern __shared__ double s_rows[];   // [2][kSingleSub][KQ]
   __shared__ unsigned long long s_xb0;
   __shared__ int s_d0, s_xLen0, s_T;
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   const double* __restrict__ mmi = a.mmi[comp];
   const double* __restrict__ mmi0 = a.mmi[s_comp0];
   const double* __restrict__ gap = a.gap[comp];
+  const double gap0 = gap[0];
   const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
   const uint32_t* __restrict__ xc = a.ctx + xb;
   const uint32_t* __restrict__ xc0 = a.ctx + s_xb0;
@@ -350,54 +353,99 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   double M = QF_NEG_INF, colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
   uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0;
   const uint32_t srow = threadIdx.x >> 6, scol = threadIdx.x & 63;   // staging: one wavefront per row of the block
-  int buf = 0;
-  for (int j0 = 1; j0 <= T; j0 += 32) {
-    const int yi = min(j0 - 1, yLen);                       // both context arrays are padded by kCtxPad words
-    W4 yw[8];
+  // Software pipeline, one barrier per block: block g's rows are in registers (loaded during block g-1's arithmetic), go to
+  // LDS buffer g & 1, and the loads of block g+1's rows are issued before block g's arithmetic; the x context word that
+  // names a row is fetched two blocks ahead, the lane's line of y context words one line ahead.
+  constexpr int kRowRegs = 3;                                         // 16-byte chunks per lane per round: 64 x 3 x 2 = 384 >= 380 doubles
+  const uint32_t rowChunks = KQ / 2;                                  // (KQ = Km * 95 with Km a power of four: even)
+  const int rowRounds = (int)((rowChunks + 64 * kRowRegs - 1) / (64 * kRowRegs));   // 1 for order 0
+  auto lead_word = [&](int g) -> uint32_t {                           // context word of the first band's x at block g, row srow
+    return xc0[min(max(d0 + 4 * g + (int)srow, -kCtxPad + 8), xLen0)];  // base i = d0 + j, j = 1 + 4g + srow -> index i - 1
+  };
+  D2 R[kRowRegs];
+  auto load_rows = [&](uint32_t word, int round) {
+    const D2* __restrict__ src = (const D2*)(mmi0 + (size_t)(word & 0x7FFFu) * KQ);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) yw[q] = *(const W4*)(yc + yi + 4 * q);
+    for (int q = 0; q < kRowRegs; ++q) R[q] = src[min((uint32_t)(round * kRowRegs + q) * 64 + scol, rowChunks - 1)];
+  };
+  auto store_rows = [&](int b, int round) {
+    D2* dst = (D2*)(s_rows + ((size_t)b * kSingleSub + srow) * KQ);
+#pragma unroll
+    for (int q = 0; q < kRowRegs; ++q) {
+      const uint32_t ch = (uint32_t)(round * kRowRegs + q) * 64 + scol;
+      if (ch < rowChunks) dst[ch] = R[q];
+    }
+  };
+  const int nBlocks = (T + kSingleSub - 1) / kSingleSub;
+  uint32_t wordCur = lead_word(0), wordNext = lead_word(1);
+  if (rowRounds == 1) load_rows(wordCur, 0);
+  W4 yw[8], ywNext[8];
+  {
+    const int yi = min(0, yLen);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ywNext[q] = *(const W4*)(yc + yi + 4 * q);
+  }
+  for (int j0 = 1; j0 <= T; j0 += 32) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) yw[q] = ywNext[q];
+    {
+      const int yi = min(j0 + 31, yLen);                    // next line; both context arrays are padded by kCtxPad words
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ywNext[q] = *(const W4*)(yc + yi + 4 * q);
+    }
     uint32_t words[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int sub = 0; sub < 32 / kSingleSub; ++sub) {
       const int js = j0 + sub * kSingleSub;                 // first column of the block
-      if (js <= T) {                                        // (uniform over the workgroup)
-        {  // stage the block's rows of the first band's x: row srow = base d0 + js + srow
-          const int i0 = min(max(d0 + js + (int)srow - 1, -kCtxPad + 8), xLen0);
-          const double* __restrict__ src = mmi0 + (size_t)(xc0[i0] & 0x7FFFu) * KQ;
-          double* dst = s_rows + ((size_t)buf * kSingleSub + srow) * KQ;
-          for (uint32_t q = scol; q < KQ; q += 64) dst[q] = src[q];
+      const int g = (js - 1) / kSingleSub, buf = g & 1;
+      if (g < nBlocks) {                                    // (uniform over the workgroup)
+        if (rowRounds == 1) {
+          store_rows(buf, 0);
+        } else {                                            // long rows (order-1 contexts): not pipelined
+          for (int round = 0; round < rowRounds; ++round) { load_rows(wordCur, round); store_rows(buf, round); }
         }
         __syncthreads();
-        const int xi = min(max(d + js - 1, -kCtxPad + 8), xLen);
-        const W4 xa = *(const W4*)(xc + xi);
-        double e[kSingleSub];
+        wordCur = wordNext;
+        wordNext = lead_word(g + 2);
+        if (rowRounds == 1 && g + 1 < nBlocks) load_rows(wordCur, 0);
         uint32_t wyc[kSingleSub];
 #pragma unroll
-        for (int c = 0; c < kSingleSub; ++c) {
-          const int col = sub * kSingleSub + c;             // 0..31 within the line
-          wyc[c] = yw[col >> 2].v[col & 3];
-          const uint32_t ey = wyc[c] & 0x7FFFu;
-          e[c] = shared_row ? s_rows[((size_t)buf * kSingleSub + c) * KQ + ey] : mmi[(size_t)(xa.v[c] & 0x7FFFu) * KQ + ey];
-        }
-        uint32_t nib = 0;
+        for (int c = 0; c < kSingleSub; ++c) { const int col = sub * kSingleSub + c; wyc[c] = yw[col >> 2].v[col & 3]; }
+        const double* __restrict__ rows = s_rows + (size_t)buf * kSingleSub * KQ;
+        // interior block: every column of it is inside this lane's band and away from the matrix edges, and the lane shares
+        // the staged rows -> the recurrence is two additions per cell (no start, no end candidates, traceback nibble 0)
+        const bool interior = shared_row && js > 1 && d + js > 1 && js + kSingleSub - 1 < yLen && d + js + kSingleSub - 1 < xLen;
+        if (!GAPCTX && __all(interior)) {
 #pragma unroll
-        for (int c = 0; c < kSingleSub; ++c) {
-          const int j = js + c, i = d + j;
-          const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
-          const uint32_t gxP = i > 1 ? gxPrev : 0u, gyP = j > 1 ? gyPrev : 0u;  // xIndelKmer[i-1], yIndelKmer[j-1] (padded 0)
-          gxPrev = xa.v[c] >> 24; gyPrev = wyc[c] >> 24;
-          const double tM = (M + gap[gxP * Kg + gyP]) + e[c];
-          double nm = tM;
-          uint32_t sm = 0;
-          if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; sm = 3; }
-          if (!valid) nm = QF_NEG_INF;
-          M = nm;
-          nib |= sm << (4 * c);
-          if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
-          if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+          for (int c = 0; c < kSingleSub; ++c) M = (M + gap0) + rows[(size_t)c * KQ + (wyc[c] & 0x7FFFu)];
+        } else {
+          const int xi = min(max(d + js - 1, -kCtxPad + 8), xLen);
+          const W4 xa = *(const W4*)(xc + xi);
+          double e[kSingleSub];
+#pragma unroll
+          for (int c = 0; c < kSingleSub; ++c) {
+            const uint32_t ey = wyc[c] & 0x7FFFu;
+            e[c] = shared_row ? rows[(size_t)c * KQ + ey] : mmi[(size_t)(xa.v[c] & 0x7FFFu) * KQ + ey];
+          }
+          uint32_t nib = 0;
+#pragma unroll
+          for (int c = 0; c < kSingleSub; ++c) {
+            const int j = js + c, i = d + j;
+            const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
+            const uint32_t gxP = i > 1 ? gxPrev : 0u, gyP = j > 1 ? gyPrev : 0u;  // xIndelKmer[i-1], yIndelKmer[j-1] (padded 0)
+            gxPrev = xa.v[c] >> 24; gyPrev = wyc[c] >> 24;
+            const double tM = (M + (GAPCTX ? gap[gxP * Kg + gyP] : gap0)) + e[c];
+            double nm = tM;
+            uint32_t sm = 0;
+            if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; sm = 3; }
+            if (!valid) nm = QF_NEG_INF;
+            M = nm;
+            nib |= sm << (4 * c);
+            if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
+            if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+          }
+          words[sub >> 1] |= nib << (16 * (sub & 1));
         }
-        words[sub >> 1] |= nib << (16 * (sub & 1));
-        buf ^= 1;
       }
     }
     // traceback words of columns j0 .. j0+31 (one per 8 columns, as k_overlap_single writes them); the unit's storage is
@@ -675,8 +723,9 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
     case 0: {
       const size_t row_lds = 2ull * kSingleSub * a.Km * (kNQualDev + 1) * 8;   // order 0 / 1 emission rows fit, longer contexts do not
       if (row_lds <= 64 * 1024 && !a.no_lds_rows) {
-        if (row_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_overlap_single_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
-        hipLaunchKernelGGL(k_overlap_single_lds, dim3((a.n_cls_units + 255) / 256), dim3(256), row_lds, s, a);
+        auto fn = a.Kg > 1 ? k_overlap_single_lds<true> : k_overlap_single_lds<false>;
+        if (row_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+        hipLaunchKernelGGL(fn, dim3((a.n_cls_units + 255) / 256), dim3(256), row_lds, s, a);
       } else
         hipLaunchKernelGGL(k_overlap_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a);
       break;
