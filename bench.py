@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--workload", default="align", choices=["align", "train", "overlap", "fulldp"],
                     help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = scaled "
                          "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
-    ap.add_argument("--overlap-rows", type=int, default=0,
-                    help="overlap workload: only the first R rows of the pair triangle (this rank's block of rows when the "
-                         "50 k-read config 3 is sharded); 0 = all pairs")
+    ap.add_argument("--overlap-rows", type=int, default=-1,
+                    help="overlap workload: rows [rank*R, rank*R+R) of the pair triangle per step (a rank's block of rows when "
+                         "config 3 is sharded by rows); 0 = all pairs of the read set; default 34 (3.4 M pairs) for the "
+                         "50 k-read config, all pairs for small --reads")
     ap.add_argument("--overlap-threshold", type=float, default=0.0,
                     help="overlap workload: alignments scoring below it are not traced back (`quaff overlap` prints only "
                          "score >= 0 by default, -threshold; pass -inf for -nothreshold)")
@@ -155,7 +156,8 @@ def extra_workload(a, rank, world, local_rank):
         extra = {"forward_bytes": res["forward_bytes"], "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
     elif a.workload == "overlap":
         ctx.set_params_json(None)
-        n = a.reads if a.reads != 100000 else 1500
+        n = a.reads if a.reads != 100000 else 50000            # BASELINE config 3: 50 k reads x 2 kb, 100x coverage of a 1 Mb genome
+        rows_per_step = a.overlap_rows if a.overlap_rows >= 0 else (34 if n >= 10000 else 0)
         genome = api.synth_ref(3, max(a.ref_len, 20 * n))
         seq, qual, off = api.synth_reads(4 + rank, genome, n, 2000)
         # SeqList::loadSequences: originals followed by their reverse complements
@@ -164,8 +166,8 @@ def extra_workload(a, rank, world, local_rank):
         seqs += [api.revcomp(s) for s in seqs]
         quals += [q[::-1] for q in quals]
         ctx.upload_reads(seqs, quals)
-        if a.overlap_rows:                       # rows [rank*R, rank*R + R) of the triangle: what one rank of the sharded config 3 owns
-            rows = np.arange(rank * a.overlap_rows, min(n - 1, (rank + 1) * a.overlap_rows))
+        if rows_per_step:                        # rows [rank*R, rank*R + R) of the triangle: one block of what a rank of the sharded config 3 owns
+            rows = np.arange(rank * rows_per_step, min(n - 1, (rank + 1) * rows_per_step))
             xs = np.concatenate([np.full(2 * n - 1 - r, r) for r in rows])
             ys = np.concatenate([np.arange(r + 1, 2 * n) for r in rows])
             keep = np.ones(len(xs), bool)
@@ -188,7 +190,9 @@ def extra_workload(a, rank, world, local_rank):
                 ph[k] = ph.get(k, 0.0) + getattr(res, "ms_" + k)
         sync_all()
         dt = time.perf_counter() - t0
-        desc = "config 3 shape: quaff overlap, %d x 2 kb reads from a %d bp genome, all-vs-all both strands (%d pairs) per GPU" % (n, len(genome), len(pairs[0]))
+        desc = "config 3%s: quaff overlap, %d x 2 kb reads from a %d bp genome, both strands, %s (%d pairs per step per GPU)" % (
+            "" if n == 50000 else " shape", n, len(genome),
+            "%d rows of the all-vs-all pair triangle per step" % rows_per_step if rows_per_step else "all-vs-all", len(pairs[0]))
         metric = "DP cells/sec (overlap Viterbi)"
         extra = {"pairs": len(pairs[0]), "score_threshold": a.overlap_threshold, "alignments": int(res.n_alignments), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
     else:
