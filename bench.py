@@ -137,13 +137,13 @@ def extra_workload(a, rank, world, local_rank):
         cfg = Q.DPConfig(band_size=a.band)
         order = None
         for _ in range(a.warmup):
-            order = ctx.count_resident(cfg)["sort_order"]      # later EM iterations run on the pruned reference order
+            order = ctx.count_resident(cfg, packed_order=True)["sort_order"]   # later EM iterations run on the pruned reference order
         sync_all()
         t0 = time.perf_counter()
         cells = 0
         ph = {}
         for _ in range(a.steps):
-            res = ctx.count_resident(cfg, sort_order=order)
+            res = ctx.count_resident(cfg, sort_order=order, packed_order=True)
             if world > 1:
                 dist.estep_allreduce(res["counts"], res["loglike"])   # the E-step's only exchange (RCCL all-reduce)
             cells += res["total_cells"] + res["backward_cells"]

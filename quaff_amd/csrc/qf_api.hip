@@ -1227,7 +1227,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
         f2.n_cls_units = bc.cls_count[cls];
         f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
         launch_forward_fill(cls, f2, s);
-      }))
+      }, 0))
     return rc;
   FinalArgs fin{};
   fin.n_pairs = n_pairs;
@@ -1265,7 +1265,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
         f2.n_cls_units = bc.cls_count[cls];
         f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
         launch_backward_fill(cls, f2, s);
-      }))
+      }, 0))
     return rc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));

@@ -165,6 +165,62 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
   if (active && l == 0) a.units[uid].end_val = endv;
 }
 
+// Single-diagonal bands (diagonal 0 is in every envelope, so nearly every true pair carries one beside its seeded band):
+// the gap states of a lone diagonal stay -inf and the match state is a serial chain, so one lane takes a band instead of
+// a 16 x 2 wavefront group with 31 of its 32 slots idle.  The values go where slot 0 of lane 0 of the (16,2) layout keeps
+// them (k_backward_fill<16,2> reads only the band's own diagonal), same arithmetic as k_forward_fill.
+__global__ __launch_bounds__(256) void k_forward_single(FbArgs a) {
+  __shared__ double s_lseh[2 * kLseNodes];
+  lseh_load(s_lseh, a.lse_h, threadIdx.x, 256);
+  __syncthreads();
+  const double* hs = s_lseh;
+  constexpr int G = 16, B = 2;
+  const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = uidx < a.n_cls_units;
+  uint32_t uid = 0;
+  int d = 0, xLen = 0, yLen = 0;
+  uint64_t xb = 0, yb = 0, fw_off = 0;
+  if (active) {
+    uid = a.cls_list[uidx];
+    const Unit u = a.units[uid];
+    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb);
+    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
+    d = u.dlo; fw_off = u.tb_off;
+  }
+  int T = active ? yLen : 0;
+  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
+  const double* __restrict__ ematch = a.dp.ematch;
+  const double* __restrict__ trans = a.dp.trans;
+  const uint32_t Kg = a.dp.Kg;
+  const bool local = a.dp.local != 0;
+  const uint8_t* __restrict__ xt = a.ref_tok + xb;
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  double* __restrict__ fw = a.fw + fw_off;
+  double M = QF_NEG_INF, endTerm = QF_NEG_INF;
+  uint32_t gkPrev = 0;
+  for (int j = 1; j <= T; ++j) {
+    const int i = d + j;
+    const bool colvalid = active && j <= yLen, valid = colvalid && i >= 1 && i <= xLen;
+    const uint32_t w = ctx[min(j - 1, yLen + 4)];
+    const uint32_t erow4 = (w & 0x7FFFu) * 4u, gk = w >> 24;
+    const uint32_t gp = j > 1 ? gkPrev : 0u;  // yIndelKmer is padded with a leading 0 (qmodel.cpp:1322)
+    gkPrev = gk;
+    const uint32_t tok = valid ? (uint32_t)xt[i - 1] : 0u;
+    double nm = lseh(hs, lseh(hs, M + trans[gp], QF_NEG_INF), QF_NEG_INF);
+    if (j == 1 && (i == 1 || local)) nm = lseh(hs, nm, 0.0);
+    nm += ematch[erow4 + tok];
+    if (!valid) nm = QF_NEG_INF;
+    M = nm;
+    if (colvalid) {
+      const uint64_t base = (uint64_t)(j - 1) * B * 3 * G;   // step t = j - 1 of lane 0, slot 0
+      fw[base] = nm; fw[base + G] = QF_NEG_INF; fw[base + 2 * G] = QF_NEG_INF;
+    }
+    if (j == yLen && valid && (local || i == xLen)) endTerm = nm + trans[3 * Kg + gk];
+  }
+  if (active) a.units[uid].end_val = endTerm > QF_NEG_INF ? lseh(hs, QF_NEG_INF, endTerm) : QF_NEG_INF;
+}
+
 // Forward result of a pair = lse over its bands (the reference accumulates `end` over all envelope cells of
 // the last column, src/qmodel.cpp:1379-1381).
 __global__ void k_pair_forward(FinalArgs a, const double* __restrict__ tab) {
@@ -267,6 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
     Fres = a.pair_fwd[u.pair];
     wgt = a.pair_weight[u.pair];
     if (!(wgt > 0.0) || !(Fres > QF_NEG_INF)) active = false;  // pruned pair: no Backward (qmodel.cpp:2252)
+    // Bands are disconnected from one another (a missing diagonal cannot be crossed), so every expected count of this
+    // band is at most exp(band's Forward end - pair's Forward) x weight; count_exp flushes to zero below ~-87: such a
+    // band (typically the lone diagonal 0 beside the seeded band) contributes exactly nothing.
+    if (u.end_val - Fres < -110.0) active = false;
   }
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
@@ -789,11 +849,13 @@ static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   }
 void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
+  if (cls == 0) { hipLaunchKernelGGL(k_forward_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a); return; }
   if (cls == kRowClass) { hipLaunchKernelGGL(k_forward_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); return; }
   QF_FB_DISPATCH(launch_fwd_gb)
 }
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
+  if (cls == 0) { launch_bwd_gb<16, 2>(a, s); return; }   // single diagonals keep the (16,2) Forward layout
   if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), (size_t)3 * a.dp.Kg * 8, s, a); return; }
   QF_FB_DISPATCH(launch_bwd_gb)
 }

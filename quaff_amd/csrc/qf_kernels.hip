@@ -910,7 +910,6 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);
       } else {
         act = true;
-        if (a.storage_mode == 1) cls = fb_class(cls);
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
         tbw = a.storage_mode == 2 ? (cls == 0 ? (unsigned long long)(yLen + 7) / 8

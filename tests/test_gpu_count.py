@@ -148,6 +148,12 @@ def test_count_internal_chunking(ctx):
         assert w["sort_order"] == p["sort_order"] and w["loglike"] == p["loglike"]
         assert w["total_cells"] == p["total_cells"] and w["forward_bytes"] == p["forward_bytes"]
         np.testing.assert_allclose(p["counts"], w["counts"], rtol=1e-9, atol=1e-12)
+    # the packed form of the per-read reference order (arrays instead of per-read lists) means the same thing
+    packed = ctx.count_resident(Q.DPConfig(), packed_order=True)["sort_order"]
+    assert [list(map(int, packed[0][r, :packed[1][r]])) for r in range(len(reads))] == whole["sort_order"]
+    whole3 = ctx.count_resident(Q.DPConfig(), sort_order=packed, packed_order=True)
+    assert np.array_equal(whole3["forward"], whole2["forward"]) and whole3["loglike"] == whole2["loglike"]
+    assert [list(map(int, whole3["sort_order"][0][r, :whole3["sort_order"][1][r]])) for r in range(len(reads))] == whole2["sort_order"]
 
 
 def test_count_wide_bands_row_space(ctx):
