@@ -312,6 +312,13 @@ def main():
         iso = BYTES_PER_CELL * cls_cells[dom] / (iso_ms * 1e-3) / 1e9
         roofline["concurrent_classes"] = sorted(ctx.L.qf_fill_class_name(k).decode() for k in cls_ms if k != dom)
         roofline["isolated"] = {"ms_per_launch": round(iso_ms, 4), "achieved": round(iso, 1), "frac": round(iso / HBM_PEAK_GBS, 4)}
+    # What actually bounds the kernel (informational; the contract's roofline above stays the HBM one): fp64 vector issue.
+    # 161 VALU instructions per wavefront step of 5 cells per lane in the fast-path loop (tools/kernel_asm.sh) = 32.2 lane
+    # operations per cell; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (the chip runs ~2.1 GHz under this load).
+    if dom_name == "k_viterbi_fill<16,5>":
+        ops = 32.2 * cls_cells[dom] / ((roofline.get("isolated", roofline)["ms_per_launch"]) * 1e-3) / 1e12
+        roofline["valu_issue"] = {"lane_ops_per_cell": 32.2, "achieved": round(ops, 2), "peak": 39.3, "unit": "T lane-ops/s",
+                                  "frac": round(ops / 39.3, 3), "of": "isolated" if "isolated" in roofline else "in-region"}
 
     cpu = None
     if a.cpu_sample > 0:
