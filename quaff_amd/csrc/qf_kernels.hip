@@ -1554,6 +1554,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   if (EMLDS) {
     for (uint32_t q = threadIdx.x; q < n_em; q += G) lds_tab[q] = a.dp.ematch[q];
     for (uint32_t q = threadIdx.x; q < kInsRows; q += G) lds_tab[n_em + q] = a.dp.eins[q];
+    for (uint32_t q = threadIdx.x; q < 4 * a.dp.Kg; q += G) lds_tab[n_em + kInsRows + q] = a.dp.trans[q];
     __syncthreads();
   }
   constexpr int K = kVitLag, R = 2 * K + 4;
@@ -1594,7 +1595,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
   const double* __restrict__ ematch = EMLDS ? lds_tab : a.dp.ematch;
   const double* __restrict__ eins = EMLDS ? lds_tab + n_em : a.dp.eins;
-  const double* __restrict__ trans = a.dp.trans;
+  const double* __restrict__ trans = EMLDS ? lds_tab + n_em + kInsRows : a.dp.trans;   // (a step's first cell waits on these)
   const uint32_t Kg = a.dp.Kg;
   const bool local = a.dp.local != 0;
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
@@ -1602,6 +1603,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   double bestEnd = QF_NEG_INF;
   uint32_t bestI = 0;
   unsigned long long woff = 0;
+  auto ctxword = [&](int j) -> uint32_t { return ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)]; };   // word of column j
 
   for (int s = 0; s < g.nStripes; ++s) {
     int jlo, jhi;
@@ -1624,18 +1626,23 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
     double p2M = QF_NEG_INF, p2I = QF_NEG_INF, p2D = QF_NEG_INF;   // last row, column of two steps ago
     double p1I = QF_NEG_INF;
     const int steps = jhi - jlo + 1 + kVitSkewMax;
+    // the column's context word is fetched a step ahead (two wavefronts per SIMD do not hide a load per step), and the
+    // previous column's word is simply the previous step's
+    uint32_t wPrev = ctxword(jlo - skew - 1), wCur = ctxword(jlo - skew);
     for (int t = 0; t < steps; ++t) {
       const int j = jlo + t - skew;
       const bool colvalid = j >= jlo && j <= jhi;
-      const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+      const uint32_t w = wCur;
+      const uint32_t wNext = ctxword(j + 1);
       const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
-      const uint32_t gp = j > 1 ? (ctx[min(max(j - 2, -kCtxPad + 1), yLen + 4)] >> 24) : 0u;  // yIndelKmer[j-1]; padded 0 for j == 1
+      const uint32_t gp = j > 1 ? (wPrev >> 24) : 0u;  // yIndelKmer[j-1]; padded 0 for j == 1
+      wPrev = w; wCur = wNext;
       const double m2m = trans[gp], m2i = trans[Kg + gp], m2d = trans[2 * Kg + gk];
       const double insE = eins[insrow];
       // row above slot 0: lane L-1's last row (column j one step ago, column j-1 two steps ago): by shuffle inside the
       // wavefront, from the previous wavefront's ring, or (lane 0 of the stripe) from the boundary buffer
-      double upM = __shfl_up(p1M, 1, 64), upD = __shfl_up(p1D, 1, 64);
-      double dgM = __shfl_up(p2M, 1, 64), dgI = __shfl_up(p2I, 1, 64), dgD = __shfl_up(p2D, 1, 64);
+      double upM = dpp_from_below<64, false>(p1M), upD = dpp_from_below<64, false>(p1D);   // DPP wave shift, not ds_bpermute
+      double dgM = dpp_from_below<64, false>(p2M), dgI = dpp_from_below<64, false>(p2I), dgD = dpp_from_below<64, false>(p2D);
       if (l == 0) {
         if (wv == 0) {
           const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
@@ -2032,7 +2039,7 @@ void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s)
     case 11: launch_fill_gb<64, 12>(a, gapctx, s); break;
     case 12: launch_fill_gb<64, 16>(a, gapctx, s); break;
     case 13: {
-      const uint32_t lds_bytes = a.dp.ematch_ninf_off + 32 + kInsRows * 8;
+      const uint32_t lds_bytes = a.dp.ematch_ninf_off + 32 + kInsRows * 8 + 4 * a.dp.Kg * 8;
       if (lds_bytes <= 52 * 1024 && !a.no_lds_tables) hipLaunchKernelGGL(k_viterbi_rows<true>, dim3(a.n_cls_units), dim3(kVitLanes), lds_bytes, s, a);
       else hipLaunchKernelGGL(k_viterbi_rows<false>, dim3(a.n_cls_units), dim3(kVitLanes), 0, s, a);
       break;
