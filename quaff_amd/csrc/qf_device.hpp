@@ -58,7 +58,7 @@ __host__ __device__ inline int classify_width(int W) {
 // columns [jlo, jhi] that its rows' band segments cover.  Forward/Backward and overlap run one wavefront per unit
 // (S = kRowStripe = 64 lanes x 8 rows); Viterbi runs a workgroup of kVitWaves wavefronts (S = kVitStripe).
 constexpr int kRowStripe = 64 * 8;
-constexpr int kVitWaves = 8;
+constexpr int kVitWaves = 4;
 constexpr int kVitLanes = kVitWaves * 64;
 constexpr int kVitStripe = kVitLanes * 8;
 constexpr int kVitLag = 8;        // extra column lag per wavefront: neighbouring wavefronts synchronise every kVitLag steps

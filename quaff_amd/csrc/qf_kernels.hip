@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Row-space Viterbi fill for bands wider than 1024 diagonals (-kmatchoff, or the full-envelope fallback of short
 // sequences against long references).  One workgroup of kVitWaves wavefronts per unit; the band's rows are cut into stripes
-// of 512 lanes x 8 rows.  Lane L (0..511) owns 8 consecutive rows and at step t is at column jlo + t - vit_skew(L), so
+// of kVitLanes lanes x 8 rows.  Lane L owns 8 consecutive rows and at step t is at column jlo + t - vit_skew(L), so
 //   ins(i,j) <- (i,  j-1): own registers (previous step)
 //   del(i,j) <- (i-1,j  ): own slot b-1 this step, or lane L-1's last row, which it finished one step ago
 //   mat(i,j) <- (i-1,j-1): own slot b-1 before this step's update, or lane L-1's last row two steps ago
