@@ -72,7 +72,8 @@ typedef struct qf_dp_config {
   int32_t reserved;        /* debug: bit 0 = workgroup-per-pair seeding kernel, bit 1 = first-generation fill kernel,
                             * bit 2 = run the fill classes one after another on one stream, bit 3 = emission
                             * tables stay in global memory, bit 4 = reference k-mer index stays in global memory,
-                            * bit 5 = overlap single-diagonal bands gather emissions from global memory; keep 0 */
+                            * bit 5 = overlap single-diagonal bands gather emissions from global memory,
+                            * bit 6 = E-step without the single-diagonal Forward kernel / negligible-band skip; keep 0 */
   uint64_t max_size;       /* memory mode: effectiveMaxSize() in bytes (-kmatchmb M => M<<20) */
 } qf_dp_config;
 

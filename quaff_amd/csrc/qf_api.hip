@@ -1221,6 +1221,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.counts = c->d_counts.as<double>();
   fa.counts_stride = (csize + 31) & ~31ull;
   fa.Km = sc.Km;
+  fa.no_band_shortcuts = (cfg->reserved >> 6) & 1;
   const bool serial_classes = (cfg->reserved & 4) != 0;
   if (int rc = launch_classes_concurrently(c, bc, serial_classes, [&](int cls, hipStream_t s) {
         FbArgs f2 = fa;
@@ -1560,6 +1561,58 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   return QF_OK;
 }
 
+// The resident sequences' derived arrays for the overlap path: tokens / context words / null log-likelihoods (prep_reads), the
+// k-mer index over the sequences themselves (every one of them can be an x), the reverse-strand context words, insert-score
+// sums and reverse-strand null log-likelihoods.  Kept across the blocks of a pair list (qf_ctx::ov_prep_epoch).
+static int prep_overlap_reads(qf_ctx* c, const qf_dp_config* cfg, int prep_k) {
+  const bool sparse = cfg->sparse != 0;
+  const uint32_t n_seqs = c->n_reads;
+  const Scores& sc = c->scores;
+  if (int rc = prep_reads(c, prep_k)) return rc;
+  if (sparse && c->read_index_k != cfg->kmer_len && cfg->kmer_len > kMaxRefK) {
+    if (int rc = build_sorted_index(c, c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), c->read_off, c->read_maxlen, cfg->kmer_len,
+                                    c->d_roff32, c->d_rskeys, c->d_rpos))
+      return rc;
+    c->read_index_k = cfg->kmer_len;
+  }
+  if (sparse && c->read_index_k != cfg->kmer_len) {  // needs the token bytes prep_reads just wrote
+    launch_ref_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len,
+                     1u << (2 * cfg->kmer_len), c->d_rbucket.as<uint32_t>(), c->d_rcursor.as<uint32_t>(),
+                     c->d_rpos.as<uint32_t>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    c->read_index_k = cfg->kmer_len;
+  }
+  HIPCHK(c, c->d_ctxc.reserve((c->read_total + 2 * kCtxPad) * 4));
+  HIPCHK(c, c->d_ins_sum.reserve((size_t)n_seqs * 8));
+  HIPCHK(c, c->d_ins_sum_c.reserve((size_t)n_seqs * 8));
+  HIPCHK(c, c->d_nll_c.reserve((size_t)n_seqs * 8));
+  HIPCHK(c, hipMemsetAsync(c->d_ctxc.p, 0, (c->read_total + 2 * kCtxPad) * 4, c->stream));
+  {
+    PrepArgs pa{};
+    pa.seq = c->d_seq.as<char>();
+    pa.qual = c->reads_have_qual ? c->d_qual.as<char>() : nullptr;
+    pa.off = c->d_roff.as<uint64_t>();
+    pa.match_len = sc.match_len;
+    pa.gap_len = sc.gap_len;
+    pa.tok = c->d_tok.as<uint8_t>();
+    pa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+    pa.ctxc = c->d_ctxc.as<uint32_t>() + kCtxPad;
+    pa.eins = c->d_eins.as<double>();
+    pa.ins_sum = c->d_ins_sum.as<double>();
+    pa.ins_sum_c = c->d_ins_sum_c.as<double>();
+    pa.nll_c = c->d_nll_c.as<double>();
+    pa.has_null = c->have_null;
+    if (c->have_null) {
+      std::vector<double> lq(4 * kNQual);
+      c->null.tables(pa.null_logEmit, pa.null_log1mEmit, pa.null_logSym, lq.data());
+      pa.null_logQual = c->d_nullq.as<double>();
+    }
+    launch_prep_overlap(pa, n_seqs, c->stream);
+    HIPCHK(c, hipGetLastError());
+  }
+  return QF_OK;
+}
+
 int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair_x, const uint32_t* pair_y,
                         const uint8_t* y_comp, uint32_t n_pairs, qf_overlap_result* out) {
   if (!c) return QF_ERR_ARG;
@@ -1610,50 +1663,8 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
   const int prep_k = sparse ? cfg->kmer_len : 0;
   const bool prepped = c->ov_prep_epoch == c->prep_epoch && c->ov_prep_k == prep_k;   // a later block of the same pair list
-  if (!prepped) {
-  if (int rc = prep_reads(c, prep_k)) return rc;
-  if (sparse && c->read_index_k != cfg->kmer_len && cfg->kmer_len > kMaxRefK) {
-    if (int rc = build_sorted_index(c, c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), c->read_off, c->read_maxlen, cfg->kmer_len,
-                                    c->d_roff32, c->d_rskeys, c->d_rpos))
-      return rc;
-    c->read_index_k = cfg->kmer_len;
-  }
-  if (sparse && c->read_index_k != cfg->kmer_len) {  // needs the token bytes prep_reads just wrote
-    launch_ref_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len,
-                     1u << (2 * cfg->kmer_len), c->d_rbucket.as<uint32_t>(), c->d_rcursor.as<uint32_t>(),
-                     c->d_rpos.as<uint32_t>(), c->stream);
-    HIPCHK(c, hipGetLastError());
-    c->read_index_k = cfg->kmer_len;
-  }
-  HIPCHK(c, c->d_ctxc.reserve((c->read_total + 2 * kCtxPad) * 4));
-  HIPCHK(c, c->d_ins_sum.reserve((size_t)n_seqs * 8));
-  HIPCHK(c, c->d_ins_sum_c.reserve((size_t)n_seqs * 8));
-  HIPCHK(c, c->d_nll_c.reserve((size_t)n_seqs * 8));
-  HIPCHK(c, hipMemsetAsync(c->d_ctxc.p, 0, (c->read_total + 2 * kCtxPad) * 4, c->stream));
-  {
-    PrepArgs pa{};
-    pa.seq = c->d_seq.as<char>();
-    pa.qual = c->reads_have_qual ? c->d_qual.as<char>() : nullptr;
-    pa.off = c->d_roff.as<uint64_t>();
-    pa.match_len = sc.match_len;
-    pa.gap_len = sc.gap_len;
-    pa.tok = c->d_tok.as<uint8_t>();
-    pa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
-    pa.ctxc = c->d_ctxc.as<uint32_t>() + kCtxPad;
-    pa.eins = c->d_eins.as<double>();
-    pa.ins_sum = c->d_ins_sum.as<double>();
-    pa.ins_sum_c = c->d_ins_sum_c.as<double>();
-    pa.nll_c = c->d_nll_c.as<double>();
-    pa.has_null = c->have_null;
-    if (c->have_null) {
-      std::vector<double> lq(4 * kNQual);
-      c->null.tables(pa.null_logEmit, pa.null_log1mEmit, pa.null_logSym, lq.data());
-      pa.null_logQual = c->d_nullq.as<double>();
-    }
-    launch_prep_overlap(pa, n_seqs, c->stream);
-    HIPCHK(c, hipGetLastError());
-  }
-  }
+  if (!prepped)
+    if (int rc = prep_overlap_reads(c, cfg, prep_k)) return rc;
   HIPCHK(c, c->d_px.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_py.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_pc.reserve((size_t)n_pairs));

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
     // Bands are disconnected from one another (a missing diagonal cannot be crossed), so every expected count of this
     // band is at most exp(band's Forward end - pair's Forward) x weight; count_exp flushes to zero below ~-87: such a
     // band (typically the lone diagonal 0 beside the seeded band) contributes exactly nothing.
-    if (u.end_val - Fres < -110.0) active = false;
+    if (!a.no_band_shortcuts && u.end_val - Fres < -110.0) active = false;
   }
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
@@ -849,6 +849,7 @@ static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   }
 void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
+  if (cls == 0 && a.no_band_shortcuts) { launch_fwd_gb<16, 2>(a, s); return; }
   if (cls == 0) { hipLaunchKernelGGL(k_forward_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a); return; }
   if (cls == kRowClass) { hipLaunchKernelGGL(k_forward_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); return; }
   QF_FB_DISPATCH(launch_fwd_gb)

@@ -105,6 +105,7 @@ struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
   const double* pair_fwd;      // [n_pairs] Forward result (Backward only)
   const double* pair_weight;   // [n_pairs] posterior weight, 0 = no Backward
   double* counts;              // flattened weighted QuaffCounts accumulators, kCountReplicas copies `counts_stride` apart
+  int no_band_shortcuts;   // A/B: lone diagonals through the (16,2) Forward kernel, Backward skips no band
   uint64_t counts_stride;
   uint32_t Km;
 };

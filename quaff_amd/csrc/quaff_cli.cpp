@@ -759,33 +759,48 @@ static int cmdOverlap(Opts& o) {
   for (qf_ctx* c : s.ctxs) QF(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
   // pair order of QuaffOverlapScheduler, src/qoverlap.cpp:475-480,528-547; every device holds all reads, consecutive
   // blocks of the pair list go to the devices in turn and are printed in list order
-  struct Block { vector<uint32_t> px, py; vector<uint8_t> pc; };
+  // A block is a run of the pair list, kept as (x, first y, last y + 1) segments; the device's host thread expands it into
+  // the index arrays, so the enumeration of 10^9 pairs is neither serial nor interleaved with the device calls.
+  struct Seg { uint32_t x, y0, y1; };
+  struct Block { vector<Seg> segs; size_t n = 0; };
   const size_t N = reads.nOriginals, total = reads.seqs.size(), G = s.devices();
-  size_t chunk = 1 << 21;   // pairs per device call (each call re-derives the reads' context arrays)
+  size_t chunk = 1 << 21;   // pairs per device call
   if (const char* e = getenv("QUAFF_HIP_OVERLAP_CHUNK")) chunk = max<size_t>(1, (size_t)atol(e));   // tests: many small blocks
   vector<Block> pend(1);
   auto flush = [&]() {
-    if (pend.back().px.empty()) pend.pop_back();
+    if (pend.back().n == 0) pend.pop_back();
     if (pend.empty()) { pend.emplace_back(); return; }
     vector<vector<Alignment>> got(pend.size());
     onDevices(pend.size(), [&](size_t k) {
       const Block& b = pend[k];
+      vector<uint32_t> px(b.n), py(b.n);
+      vector<uint8_t> pc(b.n);
+      size_t at = 0;
+      for (const Seg& g : b.segs) {
+        const size_t m = g.y1 - g.y0;
+        std::fill(px.begin() + at, px.begin() + at + m, g.x);
+        for (size_t q = 0; q < m; ++q) { py[at + q] = g.y0 + (uint32_t)q; pc[at + q] = g.y0 + q >= N; }
+        at += m;
+      }
       qf_ctx* c = s.ctxs[k];
       qf_overlap_result res;
-      QFT(c, qf_overlap_resident(c, &o.cfg, b.px.data(), b.py.data(), b.pc.data(), (uint32_t)b.px.size(), &res));
+      QFT(c, qf_overlap_resident(c, &o.cfg, px.data(), py.data(), pc.data(), (uint32_t)b.n, &res));
       for (uint32_t a = 0; a < res.n_alignments; ++a) {
         const qf_overlap_alignment& al = res.alignments[a];
-        got[k].push_back(makeOverlapAlignment(reads.seqs[b.px[al.pair]], reads.seqs[b.py[al.pair]], al, res.state_runs + al.run_offset));
+        got[k].push_back(makeOverlapAlignment(reads.seqs[px[al.pair]], reads.seqs[py[al.pair]], al, res.state_runs + al.run_offset));
       }
     });
     for (const auto& block : got) for (const Alignment& a : block) pr.write(cout, a);
     pend.assign(1, Block());
   };
   for (size_t nx = 0; nx + 1 < N; ++nx)
-    for (size_t ny = nx + 1; ny < total; ++ny) {
+    for (size_t ny = nx + 1; ny < total;) {   // the row's pairs, cut where a block fills up
       Block& b = pend.back();
-      b.px.push_back((uint32_t)nx); b.py.push_back((uint32_t)ny); b.pc.push_back(ny >= N);
-      if (b.px.size() >= chunk) { if (pend.size() == G) flush(); else pend.emplace_back(); }
+      const size_t take = min(total - ny, chunk - b.n);
+      b.segs.push_back({(uint32_t)nx, (uint32_t)ny, (uint32_t)(ny + take)});
+      b.n += take;
+      ny += take;
+      if (b.n >= chunk) { if (pend.size() == G) flush(); else pend.emplace_back(); }
     }
   flush();
   return EXIT_SUCCESS;
