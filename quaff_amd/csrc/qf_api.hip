@@ -1237,6 +1237,13 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fin.units = c->d_units.as<Unit>();
   fin.pair_head = c->d_pair_head.as<uint32_t>();
   fin.pair_score = c->d_pair_score.as<double>();
+  fin.read_off = d_roff;
+  fin.ref_off = c->d_ref_off.as<uint64_t>();
+  fin.fw = c->d_fw.as<double>();
+  fin.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
+  fin.trans = fa.dp.trans;
+  fin.Kg = fa.dp.Kg;
+  fin.local = fa.dp.local;
   launch_pair_forward(fin, c->d_lse.as<double>(), c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -221,11 +221,18 @@ __global__ __launch_bounds__(256) void k_forward_single(FbArgs a) {
   if (active) a.units[uid].end_val = endTerm > QF_NEG_INF ? lseh(hs, QF_NEG_INF, endTerm) : QF_NEG_INF;
 }
 
-// Forward result of a pair = lse over its bands (the reference accumulates `end` over all envelope cells of
-// the last column, src/qmodel.cpp:1379-1381).
+// Forward result of a pair: the reference keeps ONE running sum, `end = lse(end, mat(i,yLen) + m2e)`, down the whole last read
+// column in ascending row order (src/qmodel.cpp:1379-1381).  The table log-sum-exp drops a term more than 10 below the
+// running total, so summing band by band and combining the bands afterwards is a different number (by up to ~1e-4 when a
+// pair has dozens of bands).  One thread per pair therefore walks the bands in ascending diagonal order and the cells of
+// each band's last column in ascending row order, taking mat(i,yLen) from the Forward matrices, with the exact table.
+// (Row-space bands are whole envelopes - one band per pair - and contribute their own end sum.)
 __global__ void k_pair_forward(FinalArgs a, const double* __restrict__ tab) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.n_pairs) return;
+  const uint32_t r = p / a.n_refs, x = p % a.n_refs;
+  const int xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]), yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
+  const double m2e = yLen > 0 ? a.trans[3 * a.Kg + (a.ctx[a.read_off[r] + (uint64_t)(yLen - 1)] >> 24)] : QF_NEG_INF;
   double v = QF_NEG_INF;
   int last = -2147483647 - 1;
   while (true) {  // bands in ascending diagonal (= ascending row) order, like the reference's row loop
@@ -237,8 +244,21 @@ __global__ void k_pair_forward(FinalArgs a, const double* __restrict__ tab) {
     }
     if (pick == kNoUnit) break;
     last = best;
-    const double ev = a.units[pick].end_val;
-    if (ev > QF_NEG_INF) v = lse2(tab, v, ev);
+    const Unit u = a.units[pick];
+    if (u.cls == (uint32_t)kRowClass) {
+      if (u.end_val > QF_NEG_INF) v = lse2(tab, v, u.end_val);
+      continue;
+    }
+    const FillClass fc = fill_class(fb_class((int)u.cls));
+    const double* __restrict__ fw = a.fw + u.tb_off;
+    for (int d = u.dlo; d <= u.dhi; ++d) {
+      const int i = d + yLen;
+      if (i < 1 || i > xLen || !(a.local || i == xLen)) continue;
+      const int l = (d - u.dlo) / fc.B, b = (d - u.dlo) % fc.B;
+      const double m = fw[((uint64_t)(yLen - 1 + l) * fc.B + b) * 3 * fc.G + l];   // mat(i, yLen): step yLen-1+l of lane l, slot b
+      const double term = m + m2e;
+      if (term > QF_NEG_INF) v = lse2(tab, v, term);
+    }
   }
   a.pair_score[p] = v;
 }

@@ -196,6 +196,12 @@ struct FinalArgs {
   uint32_t* runs_tmp;
   uint32_t* runs_out;
   BatchCounters* bc;
+  // k_pair_forward: the Forward matrices and what it takes to form the end terms of a band's last column
+  const double* fw;
+  const uint32_t* ctx;
+  const double* trans;
+  uint32_t Kg;
+  int local;
 };
 
 void launch_prep_ref(const char* seq, uint64_t total, uint8_t* tok, BatchCounters* bc, hipStream_t s);

@@ -28,9 +28,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
     try:
         if seed % 2 == 0:
-            # (k >= 5 as the reference's -kmatch requires: with k = 4 and a threshold of 4 a pair has dozens of bands, and the
-            # band-by-band association of Forward's end sum reached 1.1e-4 on two counts of seed 250 - DESIGN.md section 7)
-            kw = dict(kmer_len=max(5, int(rng.integers(4, 8))), kmer_threshold=int(rng.integers(3, 25)), band_size=int(rng.integers(6, 100)),
+            # (seed 250 - k = 4, threshold 4, dozens of bands per pair - found that Forward's end sum must be one running sum
+            # across the bands, as in the reference: DESIGN.md section 4, Forward-Backward)
+            kw = dict(kmer_len=int(rng.integers(4, 8)), kmer_threshold=int(rng.integers(3, 25)), band_size=int(rng.integers(6, 100)),
                       local=bool(rng.random() < 0.8))
             if rng.random() < 0.1: kw = dict(sparse=False)
             run_case(c, both_strands(ref), reads, sc, null, cfg_kw=kw, force=bool(rng.random() < 0.3))
