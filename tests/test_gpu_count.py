@@ -180,3 +180,31 @@ def test_count_global_mode_no_paths(ctx):
     reads = make_reads(rng, ref, 5, 200)
     res, _ = run_case(ctx, both_strands(ref), reads, sc, null, cfg_kw=dict(local=False), force=True)
     assert np.isneginf(res["loglike"]) and all(o == [1, 0] for o in res["sort_order"])
+
+
+def test_count_many_bands_one_running_end_sum(ctx):
+    """Dozens of bands per pair (4-mers, threshold 4): the reference's Forward `end` is one running table-lse sum down the whole
+    last column (src/qmodel.cpp:1379-1381), and the table drops terms more than 10 below the running total, so a band-by-band
+    sum combined afterwards differed by 1.1e-4 on two counts of this case (soak seed 250)."""
+    from tests.helpers import mutate
+    rng = np.random.default_rng(5250)
+    order = int(rng.integers(0, 3))
+    pj = synth_params_json(rng, order + 1, order)
+    ctx.set_params_json(pj)
+    try:
+        sc, null = O.Scores(O.Params.from_json(pj)), O.NullParams.from_json(NULL_JSON)
+        ref = rand_seq(rng, int(rng.integers(600, 3000)))
+        n = int(rng.integers(2, 70))
+        reads = []
+        for k in range(n):
+            L = int(rng.integers(25, min(700, len(ref) - 10)))
+            s0 = int(rng.integers(0, len(ref) - L)); src = ref[s0:s0 + L]
+            if rng.random() < 0.5:
+                src = O.revcomp_str(src)
+            seq = mutate(rng, src, sub=rng.uniform(0, .08), ins=rng.uniform(0, .05), dele=rng.uniform(0, .05)) or "A"
+            reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+        res, want = run_case(ctx, both_strands(ref), reads, sc, null, cfg_kw=dict(kmer_len=4, kmer_threshold=4, band_size=42))
+        scale = max(1.0, np.abs(want).max())
+        assert (np.abs(res["counts"] - want) / np.maximum(np.abs(want), 1e-3 * scale)).max() < 5e-5
+    finally:
+        ctx.set_params_json(None)
