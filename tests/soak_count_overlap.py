@@ -33,11 +33,38 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             kw = dict(kmer_len=int(rng.integers(4, 8)), kmer_threshold=int(rng.integers(3, 25)), band_size=int(rng.integers(6, 100)),
                       local=bool(rng.random() < 0.8))
             if rng.random() < 0.1: kw = dict(sparse=False)
-            run_case(c, both_strands(ref), reads, sc, null, cfg_kw=kw, force=bool(rng.random() < 0.3))
+            force = bool(rng.random() < 0.3)
+            res, _ = run_case(c, both_strands(ref), reads, sc, null, cfg_kw=kw, force=force)
+            if rng.random() < 0.35 and res["forward_bytes"] > 4096:   # the same E-step cut into pieces by a small memory budget
+                parts = None
+                try:
+                    c.set_memory_budget(max(1024, res["forward_bytes"] // int(rng.integers(2, 9))))
+                    parts = c.count_resident(Q.DPConfig(**kw), force=force)
+                except Q.QuaffHipError as e:   # a budget below one read's own need is refused, as documented
+                    assert "over the memory budget" in str(e)
+                finally:
+                    c.set_memory_budget(0)
+                if parts is not None:
+                    assert np.array_equal(parts["forward"], res["forward"]) and parts["sort_order"] == res["sort_order"]
+                    np.testing.assert_allclose(parts["counts"], res["counts"], rtol=1e-9, atol=1e-12)
         else:
             kw = dict(kmer_len=int(rng.integers(4, 8)), kmer_threshold=int(rng.integers(3, 20)), band_size=int(rng.integers(6, 100)))
             if rng.random() < 0.1: kw = dict(sparse=False)
-            check_overlap(c, reads[:min(n, 14)], pj, kw)
+            full, _ = check_overlap(c, reads[:min(n, 14)], pj, kw)
+            if rng.random() < 0.5 and full["alignments"]:   # the printer's threshold on the device: exactly the survivors
+                sub = reads[:min(n, 14)]
+                seqs = sub + [r.revcomp() for r in sub]
+                pairs = O.overlap_task_pairs(len(sub), len(seqs))
+                scores = sorted(a["score"] for a in full["alignments"].values())
+                thr = scores[int(rng.integers(0, len(scores)))]
+                try:
+                    c.set_score_threshold(thr)
+                    cut = c.overlap_resident(pairs, Q.DPConfig(**kw))
+                finally:
+                    c.set_score_threshold(float("-inf"))
+                want = {k: (a["score"], a["ops"]) for k, a in full["alignments"].items() if a["score"] >= thr}
+                assert {k: (a["score"], a["ops"]) for k, a in cut["alignments"].items()} == want
+                assert np.array_equal(cut["score"], full["score"])
         ok += 1
     except Exception as e:
         bad += 1
