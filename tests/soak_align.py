@@ -43,7 +43,21 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             res, _ = run_both(c, both_strands(ref), reads, kw, sc, null, flags=1 if pall else 0, quals=quals)
             print("seed", seed, "gpu only: %d records, %d cells in %.1fs" % (len(res["alignments"]), res["total_cells"], time.time() - t1)); sys.stdout.flush()
             continue
-        check_against_oracle(c, both_strands(ref), reads, kw, sc, null, quals=quals, print_all=pall)
+        res = check_against_oracle(c, both_strands(ref), reads, kw, sc, null, quals=quals, print_all=pall)
+        if rng.random() < 0.4 and res["traceback_bytes"] > 4096:   # the same batch in pieces: small memory budget and / or two slots
+            key = lambda a: (a["read"], a["ref"], a["score"], a["xStart"], a["xEnd"], a["cigar"])
+            again = None
+            try:
+                c.set_memory_budget(max(1024, res["traceback_bytes"] // int(rng.integers(2, 9))))
+                c.set_pipeline_chunks(int(rng.integers(0, 4)))
+                again, _ = run_both(c, both_strands(ref), reads, kw, sc, null, flags=1 if pall else 0, quals=quals)
+            except Q.QuaffHipError as e:   # a budget below one read's own need is refused, as documented
+                assert "over the memory budget" in str(e)
+            finally:
+                c.set_memory_budget(0); c.set_pipeline_chunks(0)
+            if again is not None:
+                assert [key(a) for a in again["alignments"]] == [key(a) for a in res["alignments"]]
+                assert np.array_equal(again["viterbi"], res["viterbi"]) and again["total_cells"] == res["total_cells"]
         n_ok += 1
     except Exception as e:
         print("FAIL seed", seed, kw, "n", n, "quals", quals, "printall", pall, type(e).__name__, str(e)[:300]); sys.stdout.flush()
