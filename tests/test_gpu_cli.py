@@ -133,3 +133,34 @@ def test_batches_spread_over_devices_give_the_same_output(tmp_path):
 def test_gpus_flag_rejects_more_devices_than_visible():
     out = subprocess.run([QUAFF, "align", C8, C8, "-gpus", "99"], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "HIP device" in out.stderr
+
+
+def test_fasta_and_refseq_formats_agree_with_stockholm(tmp_path):
+    """-format fasta = the two gapped rows as FASTA records plus a blank line (Alignment::writeGappedFasta,
+    src/qmodel.cpp:548-551, :2572-2575); -format refseq = the ungapped reference row with "matches(Read)" prepended to its
+    comment (:2585-2590).  Both are rebuilt here from the Stockholm output of the same run."""
+    rng = np.random.default_rng(54)
+    ref = rand_seq(rng, 2000)
+    reads = make_reads(rng, ref, 8, 350)
+    (tmp_path / "ref.fa").write_text(">chrT a reference\n" + ref + "\n")
+    (tmp_path / "reads.fq").write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+    sto = run("align", fa, fq)
+    recs = []
+    for block in sto.split("//\n")[:-1]:
+        rows, cc = {}, {}
+        for line in block.splitlines():
+            if line.startswith("#=GS CC "):
+                name, comment = line[8:].split(" ", 1)
+                cc[name] = comment
+            elif line and not line.startswith("#"):
+                name, data = line.split(None, 1)
+                rows[name] = rows.get(name, "") + data
+        recs.append((rows, cc))
+    assert len(recs) == 8 and all(set(r) == {"Ref", "Read"} for r, _ in recs)
+    want_fasta = "".join(">Ref %s\n%s\n>Read %s\n%s\n\n" % (cc["Ref"], rows["Ref"], cc["Read"], rows["Read"]) for rows, cc in recs)
+    assert run("align", fa, fq, "-format", "fasta") == want_fasta
+    want_refseq = "".join(">Ref matches(Read) %s\n%s\n" % (cc["Ref"], rows["Ref"].replace("-", "")) for rows, cc in recs)
+    assert run("align", fa, fq, "-format", "refseq") == want_refseq
+    out_file = tmp_path / "saved.sto"
+    assert run("align", fa, fq, "-savealign", str(out_file)) == "" and out_file.read_text() == sto
