@@ -806,6 +806,55 @@ static int cmdOverlap(Opts& o) {
   return EXIT_SUCCESS;
 }
 
+// `quaff selftest <what> ...`: the host-side unit-test programs of the reference (t/testfasta.cpp, t/testfastq.cpp,
+// t/testquaffjsonio.cpp, t/testquaffnulljsonio.cpp, t/testquaffcountsjsonio.cpp, t/testnegbinom.cpp; Makefile:103-133) over
+// this build's readers, writers and fitter.  No device is touched.
+static int cmdSelfTest(deque<string>& av) {
+  Require(!av.empty(), "selftest needs a name: fasta fastq params null counts negbinom");
+  const string what = av[0];
+  av.pop_front();
+  auto parsed = [&](const string& file) { Json j; string err; if (!parse_json(slurp(file), j, err)) Fail("Couldn't parse " + file + ": " + err); return j; };
+  if (what == "fasta" || what == "fastq") {
+    Require(av.size() == 1, "selftest " + what + " <seqs>");
+    for (const FastSeq& fs : readFastSeqs(av[0])) {
+      if (what == "fasta") writeFasta(cout, fs);
+      else {   // FastSeq::writeFastq, src/fastseq.cpp:119-127
+        cout << '@' << fs.name;
+        if (fs.comment.size()) cout << ' ' << fs.comment;
+        cout << endl << fs.seq << endl;
+        if (fs.hasQual()) cout << '+' << endl << fs.qual << endl;
+      }
+    }
+    return EXIT_SUCCESS;
+  }
+  if (what == "params" || what == "null" || what == "counts") {
+    Require(av.size() == 1, "selftest " + what + " <file.json>");
+    const Json j = parsed(av[0]);
+    string err;
+    if (what == "params") { Params p; if (!p.read_json(j, err)) Fail(err); cout << p.write_json(); }
+    else if (what == "null") { NullParams p; if (!p.read_json(j, err)) Fail(err); cout << p.write_json(); }
+    else { ParamCounts c(1, 0); if (!c.read_json(j, err)) Fail(err); cout << c.write_json(); }
+    return EXIT_SUCCESS;
+  }
+  if (what == "negbinom") {   // t/testnegbinom.cpp with the exact expected frequencies instead of GSL's sampler
+    Require(av.size() == 4, "selftest negbinom pSuccess nFail nSamples relativeError");
+    const double p = atof(av[0].c_str()), r = atof(av[1].c_str()), N = atof(av[2].c_str()), eps = atof(av[3].c_str());
+    vector<double> kFreq;
+    for (int k = 0; k < 2000; ++k) {
+      const double f = N * exp(lgamma(k + r) - lgamma(r) - lgamma(k + 1.) + r * log(p) + k * log1p(-p));
+      if (k > r / p && f < 1e-9) break;
+      kFreq.push_back(f);
+    }
+    double pFit = 0, rFit = 0;
+    const int status = fit_negbinom(kFreq, pFit, rFit);
+    const bool ok = status == 0 && fabs(pFit - p) < eps * fabs(p) && fabs(rFit - r) < eps * fabs(r);   // gsl_root_test_delta(x1, x0, 0, eps)
+    cout << (ok ? "ok" : "not ok") << ": (" << pFit << ',' << rFit << ") " << (ok ? "~=" : "!=") << " (" << p << ',' << r << ')' << endl;
+    return EXIT_SUCCESS;
+  }
+  Fail("Unknown selftest: " + what);
+  return EXIT_FAILURE;
+}
+
 int main(int argc, char** argv) {
   Opts o;
   for (int n = 1; n < argc; ++n) o.av.push_back(argv[n]);
@@ -816,6 +865,7 @@ int main(int argc, char** argv) {
   if (command == "count") return cmdTrainOrCount(o, false);
   if (command == "train") return cmdTrainOrCount(o, true);
   if (command == "overlap") return cmdOverlap(o);
+  if (command == "selftest") return cmdSelfTest(o.av);
   if (command == "help" || command == "-h" || command == "--help" || command == "-help") {
     cout << "Usage: quaff {help,train,align,overlap} [options]\n\n"
             " quaff train refs.fasta reads.fastq >params.json   (-maxiter -mininc -maxreadmb -force -order/-suborder/-gaporder\n"
