@@ -164,3 +164,21 @@ def test_fasta_and_refseq_formats_agree_with_stockholm(tmp_path):
     assert run("align", fa, fq, "-format", "refseq") == want_refseq
     out_file = tmp_path / "saved.sto"
     assert run("align", fa, fq, "-savealign", str(out_file)) == "" and out_file.read_text() == sto
+
+
+def test_auto_fitted_null_model_matches_oracle(tmp_path):
+    """Without -null the null model is fitted to the reads (QuaffNullParams(seqs), src/qmodel.cpp:1811-1843, with the
+    negative-binomial fit of src/negbinom.cpp); -savenull writes it.  Two independent restatements (C++ here, Python in the
+    oracle) must print the same file at the reference's 6 significant figures."""
+    import re
+    rng = np.random.default_rng(55)
+    ref = rand_seq(rng, 2500)
+    reads = make_reads(rng, ref, 60, 300)
+    (tmp_path / "ref.fa").write_text(">ref\n" + ref + "\n")
+    (tmp_path / "reads.fq").write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    saved = tmp_path / "null.json"
+    run("align", str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq"), "-savenull", str(saved))
+    got, want = saved.read_text(), O.NullParams.fit(reads).to_json()
+    nums = lambda t: np.array(list(map(float, re.findall(r"-?\d+\.?\d*(?:e[-+]?\d+)?", t))))
+    assert re.sub(r"[-\d.e+]+", "#", got).split() == re.sub(r"[-\d.e+]+", "#", want).split()     # same layout
+    np.testing.assert_allclose(nums(got), nums(want), rtol=2e-5)                                    # same numbers (6 s.f. text)
