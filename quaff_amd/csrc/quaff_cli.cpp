@@ -810,7 +810,7 @@ static int cmdOverlap(Opts& o) {
 // t/testquaffjsonio.cpp, t/testquaffnulljsonio.cpp, t/testquaffcountsjsonio.cpp, t/testnegbinom.cpp; Makefile:103-133) over
 // this build's readers, writers and fitter.  No device is touched.
 static int cmdSelfTest(deque<string>& av) {
-  Require(!av.empty(), "selftest needs a name: fasta fastq params null counts negbinom");
+  Require(!av.empty(), "selftest needs a name: fasta fastq params null counts fit negbinom");
   const string what = av[0];
   av.pop_front();
   auto parsed = [&](const string& file) { Json j; string err; if (!parse_json(slurp(file), j, err)) Fail("Couldn't parse " + file + ": " + err); return j; };
@@ -834,6 +834,14 @@ static int cmdSelfTest(deque<string>& av) {
     if (what == "params") { Params p; if (!p.read_json(j, err)) Fail(err); cout << p.write_json(); }
     else if (what == "null") { NullParams p; if (!p.read_json(j, err)) Fail(err); cout << p.write_json(); }
     else { ParamCounts c(1, 0); if (!c.read_json(j, err)) Fail(err); cout << c.write_json(); }
+    return EXIT_SUCCESS;
+  }
+  if (what == "fit") {   // the M-step alone: QuaffParamCounts::fit, src/qmodel.cpp:1731-1768
+    Require(av.size() == 1, "selftest fit <counts.json>");
+    ParamCounts c(1, 0);
+    string err;
+    if (!c.read_json(parsed(av[0]), err)) Fail(err);
+    cout << c.fit().write_json();
     return EXIT_SUCCESS;
   }
   if (what == "negbinom") {   // t/testnegbinom.cpp with the exact expected frequencies instead of GSL's sampler

@@ -51,3 +51,46 @@ def test_json_round_trips(what, name):
 def test_negbinom_fit_recovers_parameters():
     assert selftest("negbinom", ".1", "5", "10000", ".1").startswith("ok:")           # Makefile:132
     assert selftest("negbinom", ".6", "30", "5000", ".1").startswith("ok:")
+
+
+def test_m_step_fit_from_counts():
+    """QuaffParamCounts::fit (src/qmodel.cpp:1731-1768) over the reference's counts fixture: transition probabilities are
+    yes / (yes + no), symbol probabilities the normalised count sums within a context, and every (q, r) the
+    negative-binomial fit of that context's quality counts — checked against the oracle's independent fitter."""
+    import numpy as np
+    from oracle import oracle as O
+    import json
+    cj = O.gason_loads(golden("testquaffcounts.json"))
+    # the fixture (a self-alignment) has no insertions and no mismatches: 0/0 there, in the reference too.  Fill those in.
+    for k, x in enumerate("ACGT"):
+        diag = cj["match"][""][x][x]
+        for m, y in enumerate("ACGT"):
+            if y != x:
+                cj["match"][""][x][y] = [0.0] * (2 + m) + [0.02 * (1 + m) * v for v in diag[:len(diag) - 2 - m]]
+        cj["insert"][x] = [0.1 * (1 + k) * v for v in diag[3:]] + [0.0] * 3
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(cj, f)
+    try:
+        pj = O.gason_loads(selftest("fit", f.name))
+    finally:
+        os.unlink(f.name)
+    isum = {x: float(np.sum(cj["insert"][x])) for x in "ACGT"}
+    for x in "ACGT":
+        q, r = O.fit_negbinom(np.array(cj["insert"][x], float))
+        got = pj["insert"][x]
+        assert abs(got["p"] - isum[x] / sum(isum.values())) <= 2e-5 * got["p"]
+        assert abs(got["q"] - q) <= 2e-3 * q and abs(got["r"] - r) <= 2e-3 * r, (x, got, q, r)
+    close = lambda a, b: abs(a - b) <= 2e-5 * max(abs(a), abs(b), 1e-300)     # 6 s.f. text
+    for name in ("Insert", "Delete"):
+        yes, no = cj["begin%sYes" % name][""], cj["begin%sNo" % name][""]
+        assert close(pj["begin" + name][""], 1 / (1 + no / yes))
+        assert close(pj["extend" + name], 1 / (1 + cj["extend%sNo" % name] / cj["extend%sYes" % name]))
+    for x in "ACGT":
+        sums = {y: float(np.sum(cj["match"][""][x][y])) for y in "ACGT"}
+        for y in "ACGT":
+            got = pj["match"][""][x][y]
+            assert close(got["p"], sums[y] / sum(sums.values()))
+            if sums[y] > 0:
+                q, r = O.fit_negbinom(np.array(cj["match"][""][x][y], float))
+                assert abs(got["q"] - q) <= 2e-3 * q and abs(got["r"] - r) <= 2e-3 * r, (x, y, got, q, r)   # both stop at a relative 1e-4 Newton step
