@@ -30,8 +30,8 @@ BYTES_PER_CELL = 24.0        # 3 fp64 states per DP cell
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 2: 100000)")
     ap.add_argument("--read-len", type=int, default=1000)
     ap.add_argument("--ref-len", type=int, default=10000)
