@@ -448,3 +448,24 @@ def test_score_threshold_filters_before_the_traceback(ctx):
         assert none["alignments"] == []
     finally:
         ctx.set_score_threshold(float("-inf"))
+
+
+def test_seeding_coarse_bin_widths_and_wide_counters(ctx):
+    """The wavefront seeding picks coarse bins of 32 / 16 / 8 diagonals from the chance-match rate and 32-bit coarse counters
+    when a bin could pass 65 535 matches.  One case per (width, wide) combination the other tests do not reach
+    and a homopolymer pair that really puts more than 65 535 matches into one 32-diagonal bin."""
+    sc, null = oracle_model()
+    for seed, k, ref_len, read_len in ((61, 8, 6000, 2600),     # 32-diagonal bins, wide (reads >= 2040)
+                                       (62, 7, 9000, 4300),     # 16-diagonal bins, wide (reads >= 4080)
+                                       (63, 6, 10000, 8500)):   # 8-diagonal bins, wide (reads >= 8160)
+        rng = np.random.default_rng(seed)
+        ref = rand_seq(rng, ref_len)
+        reads = make_reads(rng, ref, 2, read_len)
+        res = check_against_oracle(ctx, both_strands(ref), reads, dict(kmer_len=k), sc, null)
+        assert res["n_diagonals"].max() > 64
+    # 32-diagonal bins with 32-bit counters really needed: 8-mers of a 2 400-base homopolymer, ~77 000 matches per bin
+    rng = np.random.default_rng(64)
+    lowc = rand_seq(rng, 150) + "A" * 2400 + rand_seq(rng, 150)
+    rd = O.FastSeq("polyA", "A" * 2350 + rand_seq(rng, 40), rand_qual(rng, 2390))
+    res = check_against_oracle(ctx, [O.FastSeq("lowc", lowc)], [rd], dict(kmer_len=8), sc, null)
+    assert res["n_diagonals"].max() > 2400
