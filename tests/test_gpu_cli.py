@@ -182,3 +182,30 @@ def test_auto_fitted_null_model_matches_oracle(tmp_path):
     nums = lambda t: np.array(list(map(float, re.findall(r"-?\d+\.?\d*(?:e[-+]?\d+)?", t))))
     assert re.sub(r"[-\d.e+]+", "#", got).split() == re.sub(r"[-\d.e+]+", "#", want).split()     # same layout
     np.testing.assert_allclose(nums(got), nums(want), rtol=2e-5)                                    # same numbers (6 s.f. text)
+
+
+def test_cli_errors_exit_nonzero_with_the_reference_messages(tmp_path):
+    """Require/Fail print a message and exit(1) in the reference (src/util.cpp:80-98); an unknown base terminates it
+    (src/fastseq.cpp:76-79).  Same here: non-zero exit status, message on stderr, nothing on stdout."""
+    rng = np.random.default_rng(56)
+    ref = rand_seq(rng, 800)
+    (tmp_path / "ref.fa").write_text(">ref\n" + ref + "\n")
+    (tmp_path / "bad.fq").write_text("@r0\n%sN%s\n+\n%s\n" % (ref[100:200], ref[201:300], "5" * 200))
+    (tmp_path / "noqual.fa").write_text(">r0\n" + ref[100:300] + "\n")
+    fa = str(tmp_path / "ref.fa")
+
+    def fails(*args):
+        out = subprocess.run([QUAFF] + list(args), capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and out.stdout == "", (args, out.stdout[:200])
+        return out.stderr
+
+    assert "Unknown symbol" in fails("align", fa, str(tmp_path / "bad.fq"))
+    assert "Couldn't open" in fails("align", fa, str(tmp_path / "missing.fq"))
+    assert "does not have quality scores" in fails("train", fa, str(tmp_path / "noqual.fa"))
+    assert "out of range" in fails("align", fa, str(tmp_path / "noqual.fa"), "-kmatch", "3")
+    assert "Unknown format" in fails("align", fa, str(tmp_path / "noqual.fa"), "-format", "bam")
+    assert "does not have quality scores" in fails("align", fa, str(tmp_path / "noqual.fa"))     # reads.wantQualScores, t/quaff.cpp:117
+    # with -noquals reads without qualities are fine, and so is a read shorter than k
+    (tmp_path / "short.fa").write_text(">tiny\nACG\n>r1\n" + ref[300:500] + "\n")
+    ok = subprocess.run([QUAFF, "align", fa, str(tmp_path / "short.fa"), "-noquals", "-nothreshold"], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and ok.stdout.count("# STOCKHOLM") == 2, ok.stderr[-500:]
