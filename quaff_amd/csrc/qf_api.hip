@@ -635,6 +635,7 @@ static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs
   s.max_ref_len = (uint32_t)std::min<uint64_t>(c->ref_maxlen, 0xFFFFFFFFull);
   s.max_read_len = (uint32_t)std::min<uint64_t>(c->read_maxlen, 0xFFFFFFFFull);
   s.no_lds_index = (cfg->reserved >> 4) & 1;
+  s.few_hits = 0;   // set by seed_pairs once the x side is known (references, or reads for overlap)
   s.bc = S.d_bc.as<BatchCounters>();
 }
 
@@ -700,6 +701,7 @@ static int seed_pairs(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t n_pa
     if (int rc = reserve_pair_buffers(S, n_pairs, max_units)) return rc;
     fill_seed_args(c, *S, cfg, sa, max_units, max_nd);
     customize(sa);
+    sa.few_hits = sa.sparse && (sa.kmer_len >= 16 || (uint64_t)(sa.max_ref_len ? sa.max_ref_len : sa.max_read_len) < (1ull << (2 * sa.kmer_len)));
     if (int rc = reserve_seed_workspace(S, sa, mem, n_pairs)) return rc;
     if (launch_seed(sa, n_pairs, mem, S->stream) != 0)
       return fail(S, QF_ERR_UNSUPPORTED, "sequence pair of " + std::to_string(max_nd) + " diagonals: no seeding workspace");

@@ -644,6 +644,7 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
   const uint32_t* __restrict__ sk = a.skmer + yb;
   const unsigned long long* __restrict__ sk64 = a.skmer64 ? a.skmer64 + yb : nullptr;
   const int nk = yLen - k + 1;  // read k-mers (>= 1 here)
+  const bool few = a.few_hits != 0;   // (uniform)
   // visit(bin) for every (i, j) with equal k-mers, bin = i - j + yLen - 1 (diagenv.cpp:33-40).
   // R read positions per lane per round; the three dependent loads are issued as batches.
   auto walk = [&](auto&& visit) {
@@ -665,15 +666,21 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
           else bucket_range(a, x, xb, xLen, km[c], s[c], e[c]);
         }
       }
-      uint32_t pa[R], pb[R], pc[R], pd[R];  // the first four entries of each bucket (the index has 4 words of slack)
+      // the first entries of each bucket are fetched unconditionally, as a batch (the index has 4 words of slack): four of
+      // them, or two when a k-mer of the read is expected to occur less than once in x (`few`: 2 kb reads against each
+      // other; the third and later entries then take the rare loop)
+      uint32_t pa[R], pb[R], pc[R], pd[R];
 #pragma clang loop unroll(full)
       for (int c = 0; c < R; ++c) {
+        pc[c] = pd[c] = 0;
         if (LDSIDX) {
           const uint16_t* q4 = sp + s[c];
-          pa[c] = q4[0]; pb[c] = q4[1]; pc[c] = q4[2]; pd[c] = q4[3];
+          pa[c] = q4[0]; pb[c] = q4[1];
+          if (!few) { pc[c] = q4[2]; pd[c] = q4[3]; }
         } else {
           const uint32_t* q4 = pos + s[c];
-          pa[c] = q4[0]; pb[c] = q4[1]; pc[c] = q4[2]; pd[c] = q4[3];
+          pa[c] = q4[0]; pb[c] = q4[1];
+          if (!few) { pc[c] = q4[2]; pd[c] = q4[3]; }
         }
       }
 #pragma clang loop unroll(full)
@@ -682,9 +689,13 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
         const uint32_t n = e[c] - s[c];
         if (n > 0) visit((int)pa[c] - j + yLen - 1);
         if (n > 1) visit((int)pb[c] - j + yLen - 1);
-        if (n > 2) visit((int)pc[c] - j + yLen - 1);
-        if (n > 3) visit((int)pd[c] - j + yLen - 1);
-        for (uint32_t q = 4; q < n; ++q) visit((int)(LDSIDX ? (uint32_t)sp[s[c] + q] : pos[s[c] + q]) - j + yLen - 1);  // long buckets
+        uint32_t q = 2;
+        if (!few) {
+          if (n > 2) visit((int)pc[c] - j + yLen - 1);
+          if (n > 3) visit((int)pd[c] - j + yLen - 1);
+          q = 4;
+        }
+        for (; q < n; ++q) visit((int)(LDSIDX ? (uint32_t)sp[s[c] + q] : pos[s[c] + q]) - j + yLen - 1);  // long buckets
       }
     }
   };

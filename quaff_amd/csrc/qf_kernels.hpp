@@ -67,6 +67,7 @@ struct SeedArgs {
   uint32_t ws_slots;
   uint32_t max_ref_len;        // longest reference (0: unknown / not a reference set)
   uint32_t max_read_len;       // longest y-sequence of the batch (selects 32-bit coarse seeding counters)
+  int few_hits;                // a read k-mer is expected less than once in an x-sequence (longest x / 4^k < 1): seeding prefetches two bucket entries, not four
   int no_lds_index;            // 1: never copy the reference index to LDS (debug / A-B)
   const uint8_t* pair_skip;    // optional [n_pairs]: 1 = do not seed this pair (train: pruned references)
   int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
