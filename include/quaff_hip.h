@@ -236,7 +236,8 @@ typedef struct qf_overlap_result {
 
 /* Align pairs of the resident sequences (qf_upload_reads: originals followed, if wanted, by their reverse complements,
  * as SeqList::loadSequences builds them).  pair_x / pair_y index the resident set; y_complemented[p] != 0 tells the
- * scorer that y is a reverse-complemented read (QuaffOverlapScheduler: ny >= nOriginals). */
+ * scorer that y is a reverse-complemented read (QuaffOverlapScheduler: ny >= nOriginals).  At most 2^28 pairs per call
+ * (as for reads x references in qf_align_* / qf_count_resident); callers feed longer lists in blocks. */
 int qf_overlap_resident(qf_ctx *ctx, const qf_dp_config *cfg, const uint32_t *pair_x, const uint32_t *pair_y,
                         const uint8_t *y_complemented, uint32_t n_pairs, qf_overlap_result *out);
 

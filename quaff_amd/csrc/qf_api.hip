@@ -201,6 +201,7 @@ struct qf_ctx : Slot {
     }                                                                                           \
   } while (0)
 
+constexpr uint64_t kMaxPairsPerCall = 1ull << 28;   // unit tables are sized 4 x pairs + slack in 32 bits
 constexpr size_t kLseHermiteOffset = 100002;  // doubles: the exact table (100001) padded to even, then the spline nodes
 
 static int fail(Slot* c, int code, const std::string& msg) {
@@ -911,7 +912,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   memset(out, 0, sizeof *out);
   const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
   const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
-  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
+  if (n_pairs64 > kMaxPairsPerCall) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^28 read x reference pairs in one batch");
   const uint32_t n_pairs = (uint32_t)n_pairs64;
   out->n_reads = n_reads;
   out->n_refs = n_refs;
@@ -1308,7 +1309,7 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   memset(out, 0, sizeof *out);
   const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
   const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
-  if (n_pairs64 > 0x7FFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch");
+  if (n_pairs64 > kMaxPairsPerCall) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^28 read x reference pairs in one batch");
   const uint32_t n_pairs = (uint32_t)n_pairs64;
   out->n_reads = n_reads;
   out->n_refs = n_refs;
@@ -1634,6 +1635,7 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   out->n_pairs = n_pairs;
   if (!n_pairs) return QF_OK;
   if (!pair_x || !pair_y || !y_comp) return fail(c, QF_ERR_ARG, "null pair list");
+  if (n_pairs > kMaxPairsPerCall) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^28 pairs in one call");
   const uint32_t n_seqs = c->n_reads;
   bool need[2] = {false, false};
   for (uint32_t p = 0; p < n_pairs; ++p) {
