@@ -513,7 +513,8 @@ static int cmdAlign(Opts& o) {
   pr.header(cout, refs.seqs, false);
   // contiguous blocks of reads, one per device at a time; printed in read order whatever the device count
   const size_t G = s.devices(), n = reads.seqs.size();
-  const size_t batch = max<size_t>(1, min<size_t>(65536, (n + G - 1) / G));
+  const size_t perCall = max<size_t>(1, ((size_t)1 << 28) / max<size_t>(1, refs.seqs.size()));   // the library takes 2^28 pairs per call
+  const size_t batch = max<size_t>(1, min<size_t>({(size_t)65536, perCall, (n + G - 1) / G}));
   for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
     const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
     vector<vector<Alignment>> got(nrun);
@@ -544,7 +545,8 @@ static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_re
   // read blocks spread over the devices; block sums are added in read order (QuaffParamCounts::operator+ over tasks,
   // src/qmodel.cpp:2416-2422), so the result does not depend on the device count
   const size_t G = s.devices(), n = reads.seqs.size();
-  const size_t batch = max<size_t>(1, min<size_t>(16384, (n + G - 1) / G));
+  const size_t perCall = max<size_t>(1, ((size_t)1 << 28) / max<size_t>(1, (size_t)n_refs));   // the library takes 2^28 pairs per call
+  const size_t batch = max<size_t>(1, min<size_t>({(size_t)16384, perCall, (n + G - 1) / G}));
   const bool haveOrder = !sortOrder.empty();
   if (!haveOrder) sortOrder.assign(n, vector<uint32_t>());
   for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
