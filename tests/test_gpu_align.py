@@ -469,3 +469,27 @@ def test_seeding_coarse_bin_widths_and_wide_counters(ctx):
     rd = O.FastSeq("polyA", "A" * 2350 + rand_seq(rng, 40), rand_qual(rng, 2390))
     res = check_against_oracle(ctx, [O.FastSeq("lowc", lowc)], [rd], dict(kmer_len=8), sc, null)
     assert res["n_diagonals"].max() > 2400
+
+
+def test_many_references_of_different_lengths(ctx):
+    """Seven references (150 b ... 6 kb, one shorter than 2(k + n): full envelope against it) and their reverse complements:
+    the best reference per read, ties to the earlier one, -printall order, per-reference k-mer indices."""
+    rng = np.random.default_rng(37)
+    sc, null = oracle_model()
+    lens = [3000, 150, 6000, 800, 40, 2200, 1500]
+    fwd = [O.FastSeq("ref%d" % k, rand_seq(rng, L)) for k, L in enumerate(lens)]
+    fwd[5] = O.FastSeq("ref5", fwd[0].seq[500:2700])                      # shares 2.2 kb with ref0: ties and near-ties
+    refs = fwd + [x.revcomp() for x in fwd]
+    reads = []
+    for k in range(36):
+        x = fwd[int(rng.integers(0, len(fwd)))]
+        L = int(rng.integers(30, min(400, len(x.seq)) + 1))
+        s0 = int(rng.integers(0, len(x.seq) - L + 1))
+        src = x.seq[s0:s0 + L]
+        if k % 3 == 1:
+            src = O.revcomp_str(src)
+        seq = mutate(rng, src, sub=.04, ins=.02, dele=.02) or "A"
+        reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+    res = check_against_oracle(ctx, refs, reads, dict(), sc, null)
+    assert len({a["ref"] for a in res["alignments"]}) >= 6
+    check_against_oracle(ctx, refs, reads[:12], dict(kmer_threshold=8, band_size=20), sc, null, print_all=True)
