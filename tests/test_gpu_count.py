@@ -208,3 +208,22 @@ def test_count_many_bands_one_running_end_sum(ctx):
         assert (np.abs(res["counts"] - want) / np.maximum(np.abs(want), 1e-3 * scale)).max() < 5e-5
     finally:
         ctx.set_params_json(None)
+
+
+def test_count_many_references_and_pruned_orders(ctx):
+    """Ten reference sequences (five + reverse complements, two of them near-duplicates so that several references stay within
+    20 of a read's running log-likelihood): posterior weights over more than one reference, the next iteration's order
+    (log-likelihood descending, ties to the later reference, cut at -20), and a second E-step on the pruned orders."""
+    from tests.helpers import mutate
+    rng = np.random.default_rng(38)
+    sc, null = O.Scores(O.Params.from_json(DEFAULT_JSON)), O.NullParams.from_json(NULL_JSON)
+    base = rand_seq(rng, 1800)
+    fwd = [O.FastSeq("a", base), O.FastSeq("b", mutate(rng, base, sub=.01, ins=.002, dele=.002)), O.FastSeq("c", rand_seq(rng, 900)),
+           O.FastSeq("d", base[600:1500]), O.FastSeq("e", rand_seq(rng, 2500))]
+    refs = fwd + [x.revcomp() for x in fwd]
+    reads = make_reads(rng, base, 14, 260) + make_reads(rng, fwd[4].seq, 6, 300)
+    res, _ = run_case(ctx, refs, reads, sc, null)
+    assert max(len(o) for o in res["sort_order"]) >= 3 and min(len(o) for o in res["sort_order"]) >= 1
+    assert ((res["weight"] > 0.01).sum(axis=1) >= 2).any()          # some reads split their weight over several references
+    res2, _ = run_case(ctx, refs, reads, sc, null, orders=res["sort_order"])
+    run_case(ctx, refs, reads, sc, null, orders=res2["sort_order"], force=True)
