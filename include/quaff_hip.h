@@ -31,6 +31,8 @@
  *   QuaffOverlapViterbiMatrix ctor   src/qoverlap.cpp:77-160  qf_overlap_resident (overlap fill kernel)
  *   QuaffOverlapViterbiMatrix::alignment :162-290, scoreAdjustedAlignment :292-302   qf_overlap_resident
  *   QuaffOverlapTask::run            src/qoverlap.cpp:457-464 qf_overlap_resident (one task per pair)
+ *   QuaffAlignmentPrinter threshold  src/qmodel.cpp:2566-2569 qf_set_score_threshold (applied before the traceback)
+ *   runQuaff*Tasks worker threads    src/qmodel.cpp:2870-2882 qf_device_count + one qf_ctx per device
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative qf_status otherwise (message via qf_last_error); nothing throws or exits across
