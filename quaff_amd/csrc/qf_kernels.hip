@@ -604,7 +604,8 @@ struct __attribute__((packed, aligned(4))) U32x4u { uint32_t v[4]; };
 // CB: log2 of the coarse bin width (5, 4 or 3).  Unrelated sequences still share length/4^k k-mers per diagonal by
 // chance; when 32 diagonals' worth of those comes close to the threshold (overlap defaults: 2 kb reads, k = 6, n = 14)
 // nearly every pair would have "candidate" bins and pay the second walk, so the host picks narrower bins then.
-template <bool LDSIDX, bool WIDE, int CB>
+// RR: read positions per lane per round of the walk (4; 2 in the explicit-pair-list kernel: measured, see there)
+template <bool LDSIDX, bool WIDE, int CB, int RR = 4>
 __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair, uint32_t r, uint32_t x, uint32_t* wlds,
                                                const uint16_t* sb, const uint16_t* sp) {
   // Two-level histogram.  Pass 1 counts k-mer matches per COARSE bin of 2^CB diagonals; a diagonal can reach
@@ -648,7 +649,7 @@ __device__ __forceinline__ void seed_wave_pair(const SeedArgs& a, uint32_t pair,
   // visit(bin) for every (i, j) with equal k-mers, bin = i - j + yLen - 1 (diagenv.cpp:33-40).
   // R read positions per lane per round; the three dependent loads are issued as batches.
   auto walk = [&](auto&& visit) {
-    constexpr int R = 4;
+    constexpr int R = RR;
     for (int j0 = 0; j0 < nk; j0 += 64 * R) {
       unsigned long long km[R];
       uint32_t s[R], e[R];
@@ -873,8 +874,10 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_
     if (a.pair_skip && a.pair_skip[pair]) continue;
     uint32_t r, x;
     pair_rx(a, pair, r, x);
-    if (x == x0) seed_wave_pair<true, WIDE, CB>(a, pair, r, x, wlds, sb, sp);
-    else seed_wave_pair<false, WIDE, CB>(a, pair, r, x, wlds, nullptr, nullptr);
+    // two read positions per lane per round: reads against reads rarely share a k-mer more than once (19.0 ms per 3.4 M
+    // pairs of 2 kb reads against 21.0 with four; one and three are worse; the align kernels are best with four)
+    if (x == x0) seed_wave_pair<true, WIDE, CB, 2>(a, pair, r, x, wlds, sb, sp);
+    else seed_wave_pair<false, WIDE, CB, 2>(a, pair, r, x, wlds, nullptr, nullptr);
     wave_lds_sync();
   }
 }
