@@ -824,7 +824,14 @@ __global__ __launch_bounds__(256) void k_seed_wave(SeedArgs a, uint32_t n_pairs,
 // Short references (k-mer index of one reference <= 48 KB as 16-bit entries): a workgroup of eight wavefronts copies one
 // reference's index to LDS and seeds kSeedReadsPerBlock reads against it.  The global-memory version spends two thirds
 // of its cycles waiting on L1 misses of those gathers (measured); here the only global traffic is the reads' k-mers.
-constexpr uint32_t kSeedReadsPerBlock = 64;
+#ifndef QF_SEED_RPB
+#define QF_SEED_RPB 32
+#endif
+#ifndef QF_SEED_PPB
+#define QF_SEED_PPB 256
+#endif
+constexpr uint32_t kSeedReadsPerBlock = QF_SEED_RPB;   // k_seed_wave_lds: reads per workgroup (one reference's index in LDS)
+constexpr uint32_t kSeedPairsPerBlock = QF_SEED_PPB;   // k_seed_wave_lds_pairs: consecutive pairs per workgroup
 template <bool WIDE, int CB>
 __global__ __launch_bounds__(512) void k_seed_wave_lds(SeedArgs a, uint32_t n_reads, uint32_t wave_lds_words, uint32_t idx_words) {
   extern __shared__ uint32_t lds[];
@@ -855,7 +862,7 @@ template <bool WIDE, int CB>
 __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_t n_pairs, uint32_t wave_lds_words, uint32_t idx_words) {
   extern __shared__ uint32_t lds[];
   const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t p0 = blockIdx.x * kSeedReadsPerBlock;
+  const uint32_t p0 = blockIdx.x * kSeedPairsPerBlock;
   uint32_t r0, x0;
   pair_rx(a, a.pair_base + p0, r0, x0);
   const uint64_t xb = a.ref_off[x0];
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_
   for (uint32_t q = threadIdx.x; q < xLen + 4; q += 512) sp[q] = q < xLen ? (uint16_t)gp[q] : (uint16_t)0;
   __syncthreads();
   uint32_t* wlds = lds + idx_words + (size_t)wv * wave_lds_words;
-  const uint32_t pend = min(p0 + kSeedReadsPerBlock, n_pairs);
+  const uint32_t pend = min(p0 + kSeedPairsPerBlock, n_pairs);
   for (uint32_t p = p0 + wv; p < pend; p += 8) {
     const uint32_t pair = a.pair_base + p;
     if (a.pair_skip && a.pair_skip[pair]) continue;
@@ -2165,7 +2172,7 @@ int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
     }
     // ... or an explicit pair list (overlap): the shared x's index in LDS
     if (a.pair_x && lds_index_ok && lds_index_fits) {
-      const uint32_t blocks = (n_pairs + kSeedReadsPerBlock - 1) / kSeedReadsPerBlock;
+      const uint32_t blocks = (n_pairs + kSeedPairsPerBlock - 1) / kSeedPairsPerBlock;
       with_seed_variant(wide, cb, [&](auto w, auto c) {
         auto fn = k_seed_wave_lds_pairs<decltype(w)::value, decltype(c)::value>;
         if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
