@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=1000)
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--band", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--workload", default="align", choices=["align", "train", "overlap", "fulldp"],
                     help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = scaled "
                          "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
