@@ -71,11 +71,7 @@ typedef struct qf_dp_config {
   int32_t kmer_len;        /* -kmatch, default 6 */
   int32_t kmer_threshold;  /* -kmatchn; default 20 (align/train) or 14 (overlap); < 0 = memory mode */
   int32_t band_size;       /* -kmatchband, default 64 */
-  int32_t reserved;        /* debug: bit 0 = workgroup-per-pair seeding kernel, bit 1 = first-generation fill kernel,
-                            * bit 2 = run the fill classes one after another on one stream, bit 3 = emission
-                            * tables stay in global memory, bit 4 = reference k-mer index stays in global memory,
-                            * bit 5 = overlap single-diagonal bands gather emissions from global memory,
-                            * bit 6 = E-step without the single-diagonal Forward kernel / negligible-band skip; keep 0 */
+  int32_t reserved;        /* must be 0 */
   uint64_t max_size;       /* memory mode: effectiveMaxSize() in bytes (-kmatchmb M => M<<20) */
 } qf_dp_config;
 
@@ -132,8 +128,9 @@ int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
  * instead of after it: most read pairs of an all-vs-all overlap run do not overlap and score below 0.  In best-per-read
  * mode the read's best alignment is chosen first and then tested, as the reference does.  Default: -inf (keep all). */
 int qf_set_score_threshold(qf_ctx *ctx, double min_score);
-/* Device bytes one internal chunk may use for traceback / Forward storage (default 160 GiB; 0 restores it).  Larger
- * batches are processed in halves transparently.  (The reference bounds DP memory per thread through -kmatchmb /
+/* Device bytes one internal chunk may use for traceback / Forward storage.  Default (and 0): what hipMemGetInfo reports
+ * free at the time of the call.  Larger batches are processed in halves transparently, and so is a chunk whose allocation
+ * fails (another context or process on the same GPU).  (The reference bounds DP memory per thread through -kmatchmb /
  * -kmatchmax, src/qmodel.cpp:788-813,1058-1060, and runs reads one at a time; here whole batches are resident, so the
  * bound is on the batch.) */
 int qf_set_memory_budget(qf_ctx *ctx, uint64_t bytes);

@@ -352,10 +352,24 @@ def fit_negbinom(kfreq):
             if abs(b - a) < 1e-3 + 1e-3 * min(abs(a), abs(b)):
                 break
         r = 0.5 * (a + b)
-    for _ in range(100):  # gradientFit :262-322
-        rn = r - d1(r) / d2(r)
-        done = abs(rn - r) < 1e-4 * abs(rn)
-        r = rn
+    # gradientFit :262-322.  GSL's Newton iterate fails on a zero derivative (GSL_EZERODIV) or a non-finite value at the
+    # new point (GSL_EBADFUNC); the reference reads the solver's root only after a successful iterate (:288-290), so the
+    # last accepted root stands.
+    f, df = d1(r), d2(r)
+    for _ in range(100):
+        if df == 0.0 or not (math.isfinite(f) and math.isfinite(df)):
+            break
+        rn = r - f / df
+        if not math.isfinite(rn) or rn <= 0:
+            break
+        try:
+            fn, dfn = d1(rn), d2(rn)
+        except (ValueError, ZeroDivisionError, OverflowError):
+            break
+        if not (math.isfinite(fn) and math.isfinite(dfn)):
+            break
+        done = abs(rn - r) < 1e-4 * abs(rn) or rn == r
+        r, f, df = rn, fn, dfn
         if done or r > len(kfreq):
             break
     return popt(r), r

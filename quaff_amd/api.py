@@ -17,8 +17,7 @@ class QuaffHipError(RuntimeError):
 
 
 def library_path():
-    # QUAFF_HIP_LIBRARY: developer override for A/B builds of the same ABI (never a different implementation)
-    return os.environ.get("QUAFF_HIP_LIBRARY") or os.path.join(HERE, "libquaffhip.so")
+    return os.path.join(HERE, "libquaffhip.so")
 
 
 def build_library(force=False):
@@ -35,8 +34,8 @@ class DPConfig(C.Structure):
     _fields_ = [("local", C.c_int32), ("sparse", C.c_int32), ("kmer_len", C.c_int32), ("kmer_threshold", C.c_int32),
                 ("band_size", C.c_int32), ("reserved", C.c_int32), ("max_size", C.c_uint64)]
 
-    def __init__(self, local=True, sparse=True, kmer_len=6, kmer_threshold=20, band_size=64, max_size=0, debug_flags=0):
-        super().__init__(int(local), int(sparse), kmer_len, kmer_threshold, band_size, debug_flags, max_size)
+    def __init__(self, local=True, sparse=True, kmer_len=6, kmer_threshold=20, band_size=64, max_size=0):
+        super().__init__(int(local), int(sparse), kmer_len, kmer_threshold, band_size, 0, max_size)
 
 
 class _Alignment(C.Structure):
@@ -215,6 +214,11 @@ class Context:
     def set_memory_budget(self, nbytes):
         self.L.qf_set_memory_budget.argtypes = [C.c_void_p, C.c_uint64]
         self._chk(self.L.qf_set_memory_budget(self.h, nbytes))
+
+    def set_debug_flags(self, flags):
+        """Tests / A-B only (csrc/qf_internal.h, not part of the public ABI): force a kernel variant; results never change."""
+        self.L.qf_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+        self._chk(self.L.qf_debug_set_flags(self.h, flags))
 
     def set_score_threshold(self, min_score):
         """Alignments scoring below min_score are not traced back / returned (-inf = all; the CLI's -threshold)."""

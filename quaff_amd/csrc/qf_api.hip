@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/quaff_hip.h"
+#include "qf_internal.h"
 #include "qf_kernels.hpp"
 #include "qf_model.hpp"
 
@@ -93,7 +94,7 @@ struct HostBuf {
 // chunk's seeding and traceback (latency-bound) overlap the other's fill (VALU-bound).
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev[7] = {};   // [6]: pair results final (their copy to the host overlaps selection and traceback)
+  hipEvent_t ev[8] = {};   // [6]: pair results final (their copy to the host overlaps selection and traceback); [7]: class lists final
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   hipStream_t hi[3] = {};                                          // high priority: classes too small to fill the chip (latency-bound chains)
@@ -141,7 +142,7 @@ struct qf_ctx : Slot {
   hipEvent_t ev_tok = nullptr, ev_nll = nullptr;   // read tokens ready / null log-likelihoods ready
   uint32_t pipeline_chunks = 0;  // 0 = automatic
   bool ragged_reads = false;     // resident read lengths differ by more than 25 %: class lists are sorted by length
-  bool byte_prep = false;        // QUAFF_HIP_BYTE_PREP=1: first-generation read-preparation kernel (A/B)
+  uint32_t debug = 0;            // qf_debug_set_flags (qf_internal.h): test / A-B switches, never set by the product
   std::string devname;
   // model
   Params params;
@@ -180,7 +181,7 @@ struct qf_ctx : Slot {
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
   double min_score = -INFINITY;   // qf_set_score_threshold
-  uint64_t tb_budget = 160ull << 30;   // per-chunk device storage budget (traceback / Forward matrices)
+  uint64_t tb_budget = 0;   // qf_set_memory_budget: per-chunk device storage budget (traceback / Forward matrices); 0 = what the device has free
   bool ov_scores[2] = {false, false};
   int read_index_k = 0;
   // the reads' derived arrays (tokens, context words, insert sums, null log-likelihoods) as the overlap path leaves them
@@ -209,6 +210,30 @@ static int fail(Slot* c, int code, const std::string& msg) {
   return code;
 }
 
+// Bytes one chunk may spend on its traceback / Forward storage: the caller's figure (qf_set_memory_budget), else what the
+// device has free right now plus what `own` already holds (it is reused), less 1/16 for the per-pair arrays of the batch.
+static uint64_t chunk_budget(const qf_ctx* c, const DevBuf& own, int slots_in_flight) {
+  if (c->tb_budget) return c->tb_budget / (uint64_t)slots_in_flight;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (16ull << 30) / (uint64_t)slots_in_flight;
+  const uint64_t avail = (uint64_t)free_b + own.cap;
+  return (avail - avail / 16) / (uint64_t)slots_in_flight;
+}
+
+// The big per-chunk buffer (traceback words or Forward matrices).  Buffers never shrink by themselves, so the other entry
+// points' big buffers may still hold most of the device: on failure they are released and the allocation is tried again.
+// (`idle`: the big buffers no chunk in flight is using.)
+static hipError_t reserve_big(DevBuf& buf, size_t bytes, std::initializer_list<DevBuf*> idle) {
+  hipError_t e = buf.reserve(bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  for (DevBuf* other : idle)
+    if (other != &buf) other->release();
+  e = buf.reserve(bytes);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e;
+}
+
 extern "C" {
 
 int qf_device_count(void) {
@@ -235,7 +260,6 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   }
   qf_ctx* c = new qf_ctx();
   c->device = device_id;
-  if (const char* e = getenv("QUAFF_HIP_BYTE_PREP")) c->byte_prep = atoi(e) != 0;
   if (const char* e = getenv("QUAFF_HIP_CHUNKS")) c->pipeline_chunks = (uint32_t)atoi(e);  // tuning aid; 0 = automatic
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
@@ -580,7 +604,6 @@ static int prep_reads(qf_ctx* c, int seed_k, hipStream_t side = nullptr) {
     a.null_logQual = c->d_nullq.as<double>();
   }
   a.bc = c->d_bc.as<BatchCounters>();
-  a.byte_kernel = c->byte_prep;
   launch_prep_reads(a, c->n_reads, c->stream);
   if (side) {
     HIPCHK(c, hipEventRecord(c->ev_tok, c->stream));
@@ -632,10 +655,10 @@ static void fill_seed_args(qf_ctx* c, Slot& S, const qf_dp_config* cfg, SeedArgs
   s.ovf_cap = max_units;
   s.pair_ndiag = S.d_pair_ndiag.as<uint32_t>();
   s.pair_cells = S.d_pair_cells.as<unsigned long long>();
-  s.force_block_kernel = cfg->reserved & 1;  // debug/testing: workgroup-per-pair seeding kernel
+  s.force_block_kernel = c->debug & QF_DEBUG_BLOCK_SEED;
   s.max_ref_len = (uint32_t)std::min<uint64_t>(c->ref_maxlen, 0xFFFFFFFFull);
   s.max_read_len = (uint32_t)std::min<uint64_t>(c->read_maxlen, 0xFFFFFFFFull);
-  s.no_lds_index = (cfg->reserved >> 4) & 1;
+  s.no_lds_index = (c->debug & QF_DEBUG_GLOBAL_INDEX) != 0;
   s.few_hits = 0;   // set by seed_pairs once the x side is known (references, or reads for overlap)
   s.bc = S.d_bc.as<BatchCounters>();
 }
@@ -752,7 +775,11 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     *too_big = true;
     return QF_OK;
   }
-  HIPCHK(S, S->d_tb.reserve(tb_bytes + 64));
+  if (reserve_big(S->d_tb, tb_bytes + 64, {&c->d_fw}) != hipSuccess) {   // less memory than the budget assumed: halve the chunk
+    if (n_reads == 1) return fail(S, QF_ERR_MEMORY, "cannot allocate " + std::to_string(tb_bytes >> 20) + " MiB of traceback for one read");
+    *too_big = true;
+    return QF_OK;
+  }
   if (int rc = sort_class_lists(c, S, bc, max_units)) return rc;
   FillArgs fa{};
   fa.n_refs = n_refs;
@@ -775,8 +802,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   fa.dp.i2m = sc.trans[4 * sc.Kg + 3];
   fa.dp.Kg = sc.Kg;
   fa.dp.local = cfg->local;
-  fa.reference_kernel = (cfg->reserved >> 1) & 1;
-  fa.no_lds_tables = (cfg->reserved >> 3) & 1;
+  fa.no_lds_tables = (c->debug & QF_DEBUG_GLOBAL_TABLES) != 0;
   // One kernel per class, the class with the most cells first, spread over the main and the side streams: the small
   // classes (and the single-diagonal chains, which are latency-bound) fill the SIMDs the big class's last wavefronts
   // leave idle.  Everything was seeded on the main stream, which the host has already waited for.
@@ -788,8 +814,14 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     int order[kNumClasses], n_used = 0;
     for (int cls = 0; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
     std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
-    const bool concurrent = !(cfg->reserved & 4);
+    const bool concurrent = !(c->debug & QF_DEBUG_SERIAL_CLASSES);
     const int n_lanes = fill_token ? 2 : 4;  // two chunks in flight: one side stream each (hardware queues are few)
+    // the side streams are non-blocking: they must not start before what the main stream still has queued for this chunk
+    // (the in-place sorts of the class lists above, and the buffer clears of reserve_pair_buffers)
+    if (concurrent && n_used > 1) {
+      HIPCHK(S, hipEventRecord(S->ev[7], S->stream));
+      for (int k = 0; k < n_lanes - 1; ++k) HIPCHK(S, hipStreamWaitEvent(S->aux[k], S->ev[7], 0));
+    }
     for (int k = 0; k < n_used; ++k) {
       const int cls = order[k], lane = concurrent ? (k < n_lanes ? k : 1 + (k - 1) % (n_lanes - 1)) : 0;
       hipStream_t s = lane == 0 ? S->stream : S->aux[lane - 1];
@@ -947,7 +979,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   // Measured on config 2 (MI355X): the overlap gained is paid back by the smaller grids, so the default is one piece;
   // pieces bound the peak traceback memory (two in flight) and overlap the result copies with compute.
   uint32_t n_chunks = c->pipeline_chunks ? c->pipeline_chunks : 1u;
-  if (cfg->reserved & 4) n_chunks = 1;
+  if (c->debug & QF_DEBUG_SERIAL_CLASSES) n_chunks = 1;
   n_chunks = std::min(n_chunks, n_reads);
   std::vector<std::pair<uint32_t, uint32_t>> todo;
   for (uint32_t k = n_chunks; k-- > 0;)
@@ -968,7 +1000,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
         ++in_flight;
       }
       bool too_big = false;
-      const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, n_chunks > 1 ? c->tb_budget / 2 : c->tb_budget, out,
+      const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, chunk_budget(c, S->d_tb, n_chunks > 1 ? 2 : 1), out,
                                  out_mu, n_chunks > 1 ? &fill_mu : nullptr, &too_big);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -1072,6 +1104,12 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   return QF_OK;
 }
 
+int qf_debug_set_flags(qf_ctx* c, uint32_t flags) {
+  if (!c) return QF_ERR_ARG;
+  c->debug = flags;
+  return QF_OK;
+}
+
 int qf_set_pipeline_chunks(qf_ctx* c, uint32_t n_chunks) {
   if (!c) return QF_ERR_ARG;
   c->pipeline_chunks = n_chunks;
@@ -1087,7 +1125,7 @@ int qf_set_score_threshold(qf_ctx* c, double min_score) {
 
 int qf_set_memory_budget(qf_ctx* c, uint64_t bytes) {
   if (!c) return QF_ERR_ARG;
-  c->tb_budget = bytes ? bytes : (160ull << 30);
+  c->tb_budget = bytes;
   return QF_OK;
 }
 
@@ -1186,12 +1224,16 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
 
   // ---- Forward
   const uint64_t fw_bytes = (uint64_t)bc.tb_words * 8;
-  if (fw_bytes > c->tb_budget) {
+  if (fw_bytes > chunk_budget(c, c->d_fw, 1)) {
     if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "one read needs " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices, over the memory budget");
     *too_big = true;
     return QF_OK;
   }
-  HIPCHK(c, c->d_fw.reserve(fw_bytes + 64));
+  if (reserve_big(c->d_fw, fw_bytes + 64, {&c->d_tb, &c->second.d_tb}) != hipSuccess) {
+    if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "cannot allocate " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices for one read");
+    *too_big = true;
+    return QF_OK;
+  }
   if (int rc = sort_class_lists(c, c, bc, max_units)) return rc;
   HIPCHK(c, c->d_weight.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_fwd_out.reserve((size_t)n_pairs * 8));
@@ -1224,8 +1266,8 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.counts = c->d_counts.as<double>();
   fa.counts_stride = (csize + 31) & ~31ull;
   fa.Km = sc.Km;
-  fa.no_band_shortcuts = (cfg->reserved >> 6) & 1;
-  const bool serial_classes = (cfg->reserved & 4) != 0;
+  fa.no_band_shortcuts = (c->debug & QF_DEBUG_NO_BAND_SHORTCUTS) != 0;
+  const bool serial_classes = (c->debug & QF_DEBUG_SERIAL_CLASSES) != 0;
   if (int rc = launch_classes_concurrently(c, bc, serial_classes, [&](int cls, hipStream_t s) {
         FbArgs f2 = fa;
         f2.n_cls_units = bc.cls_count[cls];
@@ -1478,12 +1520,16 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
 
   // ---- fill
   const uint64_t tb_bytes = (uint64_t)bc.tb_words * 4;
-  if (tb_bytes > c->tb_budget) {
+  if (tb_bytes > chunk_budget(c, c->d_tb, 1)) {
     if (n_pairs == 1) return fail(c, QF_ERR_MEMORY, "one pair needs " + std::to_string(tb_bytes >> 20) + " MiB of traceback, over the memory budget");
     *too_big = true;
     return QF_OK;
   }
-  HIPCHK(c, c->d_tb.reserve(tb_bytes + 64));
+  if (reserve_big(c->d_tb, tb_bytes + 64, {&c->d_fw, &c->second.d_tb}) != hipSuccess) {
+    if (n_pairs == 1) return fail(c, QF_ERR_MEMORY, "cannot allocate " + std::to_string(tb_bytes >> 20) + " MiB of traceback for one pair");
+    *too_big = true;
+    return QF_OK;
+  }
   if (int rc = sort_class_lists(c, c, bc, max_units, true)) return rc;
   HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
@@ -1506,7 +1552,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
   oa.lse = c->d_lse.as<double>();
   oa.min_score = c->min_score;
-  oa.no_lds_rows = (cfg->reserved >> 5) & 1;
+  oa.no_lds_rows = (c->debug & QF_DEBUG_GLOBAL_OVERLAP_ROWS) != 0;
   oa.Km = sc.Km;
   oa.Kg = sc.Kg;
   oa.pair_head = c->d_pair_head.as<uint32_t>();
@@ -1520,7 +1566,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.pair_end_ij = c->d_pair_ij.as<uint32_t>();
   oa.recs = c->d_recs.as<AlignRec>();
   oa.bc = c->d_bc.as<BatchCounters>();
-  if (int rc = launch_classes_concurrently(c, bc, (cfg->reserved & 4) != 0, [&](int cls, hipStream_t s) {
+  if (int rc = launch_classes_concurrently(c, bc, (c->debug & QF_DEBUG_SERIAL_CLASSES) != 0, [&](int cls, hipStream_t s) {
         if (cls > 10 && cls != kRowClass) return;
         OvArgs o2 = oa;
         o2.n_cls_units = bc.cls_count[cls];

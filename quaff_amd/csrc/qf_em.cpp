@@ -77,16 +77,25 @@ int fit_negbinom(const std::vector<double>& kFreq, double& pSuccess, double& nSu
     }
     n = 0.5 * (a + b);
   }
-  // gradientFitNegativeBinomial, :262-322: Newton on dLL/dn, relative step test 1e-4, runaway guard
+  // gradientFitNegativeBinomial, :262-322: Newton on dLL/dn, relative step test 1e-4 (gsl_root_test_delta with epsabs 0),
+  // runaway guard.  GSL's Newton step reports a zero derivative (GSL_EZERODIV) or a non-finite function value at the new
+  // point (GSL_EBADFUNC) as an error, and the reference then keeps the last root it had accepted (it reads the solver's root
+  // only after a successful iterate, :288-290): same here, with the status handed back (the reference's callers ignore it).
+  int status = 0;
+  double f = d1(n, kFreq), df = d2(n, kFreq);
   for (int it = 0; it < 100; ++it) {
-    const double nn = n - d1(n, kFreq) / d2(n, kFreq);
-    const bool done = fabs(nn - n) < 1e-4 * fabs(nn);
-    n = nn;
-    if (done || n > (double)kFreq.size()) break;
+    if (df == 0.0 || !std::isfinite(f) || !std::isfinite(df)) { status = 2; break; }
+    const double nn = n - f / df;
+    const double fn = d1(nn, kFreq), dfn = d2(nn, kFreq);
+    if (!std::isfinite(nn) || !std::isfinite(fn) || !std::isfinite(dfn)) { status = 2; break; }
+    const bool done = fabs(nn - n) < 1e-4 * fabs(nn) || nn == n;
+    n = nn; f = fn; df = dfn;
+    if (done) break;
+    if (n > (double)kFreq.size()) { status = 3; break; }   // GSL_ERUNAWAY
   }
   nSuccess = n;
   pSuccess = opt_p(n, kFreq);
-  return 0;
+  return status;
 }
 
 // ---------------------------------------------------------------------------- counts

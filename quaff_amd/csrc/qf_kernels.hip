@@ -103,62 +103,11 @@ __global__ void k_ref_kmer_scatter(const uint8_t* __restrict__ tok, const uint64
   pos[b + slot] = (uint32_t)i;
 }
 
-// One wavefront per read: tokens, packed per-column context words, seeding k-mers and the null-model
-// log-likelihood (FastSeq::tokens/kmers/qualScores src/fastseq.cpp:71-109; QuaffDPMatrix ctor
-// src/qmodel.cpp:1308-1324; QuaffNullParams::logLikelihood :1875-1890).
-__global__ __launch_bounds__(64) void k_prep_reads(PrepArgs a) {
-  const uint32_t r = blockIdx.x, lane = threadIdx.x;
-  const uint64_t b = a.off[r];
-  const uint32_t L = (uint32_t)(a.off[r + 1] - b);
-  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-  for (uint32_t i = lane; i < L; i += 64) {
-    int t = tokenize_char((unsigned char)a.seq[b + i]);
-    if (t < 0) {
-      atomicOr(&a.bc->error, 4u);
-      a.bc->error_detail = r;
-      t = 0;
-    }
-    a.tok[b + i] = (uint8_t)t;
-    cnt0 += t == 0; cnt1 += t == 1; cnt2 += t == 2; cnt3 += t == 3;
-  }
-  for (int o = 32; o; o >>= 1) {
-    cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
-    cnt2 += __shfl_xor(cnt2, o); cnt3 += __shfl_xor(cnt3, o);
-  }
-  // most frequent token, first maximum on ties (max_element, src/fastseq.cpp:92)
-  uint32_t padTok = 0, best = cnt0;
-  if (cnt1 > best) { best = cnt1; padTok = 1; }
-  if (cnt2 > best) { best = cnt2; padTok = 2; }
-  if (cnt3 > best) { best = cnt3; padTok = 3; }
-  auto tokAt = [&](int64_t p) -> uint32_t {
-    if (p < 0) return padTok;
-    int t = tokenize_char((unsigned char)a.seq[b + p]);
-    return t < 0 ? 0u : (uint32_t)t;
-  };
-  for (uint32_t i = lane; i < L; i += 64) {
-    uint32_t mk = 0, gk = 0;
-    for (uint32_t c = 0; c < a.match_len; ++c) mk = mk * 4 + tokAt((int64_t)i - (a.match_len - 1) + c);
-    for (uint32_t c = 0; c < a.gap_len; ++c) gk = gk * 4 + tokAt((int64_t)i - (a.gap_len - 1) + c);
-    uint32_t q = kNQualDev;  // slot 94: no quality scores
-    if (a.qual) {
-      int v = (int)(signed char)a.qual[b + i] - '!';
-      q = (uint32_t)max(0, min(kNQualDev - 1, v));
-    }
-    const uint32_t t = tokAt(i);
-    a.ctx[b + i] = ctx_pack(mk * (kNQualDev + 1) + q, t * (kNQualDev + 1) + q, gk);
-    if (a.seed_k && i + a.seed_k <= L) {
-      unsigned long long sk = 0;
-      for (uint32_t c = 0; c < a.seed_k; ++c) sk = sk * 4 + tokAt(i + c);
-      if (a.skmer64) a.skmer64[b + i] = sk; else a.skmer[b + i] = (uint32_t)sk;
-    }
-  }
-}
-
-
-// k_prep_reads2: the same outputs as k_prep_reads, sixteen bases per lane.  The byte-at-a-time version spends its time in
-// ~10 single-byte gathers per base (every base re-reads its context and seed-k-mer neighbours); here each base is
-// tokenised once (SWAR on 4 characters), staged in LDS, and the context / seeding k-mers roll over a 48-token register
-// window.  One wavefront per read, 1024 bases per tile.  Seeding k-mers are produced by their LAST base (the k-mer that
+// k_prep_reads2: one wavefront per read, sixteen bases per lane: tokens, packed per-column context words and seeding k-mers
+// (FastSeq::tokens/kmers/qualScores src/fastseq.cpp:71-109; QuaffDPMatrix ctor src/qmodel.cpp:1308-1324).  A
+// byte-at-a-time version spends its time in ~10 single-byte gathers per base (every base re-reads its context and
+// seed-k-mer neighbours); here each base is tokenised once (SWAR on 4 characters), staged in LDS, and the context /
+// seeding k-mers roll over a 48-token register window.  One wavefront per read, 1024 bases per tile.  Seeding k-mers are produced by their LAST base (the k-mer that
 // starts at i is stored when base i + k - 1 is reached), so the window only looks backwards.
 struct __attribute__((packed, aligned(1))) C16 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(4))) W4a { uint32_t v[4]; };
@@ -1005,173 +954,8 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
 // QuaffViterbiMatrix::alignment's updateMax sequence would choose them (src/qmodel.cpp:1590-1616).
 // ------------------------------------------------------------------------------------------------
 
-template <int G, int B, bool GAPCTX>
-__global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
-  constexpr int UPW = 64 / G;
-  constexpr int WPL = B > 8 ? 2 : 1;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int grp = lane / G, l = lane % G;
-  const uint32_t uidx = wave * UPW + grp;
-  const bool active = uidx < a.n_cls_units;
-
-  uint32_t uid = 0;
-  int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
-  uint64_t xb = 0, yb = 0, xw = 0, tb_off = 0;
-  if (active) {
-    uid = a.cls_list[uidx];
-    const Unit u = a.units[uid];
-    const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
-    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb); xw = a.ref_woff[x];
-    yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
-    dlo = u.dlo; dhi = u.dhi; tb_off = u.tb_off;
-  }
-  int T = active ? yLen + G - 1 : 0;
-  for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
-
-  const int d0 = dlo + l * B;
-  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
-  const double* __restrict__ ematch = a.dp.ematch;
-  const double* __restrict__ eins = a.dp.eins;
-  const double* __restrict__ trans = a.dp.trans;
-  const uint32_t Kg = a.dp.Kg;
-  const bool local = a.dp.local != 0;
-  const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg], c_m2e = trans[3 * Kg];
-
-  double M[B], I[B], D[B];
-#pragma unroll
-  for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
-  double pubM = QF_NEG_INF, pubD = QF_NEG_INF;  // this lane's last slot (mat, del) after its latest step
-  double bestEnd = QF_NEG_INF;
-  uint32_t bestI = 0;
-
-  // reference tokens: 2-bit packed words, a 64-bit window (lo:hi) refreshed every 16 steps, one word
-  // prefetched ahead.  rtop(t) = 0-based reference index of the top slot's row at step t.
-  const uint32_t* __restrict__ xp = a.ref_packed + xw;
-  const int nxw = (xLen + 15) / 16 + 2;
-  const int rtop0 = d0 - l + B - 1;
-  const int q0 = rtop0 >> 4, sh0 = 2 * (rtop0 & 15);
-  auto xword = [&](int q) -> uint32_t { return xp[min(max(q, 0), nxw - 1)]; };
-  uint32_t xlo, xhi = xword(q0), xnx = xword(q0 + 1);
-  // token window: slot b at bits 2b; initialised with the rows the first step still needs
-  uint32_t win = 0;
-  {
-    const uint8_t* xt = a.ref_tok + xb;
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int row = d0 - l - 1 + b;
-      const uint32_t t = (row >= 0 && row < xLen) ? xt[row] : 0u;
-      win |= t << (2 * b);
-    }
-  }
-  // read context words, 4 columns per load, one load ahead
-  const uint32_t* __restrict__ ctx = a.ctx + yb;  // padded: indices -kCtxPad .. +kCtxPad beyond the data are readable
-  U32x4 cwn = *(const U32x4*)(ctx + (0 - l));     // columns j = t-l+1 for t = 0..3 -> index j-1 = t-l
-  uint32_t gkPrev = 0;
-  uint32_t* __restrict__ tb = a.tb + tb_off;
-
-  int chunk = 0;
-  for (int t0 = 0; t0 < T; t0 += 16, ++chunk) {
-    xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
-    const unsigned long long xpair = ((unsigned long long)xhi << 32) | xlo;
-    for (int s4 = 0; s4 < 16; s4 += 4) {
-      const U32x4 cw = cwn;
-      cwn = *(const U32x4*)(ctx + min(t0 + s4 + 4 - l, yLen + 4));
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int t = t0 + s4 + s;
-        const int j = t - l + 1;
-        const bool colvalid = active && j >= 1 && j <= yLen;
-        const uint32_t w = cw.v[s];
-        const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
-        double m2m, m2i, m2d;
-        if (GAPCTX) {
-          const uint32_t gp = j <= 1 ? 0u : gkPrev;  // yIndelKmer is padded with a leading 0 (qmodel.cpp:1322)
-          m2m = trans[gp]; m2i = trans[Kg + gp]; m2d = trans[2 * Kg + gk];
-          gkPrev = gk;
-        } else {
-          m2m = c_m2m; m2i = c_m2i; m2d = c_m2d;
-        }
-        const double insE = eins[insrow];
-        const uint32_t newTok = (uint32_t)(xpair >> (sh0 + 2 * (s4 + s))) & 3u;
-        win = (win >> 2) | (newTok << (2 * (B - 1)));
-
-        // neighbour below (diagonal d0-1, this column): lane l-1 published it at the end of the last step
-        double lowM = __shfl_up(pubM, 1, G), lowD = __shfl_up(pubD, 1, G);
-        if (l == 0) { lowM = QF_NEG_INF; lowD = QF_NEG_INF; }
-
-        double e[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) e[b] = ematch[erow4 + ((win >> (2 * b)) & 3u)];
-
-        const bool startCol = j == 1;
-        const bool endCol = j == yLen;
-        uint32_t tbw0 = 0, tbw1 = 0;
-        double nM0 = 0, nI0 = 0;  // new slot-0 values, handed to lane l-1
-        double upM = 0, upI = 0;  // lane l+1's new slot-0 values (its column is j-1)
-        double prevM = lowM, prevD = lowD;
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-          const int d = d0 + b, i = d + j;
-          const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
-          // match state: candidates in traceback order M, I, D, Start (strict >)
-          const double tM = (M[b] + m2m) + e[b], tI = (I[b] + i2m) + e[b], tD = (D[b] + d2m) + e[b];
-          double nm = tM;
-          uint32_t sm = 0;
-          if (tI > nm) { nm = tI; sm = 1; }
-          if (tD > nm) { nm = tD; sm = 2; }
-          if (startCol && (i == 1 || local) && e[b] > nm) { nm = e[b]; sm = 3; }
-          // insert state: sources on diagonal d+1, previous column (M first, then I)
-          double srcM, srcI;
-          if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; }
-          else { srcM = upM; srcI = upI; }
-          const double cM = (srcM + m2i) + insE, cI = (srcI + i2i) + insE;
-          double ni = cM;
-          uint32_t si = 0;
-          if (cI > ni) { ni = cI; si = 1; }
-          // delete state: sources on diagonal d-1, this column (M first, then D)
-          const double gM = prevM + m2d, gD = prevD + d2d;
-          double ndl = gM;
-          uint32_t sd = 0;
-          if (gD > ndl) { ndl = gD; sd = 1; }
-          if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
-          M[b] = nm; I[b] = ni; D[b] = ndl;
-          prevM = nm; prevD = ndl;
-          const uint32_t nib = sm | (si << 2) | (sd << 3);
-          if (b < 8) tbw0 |= nib << (4 * (b & 7)); else tbw1 |= nib << (4 * (b & 7));
-          if (endCol && valid && (local || i == xLen)) {
-            const double ev = nm + (GAPCTX ? trans[3 * Kg + gk] : c_m2e);
-            if (ev >= bestEnd) { bestEnd = ev; bestI = (uint32_t)i; }
-          }
-          if (b == 0) {
-            nM0 = nm; nI0 = ni;
-            // slot 0 of every lane is done: fetch lane l+1's (it is one column behind, i.e. column j-1)
-            upM = __shfl_down(nM0, 1, G); upI = __shfl_down(nI0, 1, G);
-            if (l == G - 1) { upM = QF_NEG_INF; upI = QF_NEG_INF; }
-          }
-        }
-        pubM = prevM; pubD = prevD;
-        if (colvalid) {
-          if (WPL == 1) tb[tb_word_index(t, l, G)] = tbw0;
-          else { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
-        }
-      }
-    }
-  }
-  // end cell of the unit: max value, largest row on ties (lanes hold ascending rows)
-  for (int o = 1; o < G; o <<= 1) {
-    const double ov = __shfl_xor(bestEnd, o, G);
-    const uint32_t oi = __shfl_xor(bestI, o, G);
-    if (ov > bestEnd || (ov == bestEnd && oi > bestI)) { bestEnd = ov; bestI = oi; }
-  }
-  if (active && l == 0) {
-    a.units[uid].end_val = bestEnd;
-    a.units[uid].end_i = bestI;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_viterbi_fill2: the same wavefront and the same bits as k_viterbi_fill, with a trimmed instruction stream.
+// k_viterbi_fill: the wavefront described above with a trimmed instruction stream.
 //  * Every step is classified wave-uniformly.  A FAST step has no lane on its first or last read column and no lane
 //    whose band pokes above reference row 1; it needs no start candidate, no end tracking and no row/column validity
 //    masking (cells before a lane's first column are -inf by construction, cells below the last reference row or
@@ -1210,7 +994,7 @@ __device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y
 }
 
 template <int G, int B, bool GAPCTX, bool EMLDS>
-__global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
+__global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
   // EMLDS: the match-emission table (+ its -inf row) and the insert-emission table are copied to LDS once per workgroup.
   // Every lane of a wavefront is on a different read column, so the B emission fetches of a step are 64-way gathers;
   // through the vector L1 those gathers, not the arithmetic, bound the kernel (measured), LDS serves them far faster.
@@ -1460,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_viterbi_fill2(FillArgs a) {
 // the match state is a serial chain.  One lane per unit, 8 traceback nibbles per word.
 template <bool EMLDS>
 __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
-  // EMLDS: match-emission table in LDS (see k_viterbi_fill2).  The chain of a lane is serial, so what a round costs is the
+  // EMLDS: match-emission table in LDS (see k_viterbi_fill).  The chain of a lane is serial, so what a round costs is the
   // latency of its eight emission gathers: ~100 cycles from LDS against ~800 from L2.
   extern __shared__ double lds_tab[];
   if (EMLDS) {
@@ -1569,7 +1353,7 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
 template <bool EMLDS>
 __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   constexpr int G = kVitLanes, B = 8, S = kVitStripe, NW = kVitWaves;
-  // EMLDS: emission tables in LDS (see k_viterbi_fill2): the eight emission fetches of a step are gathers
+  // EMLDS: emission tables in LDS (see k_viterbi_fill): the eight emission fetches of a step are gathers
   extern __shared__ double lds_tab[];
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
   if (EMLDS) {
@@ -1681,7 +1465,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       double aboveM = upM, aboveD = upD;
       // FAST step (wave-uniform): every lane is on an inner column (not the first or last read column) and all eight of
       // its cells are inside the band and the matrix: no start candidate, no end tracking, no masking; values by
-      // v_max_f64, flags as raw compare bits (see k_viterbi_fill2)
+      // v_max_f64, flags as raw compare bits (see k_viterbi_fill)
       const bool laneFast = colvalid && j > 1 && j < yLen && i0 >= 1 && i0 + B - 1 <= xLen && i0 - j >= dlo && i0 + B - 1 - j <= dhi;
       if (__builtin_amdgcn_ballot_w64(!laneFast) == 0) {
         uint32_t acc = 0;
@@ -2021,18 +1805,15 @@ __global__ __launch_bounds__(kTbLanes) void k_traceback(FinalArgs a) {
 template <int G, int B>
 static void launch_fill_gb(const FillArgs& a, bool gapctx, hipStream_t s) {
   const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
-  if (a.reference_kernel) {  // the first-generation kernel, kept for A/B and as a cross-check (same results)
-    if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_viterbi_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
-  } else {
+  {
     // emission tables in LDS when three workgroups' copies fit a CU's 160 KB (match contexts of up to 2 bases)
     const uint32_t lds_bytes = a.dp.ematch_ninf_off + 32 + kInsRows * 8;
     if (lds_bytes <= 52 * 1024 && !a.no_lds_tables) {
-      if (gapctx) hipLaunchKernelGGL((k_viterbi_fill2<G, B, true, true>), dim3(blocks), dim3(256), lds_bytes, s, a);
-      else hipLaunchKernelGGL((k_viterbi_fill2<G, B, false, true>), dim3(blocks), dim3(256), lds_bytes, s, a);
+      if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true, true>), dim3(blocks), dim3(256), lds_bytes, s, a);
+      else hipLaunchKernelGGL((k_viterbi_fill<G, B, false, true>), dim3(blocks), dim3(256), lds_bytes, s, a);
     } else {
-      if (gapctx) hipLaunchKernelGGL((k_viterbi_fill2<G, B, true, false>), dim3(blocks), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((k_viterbi_fill2<G, B, false, false>), dim3(blocks), dim3(256), 0, s, a);
+      if (gapctx) hipLaunchKernelGGL((k_viterbi_fill<G, B, true, false>), dim3(blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_viterbi_fill<G, B, false, false>), dim3(blocks), dim3(256), 0, s, a);
     }
   }
 }
@@ -2086,8 +1867,7 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
 }
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;
-  if (a.byte_kernel) hipLaunchKernelGGL(k_prep_reads, dim3(n_reads), dim3(64), 0, s, a);
-  else if (a.skmer64) hipLaunchKernelGGL(k_prep_reads2<true>, dim3(n_reads), dim3(64), 0, s, a);
+  if (a.skmer64) hipLaunchKernelGGL(k_prep_reads2<true>, dim3(n_reads), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_prep_reads2<false>, dim3(n_reads), dim3(64), 0, s, a);
 }
 void launch_null_ll(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {

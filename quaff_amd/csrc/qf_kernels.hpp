@@ -32,7 +32,6 @@ struct PrepArgs {
   double* ins_sum_c;       // [n] same with complemented tokens
   double* nll_c;           // [n] null log-likelihood of the reverse complement
   BatchCounters* bc;
-  int byte_kernel;         // 1: the first-generation one-base-per-lane prep kernel (debug / A-B)
 };
 
 struct SeedArgs {
@@ -87,7 +86,6 @@ struct FillArgs {
   const uint32_t* ctx;         // offset past the front pad
   uint32_t* tb;
   DpParams dp;
-  int reference_kernel;        // 1: launch the first-generation fill kernel (debug / A-B)
   int no_lds_tables;           // 1: keep the emission tables in global memory even when they fit LDS (debug / A-B)
 };
 

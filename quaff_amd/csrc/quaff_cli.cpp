@@ -14,6 +14,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <set>
 #include <sstream>
@@ -124,81 +125,94 @@ static vector<FastSeq> readFastSeqs(const string& filename) {
 }
 
 // ------------------------------------------------------------------------------------------ alignments
-struct Alignment {  // src/qmodel.h:235-254
-  FastSeq row[2];
+// A pairwise alignment in the form the device returns it: edit runs over an interval of each source sequence.  Every
+// output format is produced from the runs (the reference materialises gapped rows first and derives CIGAR strings and
+// ungapped sequences back from them, src/qmodel.cpp:553-676; the bytes written are the same).
+//   run = (length << 2) | op;  op 0: a column with a base of x and a base of y,  1: y only (x gapped),  2: x only (y gapped)
+struct Hit {
+  const FastSeq* src[2] = {nullptr, nullptr};   // x (reference / read_x), y (read / read_y)
+  unsigned lo[2] = {0, 0};                      // 1-based position of the first source base each side covers
+  vector<uint32_t> runs;
+  string label[2], note[2];                     // row names and "#=GS CC" comments
+  Coords origin[2];                             // the covered intervals in the coordinates of the original (unreversed) input
   double score = -INFINITY;
-  size_t columns() const { return row[0].seq.size(); }
-};
-static bool isGap(char c) { return c == '-' || c == '.'; }
 
-static string cigarString(const Alignment& a) {  // src/qmodel.cpp:625-653 (letter before count)
-  string cigar;
-  char last = 0;
-  size_t count = 0;
-  for (size_t col = 0; col < a.columns(); ++col) {
-    const bool g0 = isGap(a.row[0].seq[col]), g1 = isGap(a.row[1].seq[col]);
-    const char c = (!g0 && !g1) ? 'M' : (!g0 && g1) ? 'D' : (g0 && !g1) ? 'I' : 0;
-    if (!c) continue;
-    if (c == last) ++count;
-    else { if (count) cigar += last + to_string(count); last = c; count = 1; }
+  static bool consumes(int side, uint32_t op) { return op == 0 || op == (side == 0 ? 2u : 1u); }
+  size_t columns() const {
+    size_t n = 0;
+    for (uint32_t r : runs) n += r >> 2;
+    return n;
   }
-  if (count) cigar += last + to_string(count);
-  return cigar;
+  size_t span(int side) const {   // source bases covered
+    size_t n = 0;
+    for (uint32_t r : runs) if (consumes(side, r & 3u)) n += r >> 2;
+    return n;
+  }
+  // the side's bases (or quality characters) laid out over the alignment columns, `gap` where the side has none
+  string laidOut(int side, bool quality, char gap) const {
+    const string& text = quality ? src[side]->qual : src[side]->seq;
+    string out;
+    out.reserve(columns());
+    size_t at = lo[side] - 1;
+    for (uint32_t r : runs) {
+      const uint32_t len = r >> 2;
+      if (consumes(side, r & 3u)) { out.append(text, at, len); at += len; }
+      else out.append(len, gap);
+    }
+    return out;
+  }
+  string covered(int side, bool quality) const { return (quality ? src[side]->qual : src[side]->seq).substr(lo[side] - 1, span(side)); }
+  // Alignment::cigarString (letter before count); backwards = the alignment seen from the other strand
+  string cigar(bool backwards) const {
+    vector<uint32_t> rr(runs);
+    if (backwards) reverse(rr.begin(), rr.end());
+    string out(qf_cigar_string(rr.data(), (uint32_t)rr.size(), nullptr, 0), '\0');
+    if (!out.empty()) { out.push_back('\0'); qf_cigar_string(rr.data(), (uint32_t)rr.size(), &out[0], out.size()); out.pop_back(); }
+    return out;
+  }
+};
+
+// adjacent runs of the same op become one (the device never emits such neighbours; the overlap re-pairing below can)
+static void appendRun(vector<uint32_t>& runs, uint32_t op, size_t len) {
+  if (!len) return;
+  if (!runs.empty() && (runs.back() & 3u) == op) runs.back() += (uint32_t)len << 2;
+  else runs.push_back(((uint32_t)len << 2) | op);
 }
 
-static void writeStockholm(ostream& out, const Alignment& a) {  // src/qmodel.cpp:553-606
-  vector<string> rowName, rowData;
-  vector<size_t> rowIndex;
-  for (const auto& s : a.row) {
-    rowIndex.push_back(rowName.size());
-    rowName.push_back(s.name);
-    rowData.push_back(s.seq);
-    if (s.hasQual()) { rowName.push_back("#=GR " + s.name + " QS"); rowData.push_back(s.qual); }
-  }
-  string cons;
-  for (size_t pos = 0; pos < a.columns(); ++pos) {
-    const char c0 = toupper(a.row[0].seq[pos]), c1 = toupper(a.row[1].seq[pos]);
-    cons.push_back((isGap(c0) || isGap(c1)) ? '-' : (c0 == c1 ? c0 : ':'));
-  }
-  rowName.insert(rowName.begin() + rowIndex[1], "#=GC id");
-  rowData.insert(rowData.begin() + rowIndex[1], cons);
-  if (a.row[0].hasQual()) { swap(rowName[0], rowName[1]); swap(rowData[0], rowData[1]); }
-  size_t nameWidth = 0;
-  for (const auto& s : rowName) nameWidth = max(s.size(), nameWidth);
-  const size_t dataWidth = max(nameWidth, 79 - nameWidth);
-  out << "# STOCKHOLM 1.0" << endl;
-  out << "#=GF Score " << fmt6(a.score) << endl;
-  for (const auto& s : a.row) if (s.comment.size()) out << "#=GS CC " << s.name << ' ' << s.comment << endl;
-  for (size_t col = 0; col < a.columns(); col += dataWidth) {
-    if (col > 0) out << endl;
-    for (size_t r = 0; r < rowName.size(); ++r) {
-      string nm = rowName[r];
-      nm.resize(max(nm.size(), nameWidth), ' ');
-      out << nm << ' ' << rowData[r].substr(col, dataWidth) << endl;
-    }
+// Stockholm block (writeStockholm, src/qmodel.cpp:553-606): quality lines outside, the identity line between the rows
+static void writeStockholm(ostream& out, const Hit& h) {
+  const string xs = h.laidOut(0, false, '-'), ys = h.laidOut(1, false, '-');
+  string ident(xs.size(), '-');
+  for (size_t c = 0; c < xs.size(); ++c)
+    if (xs[c] != '-' && ys[c] != '-') ident[c] = toupper(xs[c]) == toupper(ys[c]) ? (char)toupper(xs[c]) : ':';
+  vector<pair<string, string>> lines;
+  if (h.src[0]->hasQual()) lines.push_back({"#=GR " + h.label[0] + " QS", h.laidOut(0, true, '~')});
+  lines.push_back({h.label[0], xs});
+  lines.push_back({"#=GC id", ident});
+  lines.push_back({h.label[1], ys});
+  if (h.src[1]->hasQual()) lines.push_back({"#=GR " + h.label[1] + " QS", h.laidOut(1, true, '~')});
+  size_t tag = 0;
+  for (const auto& l : lines) tag = max(tag, l.first.size());
+  const size_t perBlock = max(tag, 79 - tag);
+  out << "# STOCKHOLM 1.0" << endl << "#=GF Score " << fmt6(h.score) << endl;
+  for (int k = 0; k < 2; ++k) if (h.note[k].size()) out << "#=GS CC " << h.label[k] << ' ' << h.note[k] << endl;
+  for (size_t c = 0; c < xs.size(); c += perBlock) {
+    if (c) out << endl;
+    for (const auto& l : lines) out << l.first << string(tag - l.first.size(), ' ') << ' ' << l.second.substr(c, perBlock) << endl;
   }
   out << "//" << endl;
 }
 
-static Alignment revcompAlignment(const Alignment& a) {  // Alignment::revcomp, src/qmodel.cpp:655-660
-  Alignment r = a;
-  for (int k = 0; k < 2; ++k) r.row[k] = revcomp(a.row[k]);
-  return r;
-}
-static void writeSam(ostream& out, const Alignment& a) {  // src/qmodel.cpp:608-616
-  if (a.row[0].source.rev) { writeSam(out, revcompAlignment(a)); return; }
-  const int flag = a.row[1].source.rev ? 16 : 0;
-  out << a.row[1].source.name << '\t' << flag << '\t' << a.row[0].source.name << '\t' << a.row[0].source.start << "\t0\t"
-      << cigarString(a) << "\t*\t0\t0\t*\t*\tAS:i:" << ((int)round(a.score)) << endl;
-}
-static FastSeq getUngapped(const Alignment& a, int r) {  // src/qmodel.cpp:662-676
-  const FastSeq& g = a.row[r];
-  FastSeq s = g;
-  s.seq.clear();
-  s.qual.clear();
-  for (size_t i = 0; i < g.seq.size(); ++i)
-    if (!isGap(g.seq[i])) { s.seq.push_back(g.seq[i]); if (g.hasQual()) s.qual.push_back(g.qual[i]); }
-  return s;
+// SAM record (writeSam, src/qmodel.cpp:608-616).  An alignment against a reverse-complemented reference is reported on
+// the reference's forward strand: the reference flips the whole alignment first (Alignment::revcomp, :655-660), so the
+// read's strand bit toggles, the CIGAR reads backwards, and - because FastSeq::revcomp (src/fastseq.cpp:218-230) composes
+// the coordinates from the length of the GAPPED row - the position printed is end - columns + 1, not the interval's start.
+static void writeSam(ostream& out, const Hit& h) {
+  const bool flip = h.origin[0].rev;
+  const bool readRev = h.origin[1].rev != flip;
+  const unsigned pos = flip ? h.origin[0].end - (unsigned)h.columns() + 1 : h.origin[0].start;
+  out << h.origin[1].name << '\t' << (readRev ? 16 : 0) << '\t' << h.origin[0].name << '\t' << pos << "\t0\t"
+      << h.cigar(flip) << "\t*\t0\t0\t*\t*\tAS:i:" << ((int)round(h.score)) << endl;
 }
 
 struct Printer {  // QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600
@@ -231,19 +245,22 @@ struct Printer {  // QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600
       for (const auto& s : refs) if (s.source.isNull()) o << "@SQ\tSN:" << s.name << "\tLN:" << s.seq.size() << endl;
     }
   }
-  void write(ostream& out, const Alignment& a) {  // writeAlignment :2566-2600
-    if (!(a.score >= threshold)) return;
+  void write(ostream& out, const Hit& h) {  // writeAlignment :2566-2600
+    if (!(h.score >= threshold)) return;
     ostream& o = stream(out);
+    auto fasta = [&](const string& name, const string& comment, const string& text) {
+      o << '>' << name;
+      if (comment.size()) o << ' ' << comment;
+      o << endl << text << endl;
+    };
     switch (format) {
-      case Fasta: writeFasta(o, a.row[0]); writeFasta(o, a.row[1]); out << endl; break;
-      case Stockholm: writeStockholm(o, a); break;
-      case Sam: writeSam(o, a); break;
-      case Refseq: {
-        FastSeq ref = getUngapped(a, 0);
-        ref.comment = "matches(" + a.row[1].name + ") " + ref.comment;
-        writeFasta(o, ref);
+      case Fasta:
+        for (int k = 0; k < 2; ++k) fasta(h.label[k], h.note[k], h.laidOut(k, false, '-'));
+        out << endl;
         break;
-      }
+      case Stockholm: writeStockholm(o, h); break;
+      case Sam: writeSam(o, h); break;
+      case Refseq: fasta(h.label[0], "matches(" + h.label[1] + ") " + h.note[0], h.covered(0, false)); break;   // Alignment::getUngapped(0)
     }
   }
 };
@@ -465,31 +482,23 @@ struct Session {
   }
 };
 
-// gapped rows of a read-to-reference alignment from its CIGAR runs (QuaffViterbiMatrix::alignment, src/qmodel.cpp:1577-1645)
-static Alignment makeAlignment(const FastSeq& x, const FastSeq& y, const qf_alignment& al, const uint32_t* runs, bool local) {
-  Alignment a;
-  string &xr = a.row[0].seq, &yr = a.row[1].seq, &yq = a.row[1].qual;
-  size_t i = al.x_start - 1, j = 0;
-  const bool hq = y.hasQual();
-  for (uint32_t r = 0; r < al.n_runs; ++r) {
-    const uint32_t op = runs[r] & 3u, len = runs[r] >> 2;
-    for (uint32_t c = 0; c < len; ++c) {
-      if (op == 0) { xr += x.seq[i++]; yr += y.seq[j]; if (hq) yq += y.qual[j]; ++j; }
-      else if (op == 1) { xr += '-'; yr += y.seq[j]; if (hq) yq += y.qual[j]; ++j; }
-      else { xr += x.seq[i++]; yr += '-'; if (hq) yq += '~'; }
-    }
-  }
-  a.row[0].name = "Ref";
-  a.row[0].comment = local ? "substr(" + x.name + "," + to_string(al.x_start) + ".." + to_string(al.x_end) + ")" : x.name;
-  a.row[1].name = "Read";
-  a.row[1].comment = y.name;
+// a read-to-reference alignment as `quaff align` labels it (QuaffViterbiMatrix::alignment, src/qmodel.cpp:1623-1645)
+static Hit makeAlignment(const FastSeq& x, const FastSeq& y, const qf_alignment& al, const uint32_t* runs, bool local) {
+  Hit h;
+  h.src[0] = &x; h.src[1] = &y;
+  h.lo[0] = al.x_start; h.lo[1] = 1;
+  h.runs.assign(runs, runs + al.n_runs);
+  h.label[0] = "Ref";
+  h.note[0] = local ? "substr(" + x.name + "," + to_string(al.x_start) + ".." + to_string(al.x_end) + ")" : x.name;
+  h.label[1] = "Read";
+  h.note[1] = y.name;
   Coords cx, cy;
   cx.name = x.name; cx.start = al.x_start; cx.end = al.x_end;
   cy.name = y.name; cy.start = 1; cy.end = (unsigned)y.seq.size();
-  a.row[0].source = cx.compose(x.source);
-  a.row[1].source = cy.compose(y.source);
-  a.score = al.score;
-  return a;
+  h.origin[0] = cx.compose(x.source);
+  h.origin[1] = cy.compose(y.source);
+  h.score = al.score;
+  return h;
 }
 
 static int cmdAlign(Opts& o) {
@@ -517,7 +526,7 @@ static int cmdAlign(Opts& o) {
   const size_t batch = max<size_t>(1, min<size_t>({(size_t)65536, perCall, (n + G - 1) / G}));
   for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
     const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
-    vector<vector<Alignment>> got(nrun);
+    vector<vector<Hit>> got(nrun);
     onDevices(nrun, [&](size_t k) {
       const size_t lo = lo0 + k * batch, hi = min(n, lo + batch);
       qf_ctx* c = s.ctxs[k];
@@ -533,7 +542,7 @@ static int cmdAlign(Opts& o) {
         got[k].push_back(makeAlignment(refs.seqs[al.ref], reads.seqs[lo + al.read], al, res.cigar_runs + al.run_offset, o.cfg.local));
       }
     });
-    for (const auto& block : got) for (const Alignment& a : block) pr.write(cout, a);
+    for (const auto& block : got) for (const Hit& h : block) pr.write(cout, h);
   }
   return EXIT_SUCCESS;
 }
@@ -705,39 +714,33 @@ static int cmdTrainOrCount(Opts& o, bool training) {
   return EXIT_SUCCESS;
 }
 
-// gapped rows of an overlap alignment with the reference's indel squashing (src/qoverlap.cpp:231-289)
-static Alignment makeOverlapAlignment(const FastSeq& x, const FastSeq& y, const qf_overlap_alignment& al, const uint32_t* runs) {
-  Alignment a;
-  string &xr = a.row[0].seq, &yr = a.row[1].seq, &xq = a.row[0].qual, &yq = a.row[1].qual;
-  const bool hx = x.hasQual(), hy = y.hasQual();
-  size_t i = al.x_start - 1, j = al.y_start - 1;
-  uint32_t r = 0;
-  while (r < al.n_runs) {
-    if ((runs[r] & 3u) == 0) {
-      for (uint32_t c = 0; c < (runs[r] >> 2); ++c) { xr += x.seq[i]; yr += y.seq[j]; if (hx) xq += x.qual[i]; if (hy) yq += y.qual[j]; ++i; ++j; }
-      ++r;
-      continue;
-    }
-    size_t nins = 0, ndel = 0;
-    while (r < al.n_runs && (runs[r] & 3u) != 0) { ((runs[r] & 3u) == 1 ? nins : ndel) += runs[r] >> 2; ++r; }
-    const size_t shared = min(nins, ndel);
-    xr += x.seq.substr(i, ndel) + string(nins - shared, '-');
-    yr += y.seq.substr(j, shared) + string(ndel - shared, '-') + y.seq.substr(j + shared, nins - shared);
-    if (hx) xq += x.qual.substr(i, ndel) + string(nins - shared, '~');
-    if (hy) yq += y.qual.substr(j, shared) + string(ndel - shared, '~') + y.qual.substr(j + shared, nins - shared);
-    i += ndel; j += nins;
+// An overlap alignment as `quaff overlap` prints it.  The reference re-pairs every stretch of gap states between two
+// match stretches when it writes the rows (src/qoverlap.cpp:231-267): of `nd` x-only and `ni` y-only columns, min(nd, ni)
+// become ordinary two-base columns (x's bases in order against y's), and only the excess stays gapped, after them.
+static Hit makeOverlapAlignment(const FastSeq& x, const FastSeq& y, const qf_overlap_alignment& al, const uint32_t* runs) {
+  Hit h;
+  h.src[0] = &x; h.src[1] = &y;
+  h.lo[0] = al.x_start; h.lo[1] = al.y_start;
+  for (uint32_t r = 0; r < al.n_runs;) {
+    if ((runs[r] & 3u) == 0) { appendRun(h.runs, 0, runs[r] >> 2); ++r; continue; }
+    size_t only[3] = {0, 0, 0};   // [1] y-only (insert states), [2] x-only (delete states)
+    for (; r < al.n_runs && (runs[r] & 3u) != 0; ++r) only[runs[r] & 3u] += runs[r] >> 2;
+    const size_t paired = min(only[1], only[2]);
+    appendRun(h.runs, 0, paired);
+    appendRun(h.runs, 2, only[2] - paired);
+    appendRun(h.runs, 1, only[1] - paired);
   }
-  a.row[0].name = "read_x";
-  a.row[0].comment = "substr(" + x.name + "," + to_string(al.x_start) + ".." + to_string(al.x_end) + ")";
-  a.row[1].name = "read_y";
-  a.row[1].comment = "substr(" + y.name + "," + to_string(al.y_start) + ".." + to_string(al.y_end) + ")";
+  h.label[0] = "read_x";
+  h.note[0] = "substr(" + x.name + "," + to_string(al.x_start) + ".." + to_string(al.x_end) + ")";
+  h.label[1] = "read_y";
+  h.note[1] = "substr(" + y.name + "," + to_string(al.y_start) + ".." + to_string(al.y_end) + ")";
   Coords cx, cy;
   cx.name = x.name; cx.start = al.x_start; cx.end = al.x_end;
   cy.name = y.name; cy.start = al.y_start; cy.end = al.y_end;
-  a.row[0].source = cx.compose(x.source);
-  a.row[1].source = cy.compose(y.source);
-  a.score = al.score;
-  return a;
+  h.origin[0] = cx.compose(x.source);
+  h.origin[1] = cy.compose(y.source);
+  h.score = al.score;
+  return h;
 }
 
 static int cmdOverlap(Opts& o) {
@@ -772,7 +775,7 @@ static int cmdOverlap(Opts& o) {
   auto flush = [&]() {
     if (pend.back().n == 0) pend.pop_back();
     if (pend.empty()) { pend.emplace_back(); return; }
-    vector<vector<Alignment>> got(pend.size());
+    vector<vector<Hit>> got(pend.size());
     onDevices(pend.size(), [&](size_t k) {
       const Block& b = pend[k];
       vector<uint32_t> px(b.n), py(b.n);
@@ -792,7 +795,7 @@ static int cmdOverlap(Opts& o) {
         got[k].push_back(makeOverlapAlignment(reads.seqs[px[al.pair]], reads.seqs[py[al.pair]], al, res.state_runs + al.run_offset));
       }
     });
-    for (const auto& block : got) for (const Alignment& a : block) pr.write(cout, a);
+    for (const auto& block : got) for (const Hit& h : block) pr.write(cout, h);
     pend.assign(1, Block());
   };
   for (size_t nx = 0; nx + 1 < N; ++nx)
@@ -859,6 +862,14 @@ static int cmdSelfTest(deque<string>& av) {
     const int status = fit_negbinom(kFreq, pFit, rFit);
     const bool ok = status == 0 && fabs(pFit - p) < eps * fabs(p) && fabs(rFit - r) < eps * fabs(r);   // gsl_root_test_delta(x1, x0, 0, eps)
     cout << (ok ? "ok" : "not ok") << ": (" << pFit << ',' << rFit << ") " << (ok ? "~=" : "!=") << " (" << p << ',' << r << ')' << endl;
+    return EXIT_SUCCESS;
+  }
+  if (what == "fitvec") {   // fit_negbinom on a literal count vector (degenerate inputs): prints status p r
+    vector<double> kFreq;
+    for (const auto& v : av) kFreq.push_back(atof(v.c_str()));
+    double pFit = 0, rFit = 0;
+    const int status = fit_negbinom(kFreq, pFit, rFit);
+    cout << status << ' ' << setprecision(17) << pFit << ' ' << rFit << endl;
     return EXIT_SUCCESS;
   }
   Fail("Unknown selftest: " + what);

@@ -34,7 +34,8 @@ ocfg = O.DPConfig(local=kw.get("local", True), kmer_threshold=kw.get("kmer_thres
 want, ylogs, _ = oracle_estep(refs, reads, sc, null, ocfg, None, use_null=not force)
 scale = max(1.0, np.abs(want).max())
 for flags in (0, 64):
-    res = c.count_resident(Q.DPConfig(debug_flags=flags, **kw), force=force)
+    c.set_debug_flags(flags)
+    res = c.count_resident(Q.DPConfig(**kw), force=force)
     err = np.abs(res["counts"] - want) / np.maximum(np.abs(want), 1e-3 * scale)
     k = int(err.argmax())
     print("flags", flags, kw, "order", order, "worst rel err %.3e at %d (got %.8g want %.8g)" % (err.max(), k, res["counts"][k], want[k]),

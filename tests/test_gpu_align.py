@@ -108,7 +108,9 @@ def test_envelopes_match_oracle(ctx):
             for x, rf in enumerate(refs):
                 want = O.envelope(O.tokens(rf.seq), O.tokens(read.seq), ocfg, 24)
                 for dbg in (0, 1):      # 0: wavefront-per-pair seeding kernel, 1: workgroup-per-pair kernel
-                    got = ctx.envelope(r, x, Q.DPConfig(debug_flags=dbg, **kw))
+                    ctx.set_debug_flags(dbg)
+                    got = ctx.envelope(r, x, Q.DPConfig(**kw))
+                    ctx.set_debug_flags(0)
                     assert np.array_equal(got, want), (kw, dbg, r, x, len(got), len(want))
 
 
@@ -382,6 +384,57 @@ def test_ragged_batch_sorted_class_lists(ctx):
         reads.append(O.FastSeq("r%d" % n, seq, rand_qual(rng, len(seq))))
     res = check_against_oracle(ctx, both_strands(ref), reads, dict(), sc, null)
     assert len(res["alignments"]) == 72
+
+
+def test_ragged_batch_many_classes_side_streams(ctx):
+    """900 ragged reads x 2 strands whose bands span four fill classes with more than 64 units each (a 18..60-base deletion in
+    the middle of two reads in three widens the seeded band from 65..80 to 85..125 diagonals; the wrong strand gives lone
+    diagonals): every class list is
+    sorted in place on the main stream while the other classes' fills run on side streams, which therefore have to wait
+    for the sorts.  One piece and four pieces (two in flight), three rounds each, all against the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    import quaff_amd as Q
+    rng = np.random.default_rng(77)
+    ref = rand_seq(rng, 4000)
+    sc, null = oracle_model()
+    reads = []
+    for n in range(900):
+        L = int(rng.integers(200, 900))
+        s = int(rng.integers(0, len(ref) - L))
+        src = ref[s:s + L]
+        cut = (0, int(rng.integers(18, 30)), int(rng.integers(40, 60)))[n % 3]   # a deletion mid-read: two seed diagonals, one wider band
+        if cut:
+            src = src[:len(src) // 2] + src[len(src) // 2 + cut:]
+        if n & 1:
+            src = O.revcomp_str(src)
+        seq = mutate(rng, src)
+        reads.append(O.FastSeq("r%d" % n, seq, rand_qual(rng, len(seq))))
+    refs = both_strands(ref)
+    ocfg = O.DPConfig()
+    O.lib()
+    with ThreadPoolExecutor(8) as ex:
+        want = list(ex.map(lambda rd: O.align_read(refs, rd, sc, null, ocfg), reads))
+    ctx.set_refs([x.seq for x in refs])
+    ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+    try:
+        for chunks in (1, 4):
+            ctx.set_pipeline_chunks(chunks)
+            for rnd in range(3):
+                res = ctx.align_resident(Q.DPConfig(), 0)
+                if chunks == 1 and rnd == 0:
+                    big = [c for c in res["classes"] if c["units"] > 64]
+                    assert len(big) >= 3, res["classes"]
+                got = {a["read"]: a for a in res["alignments"]}
+                assert len(got) == sum(1 for k in want if k)
+                for r, kept in enumerate(want):
+                    if not kept:
+                        assert r not in got
+                        continue
+                    g, k = got[r], kept[0]
+                    assert (g["ref"], g["viterbi"], g["score"], g["xStart"], g["xEnd"], g["ops"]) == \
+                           (k["ref"], k["raw"], k["score"], k["xStart"], k["xEnd"], k["ops"]), (chunks, rnd, r)
+    finally:
+        ctx.set_pipeline_chunks(0)
 
 
 def test_long_reads_wide_seed_counters(ctx):

@@ -94,3 +94,18 @@ def test_m_step_fit_from_counts():
             if sums[y] > 0:
                 q, r = O.fit_negbinom(np.array(cj["match"][""][x][y], float))
                 assert abs(got["q"] - q) <= 2e-3 * q and abs(got["r"] - r) <= 2e-3 * r, (x, y, got, q, r)   # both stop at a relative 1e-4 Newton step
+
+
+def test_negbinom_fit_degenerate_count_vectors():
+    """Count vectors the E-step can hand the M-step for a rarely used (context, base) cell: a single occupied bin (zero
+    variance), variance below the mean, flat, nearly empty.  The reference keeps GSL's last accepted root when a Newton step
+    fails (src/negbinom.cpp:262-322) and ignores the status; the fit must stay finite and agree with the oracle's."""
+    import numpy as np
+    from oracle import oracle as O
+    for vec in ([0, 0, 5, 0, 0, 0], [3, 0, 0, 0], [1, 2, 3, 2, 1, 0, 0, 0], [5] * 8, [0, 0, 0, 0, 7], [1e-300, 0, 0], [10, 1],
+                [0.0] * 20 + [2.5] + [0.0] * 73, [1e-12] * 94):
+        status, p, r = selftest("fitvec", *[repr(float(v)) for v in vec]).split()
+        p, r = float(p), float(r)
+        assert np.isfinite(p) and np.isfinite(r) and 0 < p <= 1 and r > 0, (vec, status, p, r)
+        qo, ro = O.fit_negbinom(np.array(vec, float))
+        assert abs(p - qo) <= 2e-3 * qo and abs(r - ro) <= 2e-3 * ro, (vec, status, p, r, qo, ro)
