@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's config 2:
+"""bench.py — BASELINE.json's metric (DP cells/s of the k-mer-seeded banded pair-HMM DP) on BASELINE.json's configs.
 
-    banded Viterbi align, 1 synthetic 10 kb reference (+ its reverse complement) x 100 k synthetic
-    1 kb reads, -kmatchband 64 (k=6, threshold 20), DP cells/s.
+Default (the headline line, `--workload align`) = BASELINE config 2: banded Viterbi align, 1 synthetic 10 kb reference (+ its
+reverse complement) x 100 k synthetic 1 kb reads per GPU, -kmatchband 64 (k = 6, threshold 20).  `--workload train | overlap |
+fulldp` = configs 4 / 3 / 5 (supplementary lines, same JSON shape; the driver runs only the default).
 
-A "step" is one pass of the whole hot path (read prep, k-mer seeding, banded Viterbi fill, best
-reference per read, traceback to CIGAR runs, results copied to the host) over one batch of reads that
-is already resident in HBM.  Weak scaling: every rank owns its own --reads reads (different seeds) and
-one GPU; there is no data-path collective (read x reference pairs are independent), torch.distributed is
-used only for the barrier and the max-over-ranks time.
+A "step" is one pass of the whole hot path (read prep, k-mer seeding, DP fill, selection, traceback / count reduction, results
+on the host) over one batch that is already resident in HBM.  N > 1: one process per GPU.  `python bench.py --gpus N` starts
+the N ranks itself (torch.distributed.run as a child process, before anything touches HIP); under the driver's own
+`python -m torch.distributed.run ... bench.py --gpus N` the ranks come from the environment.  Read x reference pairs are
+independent, so there is no data-path collective: torch.distributed (backend nccl = RCCL) carries the barrier and the
+max-over-ranks time; `train` adds the E-step's one exchange, an RCCL all-reduce of the counts through the library's own
+qf_allreduce_counts.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof with the
-reference's algorithmic 24 B/cell; `cpu_baseline` times the oracle (a bit-exact CPU port
-of the reference algorithm, oracle/) on a bounded sample on this box's host cores.
+Prints ONE JSON line (rank 0) with
+  roofline      the dominant kernel against the roof that binds it: fp64 vector issue for the Viterbi kernels (DESIGN.md 4:
+                20 f64 operations per cell, 39.3 T op/s), HBM at the algorithmic 24 B/cell for Forward / Backward (which do
+                materialise the matrix); the HBM view (algorithmic GB/s, PMC traffic) is always given beside it;
+  cpu_baseline  the oracle (oracle/, a bit-exact CPU port of the reference's algorithm) timed on a bounded sample on this
+                box's host cores, which also re-checks the GPU's results for that sample (`gpu_parity_mismatches`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,83 +31,71 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+F64_PEAK_TOPS = 39.3         # 256 CUs x 4 SIMDs x 16 fp64 lanes x 2.4 GHz (= the 78.6 TFLOP/s FMA peak / 2)
 BYTES_PER_CELL = 24.0        # 3 fp64 states per DP cell
+# fp64-rate operations the recurrence needs per cell, whatever the kernel ("arithmetic floors")
+F64_OPS_PER_CELL = {"viterbi": 20.0, "forward": 65.0, "backward": 101.0, "overlap": 52.0, "overlap_single": 3.0}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 2: 100000)")
-    ap.add_argument("--read-len", type=int, default=1000)
-    ap.add_argument("--ref-len", type=int, default=10000)
-    ap.add_argument("--band", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--workload", default="align", choices=["align", "train", "overlap", "fulldp"],
-                    help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = scaled "
-                         "versions of configs 4 / 3 / 5 (supplementary lines, same JSON shape)")
+                    help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = configs 4 / 3 / 5")
+    ap.add_argument("--reads", type=int, default=0,
+                    help="reads: per GPU for align (default 100000, weak scaling); in all for train (20000), overlap (50000) and "
+                         "fulldp (256), which are sharded over the ranks (strong scaling, as BASELINE.json states them)")
+    ap.add_argument("--read-len", type=int, default=0, help="default 1000 (align, train), 2000 (overlap), 5000 (fulldp)")
+    ap.add_argument("--ref-len", type=int, default=0, help="default 10000 (align, train), 100000 (fulldp); overlap: genome = 20 x reads")
+    ap.add_argument("--band", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="units in the CPU-baseline / parity sample (reads; pairs for overlap); 0 = skip; default per workload")
     ap.add_argument("--overlap-rows", type=int, default=-1,
-                    help="overlap workload: rows [rank*R, rank*R+R) of the pair triangle per step (a rank's block of rows when "
-                         "config 3 is sharded by rows); 0 = all pairs of the read set; default 34 (3.4 M pairs) for the "
-                         "50 k-read config, all pairs for small --reads")
+                    help="overlap: the job is rows [0, R) of the all-vs-all pair triangle (row nx = pairs (nx, ny > nx), both "
+                         "strands), cut into per-rank blocks of equal pair count; default 34 rows (3.4 M pairs) for the 50 k-read "
+                         "config, the whole triangle for small --reads")
     ap.add_argument("--overlap-threshold", type=float, default=0.0,
-                    help="overlap workload: alignments scoring below it are not traced back (`quaff overlap` prints only "
-                         "score >= 0 by default, -threshold; pass -inf for -nothreshold)")
-    ap.add_argument("--reference-kernel", action="store_true", help="A/B: use the first-generation fill kernel")
+                    help="overlap: alignments scoring below it are not traced back (`quaff overlap` prints only score >= 0 by "
+                         "default, -threshold; pass -inf for -nothreshold)")
     ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
-    ap.add_argument("--debug-flags", type=int, default=0, help="developer: extra qf_dp_config.reserved bits (A/B switches)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="developer: csrc/qf_internal.h switches (A/B)")
     ap.add_argument("--chunks", type=int, default=0, help="pieces per batch kept two in flight (0 = library default)")
     ap.add_argument("--align-flags", type=int, default=0, help="developer: QF_ALIGN_* flags (2 = scores only, not a valid bench)")
     ap.add_argument("--single-device", action="store_true",
-                    help="testing only: every rank uses GPU 0 (rehearse the N>1 path on a one-GPU box)")
+                    help="testing only: every rank uses GPU 0 and the process group is gloo (RCCL wants one GPU per rank)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = this process's CPU share (at most 16)")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(ref, seq, qual, off, n_sample, threads, band, gpu_res):
-    """Oracle (oracle/, kind "port") on the first n_sample reads, one read per task on a thread pool —
-    the reference's execution model (runQuaffAlignmentTasks, src/qmodel.cpp:2870-2882).  Also checks the
-    GPU's alignments for those reads bit-for-bit."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    golden = os.path.join(ROOT, "tests", "golden")
-    sc = O.Scores(O.Params.from_json(open(os.path.join(golden, "defaultparams.json")).read()))
-    null = O.NullParams.from_json(open(os.path.join(golden, "testquaffnullparams.json")).read())
-    x = O.FastSeq("ref", ref.decode())
-    refs = [x, x.revcomp()]
-    cfg = O.DPConfig(band=band)
-    reads = [O.FastSeq("read%d" % n, seq[int(off[n]):int(off[n + 1])].decode(), qual[int(off[n]):int(off[n + 1])].decode())
-             for n in range(n_sample)]
-    O.lib()
-    t0 = time.time()
-    with ThreadPoolExecutor(threads) as ex:
-        out = list(ex.map(lambda r: O.align_read(refs, r, sc, null, cfg), reads))
-    dt = time.time() - t0
-    cells = 0
-    mismatches = 0
-    for n, kept in enumerate(out):
-        for xi in range(2):
-            cells += int(gpu_res["cells"][n, xi])
-        g = gpu_res["by_read"].get(n)
-        if not kept:
-            mismatches += g is not None
-            continue
-        k = kept[0]
-        if g is None or (g["ref"], g["viterbi"], g["xStart"], g["xEnd"], g["cigar"]) != \
-                (k["ref"], k["raw"], k["xStart"], k["xEnd"], O.cigar(k["ops"])):
-            mismatches += 1
-    return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
-            "sample": "first %d of the rank-0 reads x 2 strands (%d cells), oracle/quaff_oracle.c, %d threads, one read per task"
-                      % (n_sample, cells, threads),
-            "seconds": round(dt, 3), "gpu_parity_mismatches": mismatches}
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with no rank environment: start N ranks (one per GPU) as a child torch.distributed.run and
+    relay its output.  This process has not imported anything that touches HIP and never will."""
+    import socket
+    port = a.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def golden(name):
+    return open(os.path.join(ROOT, "tests", "golden", name)).read()
 
 
 def order2_params_json():
     """-order 2 shaped parameters (matchOrder 3, gapOrder 2) made by repeating the built-in order-0/1 values for every
     context, as `quaff train -order 2` would start from a context-free prior."""
     import re
-    base = open(os.path.join(ROOT, "tests", "golden", "defaultparams.json")).read()
+    base = golden("defaultparams.json")
     bi = re.search(r'"beginInsert": \{ "": ([0-9.e-]+)', base).group(1)
     bd = re.search(r'"beginDelete": \{ "": ([0-9.e-]+)', base).group(1)
     block = base[base.index('"match": {') + len('"match": {'):]
@@ -114,172 +109,526 @@ def order2_params_json():
             % gaps + mid + '"match": {\n' + match + " } }\n")
 
 
-def extra_workload(a, rank, world, local_rank):
-    """Supplementary workloads (scaled configs 3, 4, 5).  One JSON line, same keys as the headline line."""
-    import numpy as np
-    import quaff_amd as Q
-    from quaff_amd import api, dist
-    ctx = Q.Context(local_rank)
-    null_json = open(os.path.join(ROOT, "tests", "golden", "testquaffnullparams.json")).read()
-    ctx.set_null_json(null_json)
+def cpu_threads(a):
+    # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe beyond the affinity mask
+    return a.cpu_threads or min(16, len(os.sched_getaffinity(0)))
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
 
-    if a.workload == "train":
-        ctx.set_params_json(order2_params_json())
-        ref = api.synth_ref(1, a.ref_len)
-        ctx.set_refs([ref, api.revcomp(ref)])
-        n = a.reads if a.reads != 100000 else 20000
-        seq, qual, off = api.synth_reads(2 + rank, ref, n, a.read_len)
-        ctx.upload_reads_packed(seq, qual, off)
-        cfg = Q.DPConfig(band_size=a.band)
-        order = None
-        for _ in range(a.warmup):
-            order = ctx.count_resident(cfg, packed_order=True)["sort_order"]   # later EM iterations run on the pruned reference order
-        sync_all()
-        t0 = time.perf_counter()
-        cells = 0
-        ph = {}
-        for _ in range(a.steps):
-            res = ctx.count_resident(cfg, sort_order=order, packed_order=True)
-            if world > 1:
-                dist.estep_allreduce(res["counts"], res["loglike"])   # the E-step's only exchange (RCCL all-reduce)
-            cells += res["total_cells"] + res["backward_cells"]
-            for k, v in res["ms"].items():
-                ph[k] = ph.get(k, 0.0) + v
-        sync_all()
-        dt = time.perf_counter() - t0
-        desc = "config 4 shape: quaff train E-step, -order 2, %d bp ref (+revcomp) x %d x %d bp reads per GPU, band %d" % (a.ref_len, n, a.read_len, a.band)
-        metric = "DP cells/sec (Forward + Backward E-step)"
-        extra = {"forward_bytes": res["forward_bytes"], "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
-    elif a.workload == "overlap":
-        ctx.set_params_json(None)
-        n = a.reads if a.reads != 100000 else 50000            # BASELINE config 3: 50 k reads x 2 kb, 100x coverage of a 1 Mb genome
-        rows_per_step = a.overlap_rows if a.overlap_rows >= 0 else (34 if n >= 10000 else 0)
-        genome = api.synth_ref(3, max(a.ref_len, 20 * n))
-        seq, qual, off = api.synth_reads(4 + rank, genome, n, 2000)
-        # SeqList::loadSequences: originals followed by their reverse complements
-        seqs = [seq[int(off[k]):int(off[k + 1])] for k in range(n)]
-        quals = [qual[int(off[k]):int(off[k + 1])] for k in range(n)]
-        seqs += [api.revcomp(s) for s in seqs]
-        quals += [q[::-1] for q in quals]
-        ctx.upload_reads(seqs, quals)
-        if rows_per_step:                        # rows [rank*R, rank*R + R) of the triangle: one block of what a rank of the sharded config 3 owns
-            rows = np.arange(rank * rows_per_step, min(n - 1, (rank + 1) * rows_per_step))
-            xs = np.concatenate([np.full(2 * n - 1 - r, r) for r in rows])
-            ys = np.concatenate([np.arange(r + 1, 2 * n) for r in rows])
-            keep = np.ones(len(xs), bool)
-        else:
-            xs, ys = np.triu_indices(2 * n, 1)   # QuaffOverlapScheduler order: nx < ny, nx an original
-            keep = xs < n - 1
-        pairs = (xs[keep].astype(np.uint32), ys[keep].astype(np.uint32), (ys[keep] >= n).astype(np.uint8))
-        cfg = Q.DPConfig(kmer_threshold=14, band_size=a.band)
-        ctx.set_score_threshold(a.overlap_threshold)
-        for _ in range(a.warmup):
-            ctx.overlap_resident(pairs, cfg, raw=True)
-        sync_all()
-        t0 = time.perf_counter()
-        cells = 0
-        ph = {}
-        for _ in range(a.steps):
-            res = ctx.overlap_resident(pairs, cfg, raw=True)
-            cells += int(res.total_cells)
-            for k in ("prep", "seed", "fill", "traceback", "total"):
-                ph[k] = ph.get(k, 0.0) + getattr(res, "ms_" + k)
-        sync_all()
-        dt = time.perf_counter() - t0
-        desc = "config 3%s: quaff overlap, %d x 2 kb reads from a %d bp genome, both strands, %s (%d pairs per step per GPU)" % (
-            "" if n == 50000 else " shape", n, len(genome),
-            "%d rows of the all-vs-all pair triangle per step" % rows_per_step if rows_per_step else "all-vs-all", len(pairs[0]))
-        metric = "DP cells/sec (overlap Viterbi)"
-        extra = {"pairs": len(pairs[0]), "score_threshold": a.overlap_threshold, "alignments": int(res.n_alignments), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
+def pmc_for(workload, kernel_prefix):
+    """HBM bytes per launch and issue counters of one kernel from the committed rocprofv3 --pmc summaries of this build
+    (profiles/r02_pmc_<workload>.json, written by tools/pmc_summary.py); None when there is no capture for it."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
+    if not os.path.exists(path):
+        return None
+    for k in json.load(open(path)).get("kernels", []):
+        if kernel_prefix in k["kernel"].replace(" ", ""):
+            return k
+    return None
+
+
+def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
+    """The roofline object of one kernel launch: `bound` says which roof `achieved / peak / frac` are quoted against; both
+    views are spelled out beside it."""
+    ops = F64_OPS_PER_CELL[kind]
+    t = ms * 1e-3
+    alg_gbs = BYTES_PER_CELL * cells / t / 1e9
+    valu = ops * cells / t / 1e12
+    pmc = pmc_for(workload, kernel.replace(" ", ""))
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    out = {"bound": bound, "kernel": kernel, "cells_per_launch": int(cells), "ms_per_launch": round(ms, 4)}
+    if bound == "fp64_valu":
+        out.update(achieved=round(valu, 3), peak=F64_PEAK_TOPS, unit="TFLOP/s", frac=round(valu / F64_PEAK_TOPS, 4),
+                   f64_ops_per_cell=ops)
     else:
+        out.update(achieved=round(alg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_gbs / HBM_PEAK_GBS, 4),
+                   bytes_per_cell=BYTES_PER_CELL)
+    out["traffic"] = traffic
+    out["hbm"] = {"algorithmic_GBs": round(alg_gbs, 1), "algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                  "bytes_per_cell": BYTES_PER_CELL, "traffic_bytes_per_launch": traffic,
+                  "traffic_GBs": round(traffic / t / 1e9, 1) if traffic else None,
+                  "traffic_frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
+    out["fp64_valu"] = {"f64_ops_per_cell": ops, "achieved_Tops": round(valu, 3), "peak_Tops": F64_PEAK_TOPS,
+                        "frac": round(valu / F64_PEAK_TOPS, 4)}
+    if pmc:
+        out["pmc"] = {k: pmc[k] for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "valu_busy_frac",
+                                          "clock_GHz", "valu_insts_per_cell") if k in pmc}
+    if extra:
+        out.update(extra)
+    return out
+
+
+class Job:
+    """One workload on one rank.  setup() leaves everything resident; step() runs the hot path once and returns the cells
+    it processed; finish() (rank 0, after the timed region) builds the roofline and the CPU-baseline / parity leg."""
+    metric = "DP cells/sec"
+    scaling = "weak"
+
+    def __init__(self, a, rank, world, local_rank):
+        self.a, self.rank, self.world, self.local_rank = a, rank, world, local_rank
+        self.phase = {}
+        self.extra = {}
+
+    def add_phases(self, res, names):
+        for k in names:
+            self.phase[k] = self.phase.get(k, 0.0) + float(getattr(res, "ms_" + k))
+
+
+# ------------------------------------------------------------------------------------------------ config 2: align
+class AlignJob(Job):
+    metric = "DP cells/sec (banded Viterbi)"
+
+    def setup(self, Q, api, dist):
+        a = self.a
+        self.n = a.reads or 100000
+        self.read_len = a.read_len or 1000
+        self.ref_len = a.ref_len or 10000
+        self.ctx = ctx = Q.Context(self.local_rank)
         ctx.set_params_json(None)
-        ref_len = a.ref_len if a.ref_len != 10000 else 100000
-        ref = api.synth_ref(1, ref_len)
-        ctx.set_refs([ref, api.revcomp(ref)])
-        n = a.reads if a.reads != 100000 else 256
-        seq, qual, off = api.synth_reads(2 + rank, ref, n, 5000)
-        ctx.upload_reads_packed(seq, qual, off)
-        cfg = Q.DPConfig(sparse=False)
-        for _ in range(a.warmup):
-            ctx.align_resident(cfg, 0, raw=True)
-        sync_all()
-        t0 = time.perf_counter()
+        ctx.set_null_json(golden("testquaffnullparams.json"))
+        self.ref = api.synth_ref(1, self.ref_len)
+        ctx.set_refs([self.ref, api.revcomp(self.ref)])
+        self.seq, self.qual, self.off = api.synth_reads(2 + self.rank, self.ref, self.n, self.read_len)
+        ctx.upload_reads_packed(self.seq, self.qual, self.off)          # resident in HBM before the timed region
+        ctx.set_pipeline_chunks(a.chunks)
+        ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
+        self.cfg = Q.DPConfig(band_size=a.band)
+        self.cls_ms, self.cls_cells = {}, {}
+        self.Q = Q
+
+    def reset(self):
+        self.cls_ms, self.cls_cells, self.phase = {}, {}, {}
+
+    def step(self):
+        res = self.ctx.align_resident(self.cfg, self.a.align_flags, raw=True)   # synchronous: returns with the results on the host
+        for k in range(res.n_fill_classes):
+            if res.units_class[k]:
+                self.cls_ms[k] = self.cls_ms.get(k, 0.0) + res.ms_fill_class[k]
+                self.cls_cells[k] = int(res.cells_class[k])
+        self.add_phases(res, ("prep", "seed", "fill", "traceback", "total"))
+        self.last = (int(res.traceback_bytes), int(res.n_units), int(res.n_alignments))
+        return int(res.total_cells)
+
+    def describe(self):
+        return ("BASELINE config 2: quaff align, 1 x %d bp ref (+revcomp) x %d x %d bp reads per GPU, -kmatchband %d, k=6, threshold 20, "
+                "local, best alignment per read + CIGAR" % (self.ref_len, self.n, self.read_len, self.a.band))
+
+    def kernel_symbol(self, cls):
+        name = self.ctx.L.qf_fill_class_name(cls).decode()
+        if name.startswith("k_viterbi_fill<"):     # the instantiation that runs for order-0/1 parameters: <G, B, GAPCTX=false, EMLDS=true>
+            return "qf::" + name[:-1] + ",false,true>"
+        return "qf::" + name + ("<true>" if name in ("k_viterbi_single", "k_viterbi_rows") else "")
+
+    def finish(self, steps):
+        a, ctx = self.a, self.ctx
+        dom = max(self.cls_cells, key=lambda k: self.cls_cells[k])   # the class that does most of the work (the others run beside it)
+        dom_ms = self.cls_ms[dom] / steps
+        sym = self.kernel_symbol(dom)
+        roof = roofline_entry(a.workload, sym, "viterbi", self.cls_cells[dom], dom_ms, "fp64_valu")
+        if not a.serial_classes and len(self.cls_ms) > 1:
+            # In the timed region the fill classes run on concurrent streams, so the dominant kernel's event-bracketed duration
+            # includes the share of the GPU the other classes took.  One extra, untimed pass with the classes one after
+            # another gives the same kernel's duration alone (what rocprofv3 --stats shows for a serialised run).
+            ctx.set_debug_flags(4 | a.debug_flags)
+            sres = ctx.align_resident(self.cfg, a.align_flags, raw=True)
+            ctx.set_debug_flags(a.debug_flags)
+            iso_ms = float(sres.ms_fill_class[dom])
+            iso = roofline_entry(a.workload, sym, "viterbi", self.cls_cells[dom], iso_ms, "fp64_valu")
+            roof["concurrent_kernels"] = sorted(self.kernel_symbol(k) for k in self.cls_ms if k != dom)
+            roof["isolated"] = {"ms_per_launch": iso["ms_per_launch"], "achieved": iso["achieved"], "frac": iso["frac"]}
+        tb_bytes, n_units, n_align = self.last
+        self.extra = {"reads_per_gpu": self.n, "pairs_per_gpu": 2 * self.n, "bands": n_units, "alignments": n_align,
+                      "traceback_bytes": tb_bytes,
+                      "fill_kernels": {self.kernel_symbol(k): {"ms": round(self.cls_ms[k] / steps, 4), "cells": self.cls_cells[k]}
+                                       for k in sorted(self.cls_ms)}}
+        cpu = None
+        n_s = min(3000 if a.cpu_sample < 0 else a.cpu_sample, self.n)
+        if n_s > 0:
+            full = ctx.align_resident(self.cfg, 0, reads_below=n_s)   # unpacked view of the same batch for the parity check
+            cpu = self.cpu_baseline(n_s, cpu_threads(a), full)
+        return roof, cpu
+
+    def cpu_baseline(self, n_sample, threads, gpu_res, cfg_kw=None):
+        """Oracle (oracle/, kind "port") on the first n_sample reads, one read per task on a thread pool — the reference's
+        execution model (runQuaffAlignmentTasks, src/qmodel.cpp:2870-2882).  Also checks the GPU's alignments for those
+        reads bit-for-bit."""
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as O
+        sc = O.Scores(O.Params.from_json(golden("defaultparams.json")))
+        null = O.NullParams.from_json(golden("testquaffnullparams.json"))
+        x = O.FastSeq("ref", self.ref.decode())
+        refs = [x, x.revcomp()]
+        cfg = O.DPConfig(band=self.a.band, **(cfg_kw or {}))
+        seq, qual, off = self.seq, self.qual, self.off
+        reads = [O.FastSeq("read%d" % n, seq[int(off[n]):int(off[n + 1])].decode(), qual[int(off[n]):int(off[n + 1])].decode())
+                 for n in range(n_sample)]
+        O.lib()
+        t0 = time.time()
+        with ThreadPoolExecutor(threads) as ex:
+            out = list(ex.map(lambda r: O.align_read(refs, r, sc, null, cfg), reads))
+        dt = time.time() - t0
+        by_read = {al["read"]: al for al in gpu_res["alignments"]}
         cells = 0
-        ph = {}
-        for _ in range(a.steps):
-            res = ctx.align_resident(cfg, 0, raw=True)
-            cells += int(res.total_cells)
-            for k in ("prep", "seed", "fill", "traceback", "total"):
-                ph[k] = ph.get(k, 0.0) + getattr(res, "ms_" + k)
-        sync_all()
-        dt = time.perf_counter() - t0
-        desc = "config 5 shape: -kmatchoff full DP, %d bp ref (+revcomp) x %d x 5 kb reads per GPU" % (ref_len, n)
-        metric = "DP cells/sec (unbanded Viterbi)"
-        extra = {"traceback_bytes": int(res.traceback_bytes), "phase_ms": {k: round(v / a.steps, 3) for k, v in ph.items()}}
-    if world > 1:
-        dt = dist.allreduce_max(dt)
-        cells = int(dist.allreduce_sum(np.array([float(cells)]))[0])
-    if rank == 0:
-        print(json.dumps({"metric": metric, "value": cells / dt, "unit": "DP cells/s", "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": dict({"workload": desc}, **extra)}))
-    ctx.close()
-    dist.finalize()
+        mismatches = 0
+        for n, kept in enumerate(out):
+            cells += int(gpu_res["cells"][n].sum())
+            g = by_read.get(n)
+            if not kept:
+                mismatches += g is not None
+                continue
+            k = kept[0]
+            if g is None or (g["ref"], g["viterbi"], g["score"], g["xStart"], g["xEnd"], g["cigar"]) != \
+                    (k["ref"], k["raw"], k["score"], k["xStart"], k["xEnd"], O.cigar(k["ops"])):
+                mismatches += 1
+        return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
+                "sample": "first %d of the rank-0 reads x 2 strands (%d cells), oracle/quaff_oracle.c, %d threads, one read per task; "
+                          "GPU reference choice, score, coordinates and CIGAR compared with == for every one of them"
+                          % (n_sample, cells, threads),
+                "seconds": round(dt, 3), "gpu_parity_mismatches": mismatches}
+
+
+# ------------------------------------------------------------------------------------------------ config 5: full DP
+class FullDPJob(AlignJob):
+    metric = "DP cells/sec (unbanded Viterbi)"
+    scaling = "strong"
+
+    def setup(self, Q, api, dist):
+        a = self.a
+        total = a.reads or 256
+        self.read_len = a.read_len or 5000
+        self.ref_len = a.ref_len or 100000
+        self.ctx = ctx = Q.Context(self.local_rank)
+        ctx.set_params_json(None)
+        ctx.set_null_json(golden("testquaffnullparams.json"))
+        self.ref = api.synth_ref(1, self.ref_len)
+        ctx.set_refs([self.ref, api.revcomp(self.ref)])
+        seq, qual, off = api.synth_reads(2, self.ref, total, self.read_len)      # the whole job; every rank cuts out its own block
+        import numpy as np
+        cuts = dist.balanced_blocks(np.diff(off).astype(np.float64), self.world)   # cells of a read = its length x the references' lengths
+        lo, hi = int(cuts[self.rank]), int(cuts[self.rank + 1])
+        b0, b1 = int(off[lo]), int(off[hi])
+        self.seq, self.qual, self.off = seq[b0:b1], qual[b0:b1], (off[lo:hi + 1] - off[lo]).astype(np.uint64)
+        self.n, self.total_reads = hi - lo, total
+        ctx.upload_reads_packed(self.seq, self.qual, self.off)
+        ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
+        self.cfg = Q.DPConfig(sparse=False)
+        self.cls_ms, self.cls_cells = {}, {}
+        self.Q = Q
+
+    def describe(self):
+        return ("BASELINE config 5%s: -kmatchoff full DP, %d bp ref (+revcomp) x %d x %d bp reads sharded over %d GPU(s) by cell count"
+                % ("" if (self.total_reads, self.ref_len, self.read_len) == (10000, 100000, 5000) else " shape (10 000 reads in the stated config)",
+                   self.ref_len, self.total_reads, self.read_len, self.world))
+
+    def finish(self, steps):
+        a, ctx = self.a, self.ctx
+        dom = max(self.cls_cells, key=lambda k: self.cls_cells[k])
+        sym = self.kernel_symbol(dom)
+        roof = roofline_entry(a.workload, sym, "viterbi", self.cls_cells[dom], self.cls_ms[dom] / steps, "fp64_valu")
+        tb_bytes, n_units, n_align = self.last
+        self.extra = {"reads_this_rank": self.n, "alignments": n_align, "traceback_bytes": tb_bytes}
+        cpu = None
+        n_s = min(1 if a.cpu_sample < 0 else a.cpu_sample, self.n)
+        if n_s > 0:
+            full = ctx.align_resident(self.cfg, 0, reads_below=n_s)
+            cpu = self.cpu_baseline(n_s, min(cpu_threads(a), 2 * n_s), full, cfg_kw=dict(sparse=False))
+            cpu["sample"] = cpu["sample"].replace("one read per task", "one read per task (a read's two strands run one after the other)")
+        return roof, cpu
+
+
+# ------------------------------------------------------------------------------------------------ config 4: train E-step
+class TrainJob(Job):
+    metric = "DP cells/sec (Forward + Backward E-step)"
+    scaling = "strong"
+
+    def setup(self, Q, api, dist):
+        a = self.a
+        total = a.reads or 20000
+        self.read_len = a.read_len or 1000
+        self.ref_len = a.ref_len or 10000
+        self.ctx = ctx = Q.Context(self.local_rank)
+        self.params_json = order2_params_json()
+        ctx.set_params_json(self.params_json)
+        ctx.set_null_json(golden("testquaffnullparams.json"))
+        self.ref = api.synth_ref(1, self.ref_len)
+        ctx.set_refs([self.ref, api.revcomp(self.ref)])
+        seq, qual, off = api.synth_reads(2, self.ref, total, self.read_len)
+        import numpy as np
+        lo, hi = dist.shard_range(total, self.rank, self.world)            # read ownership is fixed across EM iterations
+        b0, b1 = int(off[lo]), int(off[hi])
+        self.seq, self.qual, self.off = seq[b0:b1], qual[b0:b1], (off[lo:hi + 1] - off[lo]).astype(np.uint64)
+        self.n, self.total_reads = hi - lo, total
+        ctx.upload_reads_packed(self.seq, self.qual, self.off)
+        ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
+        self.cfg = Q.DPConfig(band_size=a.band)
+        self.dist = dist
+        self.rccl = dist.attach_rccl(ctx) if self.world > 1 or os.environ.get("WORLD_SIZE") else False
+        self.order = None
+        self.cls = {}
+        self.Q = Q
+
+    def reset(self):
+        self.phase, self.cls = {}, {}
+
+    def step(self):
+        res = self.ctx.count_resident(self.cfg, sort_order=self.order, packed_order=True)
+        if self.order is None:
+            self.order = res["sort_order"]     # later EM iterations run on the pruned reference order (the warm-up provides it)
+        if self.world > 1 or self.rccl:
+            self.global_counts, self.global_ll = self.dist.estep_allreduce(res["counts"], res["loglike"], self.ctx)   # the E-step's only exchange
+        for k, v in res["ms"].items():
+            self.phase[k] = self.phase.get(k, 0.0) + v
+        for c in res["classes"]:
+            e = self.cls.setdefault(c["geometry"], {"ms_forward": 0.0, "ms_backward": 0.0, "cells": c["cells"], "units": c["units"]})
+            e["ms_forward"] += c["ms_forward"]
+            e["ms_backward"] += c["ms_backward"]
+        self.last = res
+        return res["total_cells"] + res["backward_cells"]
+
+    def describe(self):
+        return ("BASELINE config 4%s: quaff train E-step (Forward-Backward), -order 2, %d bp ref (+revcomp) x %d x %d bp reads sharded over "
+                "%d GPU(s), band %d, counts all-reduced by %s" % ("" if self.total_reads == 20000 else " shape", self.ref_len, self.total_reads,
+                                                                  self.read_len, self.world, self.a.band,
+                                                                  "RCCL (qf_allreduce_counts)" if self.rccl else "the host (one rank)" if self.world == 1 else "gloo (one-GPU rehearsal)"))
+
+    def finish(self, steps):
+        a = self.a
+        geo = max(self.cls, key=lambda g: self.cls[g]["cells"])
+        e = self.cls[geo]
+        G, B = geo[geo.index("<") + 1:-1].split(",")
+        back_cells = self.last["backward_cells"]
+        # the dominant kernel: Backward of the dominant class (it re-reads the Forward matrix: 24 B/cell algorithmic)
+        bsym = "qf::k_backward_fill<%s,%s>" % (G, B)
+        fsym = "qf::k_forward_fill<%s,%s>" % (G, B)
+        bcells = e["cells"] * back_cells / max(1, self.last["total_cells"])     # pruned pairs get no Backward pass
+        roof = roofline_entry(a.workload, bsym, "backward", bcells, e["ms_backward"] / steps, "hbm")
+        fwd = roofline_entry(a.workload, fsym, "forward", e["cells"], e["ms_forward"] / steps, "hbm")
+        roof["forward_kernel"] = {k: fwd[k] for k in ("kernel", "cells_per_launch", "ms_per_launch", "achieved", "frac", "traffic", "fp64_valu")}
+        es_ms = (self.phase["forward"] + self.phase["backward"]) / steps
+        es_bytes = BYTES_PER_CELL * (self.last["total_cells"] + back_cells)
+        roof["estep"] = {"ms": round(es_ms, 3), "algorithmic_bytes": es_bytes, "achieved": round(es_bytes / (es_ms * 1e-3) / 1e9, 1),
+                         "frac": round(es_bytes / (es_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "forward_bytes_allocated": self.last["forward_bytes"]}
+        self.extra = {"reads_this_rank": self.n, "forward_bytes": self.last["forward_bytes"],
+                      "kernels": {g: {"ms_forward": round(v["ms_forward"] / steps, 4), "ms_backward": round(v["ms_backward"] / steps, 4),
+                                      "cells": v["cells"], "units": v["units"]} for g, v in sorted(self.cls.items())}}
+        cpu = None
+        n_s = min(1000 if a.cpu_sample < 0 else a.cpu_sample, self.n)
+        if n_s > 0:
+            cpu = self.cpu_baseline(n_s, cpu_threads(a))
+        return roof, cpu
+
+    def cpu_baseline(self, n_sample, threads):
+        """The oracle's QuaffCountingTask (one read per task) on the first n_sample reads of rank 0, timed; the GPU runs the same
+        sample alone and its per-read log-likelihoods, next-iteration orders and summed counts are compared at 1e-4 relative."""
+        from concurrent.futures import ThreadPoolExecutor
+        import numpy as np
+        from oracle import oracle as O
+        sc = O.Scores(O.Params.from_json(self.params_json))
+        null = O.NullParams.from_json(golden("testquaffnullparams.json"))
+        x = O.FastSeq("ref", self.ref.decode())
+        refs = [x, x.revcomp()]
+        cfg = O.DPConfig(band=self.a.band)
+        seq, qual, off = self.seq, self.qual, self.off
+        reads = [O.FastSeq("read%d" % n, seq[int(off[n]):int(off[n + 1])].decode(), qual[int(off[n]):int(off[n + 1])].decode())
+                 for n in range(n_sample)]
+        O.lib()
+        t0 = time.time()
+        with ThreadPoolExecutor(threads) as ex:
+            out = list(ex.map(lambda r: O.count_read(refs, r, sc, null, cfg), reads))
+        dt = time.time() - t0
+        want = np.sum([o[0] for o in out], axis=0)
+        ylogs = np.array([o[1] for o in out])
+        b1 = int(off[n_sample])
+        self.ctx.upload_reads_packed(seq[:b1], qual[:b1], off[:n_sample + 1].copy())
+        res = self.ctx.count_resident(self.cfg)
+        self.ctx.upload_reads_packed(seq, qual, off)
+        mism = int(np.sum(np.abs(res["read_loglike"] - ylogs) > 1e-4 * np.abs(ylogs)))
+        mism += sum(1 for r in range(n_sample) if res["sort_order"][r] != out[r][2])
+        big = np.abs(want) > 1e-6
+        rel = np.abs(res["counts"] - want)[big] / np.abs(want)[big]
+        mism += int(np.sum(rel > 1e-4))
+        cells = res["total_cells"] + res["backward_cells"]
+        return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
+                "sample": "first %d of the rank-0 reads x 2 strands (%d Forward + Backward cells), oracle/quaff_oracle.c, %d threads, one read "
+                          "per task; GPU per-read log-likelihood, pruned reference order and every count entry above 1e-6 compared at 1e-4 relative"
+                          % (n_sample, cells, threads),
+                "seconds": round(dt, 3), "gpu_parity_mismatches": mism,
+                "max_rel_err_counts": float(rel.max()) if rel.size else 0.0,
+                "max_rel_err_read_loglike": float(np.max(np.abs(res["read_loglike"] - ylogs) / np.abs(ylogs)))}
+
+
+# ------------------------------------------------------------------------------------------------ config 3: overlap
+class OverlapJob(Job):
+    metric = "DP cells/sec (overlap Viterbi)"
+    scaling = "strong"
+
+    def setup(self, Q, api, dist):
+        import numpy as np
+        a = self.a
+        self.n = n = a.reads or 50000            # BASELINE config 3: 50 k reads x 2 kb, 100x coverage of a 1 Mb genome
+        self.read_len = a.read_len or 2000
+        rows = a.overlap_rows if a.overlap_rows >= 0 else (34 if n >= 10000 else 0)
+        self.rows = rows = min(rows, n - 1) if rows else n - 1
+        self.ctx = ctx = Q.Context(self.local_rank)
+        ctx.set_params_json(None)
+        ctx.set_null_json(golden("testquaffnullparams.json"))
+        self.genome = api.synth_ref(3, max(a.ref_len, 20 * n))
+        seq, qual, off = api.synth_reads(4, self.genome, n, self.read_len)
+        # SeqList::loadSequences: originals followed by their reverse complements
+        self.seqs = [seq[int(off[k]):int(off[k + 1])] for k in range(n)]
+        self.quals = [qual[int(off[k]):int(off[k + 1])] for k in range(n)]
+        self.seqs += [api.revcomp(s) for s in self.seqs]
+        self.quals += [q[::-1] for q in self.quals[:n]]
+        ctx.upload_reads(self.seqs, self.quals)
+        # QuaffOverlapScheduler order (src/qoverlap.cpp:475-480): nx < ny, nx an original, ny over originals then complements.
+        # Row nx holds 2n - 1 - nx pairs; ranks take contiguous row blocks of equal pair count.
+        row_len = (2 * n - 1 - np.arange(rows)).astype(np.float64)
+        cuts = dist.balanced_blocks(row_len, self.world)
+        r0, r1 = int(cuts[self.rank]), int(cuts[self.rank + 1])
+        self.row_block = (r0, r1)
+        xs = np.concatenate([np.full(2 * n - 1 - r, r, np.uint32) for r in range(r0, r1)]) if r1 > r0 else np.zeros(0, np.uint32)
+        ys = np.concatenate([np.arange(r + 1, 2 * n, dtype=np.uint32) for r in range(r0, r1)]) if r1 > r0 else np.zeros(0, np.uint32)
+        self.pairs = (xs, ys, (ys >= n).astype(np.uint8))
+        self.cfg = Q.DPConfig(kmer_threshold=14, band_size=a.band)
+        ctx.set_score_threshold(a.overlap_threshold)
+        ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
+        self.cls = {}
+        self.Q = Q
+
+    def reset(self):
+        self.phase, self.cls = {}, {}
+
+    def step(self):
+        res = self.ctx.overlap_resident(self.pairs, self.cfg, raw=True)
+        self.add_phases(res, ("prep", "seed", "fill", "traceback", "total"))
+        for k in range(res.n_fill_classes):
+            if res.units_class[k]:
+                e = self.cls.setdefault(k, {"ms": 0.0, "cells": int(res.cells_class[k]), "units": int(res.units_class[k])})
+                e["ms"] += res.ms_fill_class[k]
+        self.n_align = int(res.n_alignments)
+        return int(res.total_cells)
+
+    def describe(self):
+        return ("BASELINE config 3%s: quaff overlap, %d x %d bp reads from a %d bp genome, both strands, rows [0, %d) of the all-vs-all pair "
+                "triangle sharded over %d GPU(s) by pair count (%d pairs on rank 0)"
+                % ("" if self.n == 50000 else " shape", self.n, self.read_len, len(self.genome), self.rows, self.world, len(self.pairs[0])))
+
+    def kernel_symbol(self, cls):
+        name = self.ctx.L.qf_fill_class_name(cls).decode()
+        if cls == 0:
+            return "qf::k_overlap_single_lds"
+        if name == "k_viterbi_rows":
+            return "qf::k_overlap_rows"
+        return "qf::" + name.replace("k_viterbi_fill", "k_overlap_fill")
+
+    def finish(self, steps):
+        a = self.a
+        # the kernel the fill phase spends most of its time in
+        dom = max(self.cls, key=lambda k: self.cls[k]["ms"])
+        e = self.cls[dom]
+        sym = self.kernel_symbol(dom)
+        kind = "overlap_single" if dom == 0 else "overlap"
+        roof = roofline_entry(a.workload, sym, kind, e["cells"], e["ms"] / steps, "fp64_valu" if dom else "hbm")
+        self.extra = {"pairs_this_rank": len(self.pairs[0]), "rows_this_rank": list(self.row_block), "score_threshold": a.overlap_threshold,
+                      "alignments": self.n_align,
+                      "fill_kernels": {self.kernel_symbol(k): {"ms": round(v["ms"] / steps, 4), "cells": v["cells"], "bands": v["units"]}
+                                       for k, v in sorted(self.cls.items())}}
+        cpu = None
+        n_s = min(2000 if a.cpu_sample < 0 else a.cpu_sample, len(self.pairs[0]))
+        if n_s > 0:
+            cpu = self.cpu_baseline(n_s, cpu_threads(a))
+        return roof, cpu
+
+    def cpu_baseline(self, n_sample, threads):
+        """Oracle overlap (QuaffOverlapTask::run, one pair per task) on every pair of this rank's block the GPU returned an
+        alignment for (score >= threshold) plus a random n_sample of the rest: result, score, coordinates and state path compared
+        with ==; pairs below the threshold must have no alignment."""
+        from concurrent.futures import ThreadPoolExecutor
+        import numpy as np
+        from oracle import oracle as O
+        params = O.Params.from_json(golden("defaultparams.json"))
+        sc = O.Scores(params)
+        null = O.NullParams.from_json(golden("testquaffnullparams.json"))
+        osc = [O.OverlapScores(params, sc, False), O.OverlapScores(params, sc, True)]
+        cfg = O.DPConfig(kmer_threshold=14, band=self.a.band)
+        res = self.ctx.overlap_resident(self.pairs, self.cfg)
+        xs, ys, cs = self.pairs
+        rng = np.random.default_rng(5)
+        pick = sorted(set(res["alignments"].keys()) | set(int(p) for p in rng.choice(len(xs), size=n_sample, replace=False)))
+        fs = {}
+
+        def seq_of(k):
+            if k not in fs:
+                fs[k] = O.FastSeq("s%d" % k, self.seqs[k].decode(), self.quals[k].decode())
+            return fs[k]
+        for p in pick:
+            seq_of(int(xs[p])), seq_of(int(ys[p]))
+        O.lib()
+        t0 = time.time()
+        with ThreadPoolExecutor(threads) as ex:
+            out = list(ex.map(lambda p: O.overlap_pair(fs[int(xs[p])], fs[int(ys[p])], bool(cs[p]), osc[int(cs[p])], sc, null, cfg), pick))
+        dt = time.time() - t0
+        thr = self.a.overlap_threshold
+        mism, cells = 0, 0
+        for p, want in zip(pick, out):
+            cells += int(res["cells"][p])
+            g = res["alignments"].get(p)
+            if want is None:
+                mism += g is not None or np.isfinite(res["viterbi"][p])
+                continue
+            if res["viterbi"][p] != want["result"] or res["score"][p] != want["score"]:
+                mism += 1
+                continue
+            if want["score"] >= thr:
+                if g is None or (g["xStart"], g["xEnd"], g["yStart"], g["yEnd"], g["ops"]) != \
+                        (want["xStart"], want["xEnd"], want["yStart"], want["yEnd"], want["ops"]):
+                    mism += 1
+            elif g is not None:
+                mism += 1
+        return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
+                "sample": "%d pairs of the rank-0 block: all %d with a returned alignment + a random %d (%d cells), oracle/quaff_oracle.c, %d "
+                          "threads, one pair per task; result, score, coordinates and state path compared with =="
+                          % (len(pick), len(res["alignments"]), n_sample, cells, threads),
+                "seconds": round(dt, 3), "gpu_parity_mismatches": int(mism)}
+
+
+JOBS = {"align": AlignJob, "fulldp": FullDPJob, "train": TrainJob, "overlap": OverlapJob}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import numpy as np
-    import quaff_amd as Q
-    from quaff_amd import api, dist
+    from quaff_amd import dist
     if a.single_device:
         local_rank = 0
         os.environ["LOCAL_RANK"] = "0"
-    if world > 1:
-        # nccl == RCCL on ROCm, one process per GPU (RCCL refuses two ranks on one GPU, so the rehearsal uses gloo)
+    if "WORLD_SIZE" in os.environ:
+        # one process per GPU under torch.distributed.run; nccl == RCCL on ROCm.  torch is imported (and brings its HIP runtime)
+        # before libquaffhip is loaded.  RCCL wants a GPU per rank, so the one-GPU rehearsal uses gloo.
         dist.init("gloo" if a.single_device else "nccl")
+    import numpy as np
+    import quaff_amd as Q
+    from quaff_amd import api
 
-    if a.workload != "align":
-        return extra_workload(a, rank, world, local_rank)
-    ctx = Q.Context(local_rank)
-    ctx.set_params_json(None)
-    ctx.set_null_json(open(os.path.join(ROOT, "tests", "golden", "testquaffnullparams.json")).read())
-    ref = api.synth_ref(1, a.ref_len)
-    ctx.set_refs([ref, api.revcomp(ref)])
-    seq, qual, off = api.synth_reads(2 + rank, ref, a.reads, a.read_len)
-    ctx.upload_reads_packed(seq, qual, off)          # resident in HBM before the timed region
-    ctx.set_pipeline_chunks(a.chunks)
-    cfg = Q.DPConfig(band_size=a.band, debug_flags=(2 if a.reference_kernel else 0) | (4 if a.serial_classes else 0) | a.debug_flags)
+    job = JOBS[a.workload](a, rank, world, local_rank)
+    job.setup(Q, api, dist)
 
     def sync_all():
-        if world > 1:
+        if "WORLD_SIZE" in os.environ:
             dist.barrier()                    # barrier + torch.cuda.synchronize() on both sides
 
     for _ in range(a.warmup):
-        ctx.align_resident(cfg, a.align_flags, raw=True)
+        job.step()
+    if hasattr(job, "reset"):
+        job.reset()
     sync_all()
     t0 = time.perf_counter()
-    cls_ms, cls_cells, cls_names = {}, {}, {}
-    phases = {"prep": 0.0, "seed": 0.0, "fill": 0.0, "traceback": 0.0, "total": 0.0}
     total_cells = 0
     for _ in range(a.steps):
-        res = ctx.align_resident(cfg, a.align_flags, raw=True)   # synchronous: returns after results are on the host
-        total_cells += int(res.total_cells)
-        for k in range(res.n_fill_classes):
-            if res.units_class[k]:
-                cls_ms[k] = cls_ms.get(k, 0.0) + res.ms_fill_class[k]
-                cls_cells[k] = int(res.cells_class[k])
-        for p in phases:
-            phases[p] += getattr(res, "ms_" + p)
-        tb_bytes, n_units, n_align = int(res.traceback_bytes), int(res.n_units), int(res.n_alignments)
+        total_cells += job.step()
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -288,63 +637,16 @@ def main():
     if rank != 0:
         dist.finalize()
         return
-
-    dom = max(cls_cells, key=lambda k: cls_cells[k])   # the class that does most of the work (the others run beside it)
-    dom_ms = cls_ms[dom] / a.steps
-    dom_name = ctx.L.qf_fill_class_name(dom).decode()
-    achieved = BYTES_PER_CELL * cls_cells[dom] / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("kernel") == dom_name and tj.get("reads") == a.reads and tj.get("read_len") == a.read_len:
-            traffic = tj.get("hbm_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "cells_per_launch": cls_cells[dom], "bytes_per_cell": BYTES_PER_CELL, "ms_per_launch": round(dom_ms, 4)}
-    if not a.serial_classes and len(cls_ms) > 1:
-        # In the timed region the fill classes run on concurrent streams, so the dominant kernel's event-bracketed duration
-        # includes the share of the GPU the other classes took.  One extra, untimed pass with the classes one after
-        # another gives the same kernel's duration alone (what rocprofv3 --stats shows for a serialised run).
-        scfg = Q.DPConfig(band_size=a.band, debug_flags=cfg.reserved | 4)
-        sres = ctx.align_resident(scfg, a.align_flags, raw=True)
-        iso_ms = float(sres.ms_fill_class[dom])
-        iso = BYTES_PER_CELL * cls_cells[dom] / (iso_ms * 1e-3) / 1e9
-        roofline["concurrent_classes"] = sorted(ctx.L.qf_fill_class_name(k).decode() for k in cls_ms if k != dom)
-        roofline["isolated"] = {"ms_per_launch": round(iso_ms, 4), "achieved": round(iso, 1), "frac": round(iso / HBM_PEAK_GBS, 4)}
-    # What actually bounds the kernel (informational; the contract's roofline above stays the HBM one): fp64 vector issue.
-    # 161 VALU instructions per wavefront step of 5 cells per lane in the fast-path loop (tools/kernel_asm.sh) = 32.2 lane
-    # operations per cell; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (the chip runs ~2.1 GHz under this load).
-    if dom_name == "k_viterbi_fill<16,5>":
-        ops = 32.2 * cls_cells[dom] / ((roofline.get("isolated", roofline)["ms_per_launch"]) * 1e-3) / 1e12
-        roofline["valu_issue"] = {"lane_ops_per_cell": 32.2, "achieved": round(ops, 2), "peak": 39.3, "unit": "T lane-ops/s",
-                                  "frac": round(ops / 39.3, 3), "of": "isolated" if "isolated" in roofline else "in-region"}
-
-    cpu = None
-    if a.cpu_sample > 0:
-        n_s = min(a.cpu_sample, a.reads)
-        full = ctx.align_resident(cfg, 0, reads_below=n_s)   # unpacked view of the same batch for the parity check
-        full["by_read"] = {al["read"]: al for al in full["alignments"]}
-        # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe beyond the affinity mask
-        threads = a.cpu_threads or min(16, len(os.sched_getaffinity(0)))
-        cpu = cpu_baseline(ref, seq, qual, off, n_s, threads, a.band, full)
-
-    out = {
-        "metric": "DP cells/sec (banded Viterbi)", "value": total_cells / dt, "unit": "DP cells/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: quaff align, 1 x %d bp ref (+revcomp) x %d x %d bp reads per GPU, "
-                               "-kmatchband %d, k=6, threshold 20, local, best alignment per read + CIGAR"
-                               % (a.ref_len, a.reads, a.read_len, a.band),
-                   "reads_per_gpu": a.reads, "pairs_per_gpu": 2 * a.reads, "cells_per_step_per_gpu": total_cells // (a.steps * world),
-                   "bands": n_units, "alignments": n_align, "traceback_bytes": tb_bytes,
-                   "phase_ms": {k: round(v / a.steps, 3) for k, v in phases.items()},
-                   "fill_kernels": {ctx.L.qf_fill_class_name(k).decode(): {"ms": round(cls_ms[k] / a.steps, 4), "cells": cls_cells[k]}
-                                    for k in sorted(cls_ms)}},
-        "roofline": roofline, "cpu_baseline": cpu,
-    }
+    roof, cpu = job.finish(a.steps)
+    cfg = {"workload": job.describe(), "cells_per_step": total_cells // a.steps,
+           "phase_ms": {k: round(v / a.steps, 3) for k, v in job.phase.items()}}
+    cfg.update(job.extra)
+    out = {"metric": job.metric, "value": total_cells / dt, "unit": "DP cells/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": job.scaling,
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))
-    ctx.close()
+    sys.stdout.flush()
+    job.ctx.close()
     dist.finalize()
 
 

@@ -26,7 +26,7 @@
  *   QuaffBackwardMatrix ctor         src/qmodel.cpp:1393-1510 qf_count_resident (backward kernels + counts)
  *   QuaffCountingTask::run           src/qmodel.cpp:2238-2271 qf_count_resident (pruning, weights, new order)
  *   QuaffParamCounts(QuaffCounts)    src/qmodel.cpp:407-417   qf_count_result.counts layout
- *   QuaffTrainer::getCounts reduce   src/qmodel.cpp:2416-2422 sum over the batch (+ caller's all-reduce)
+ *   QuaffCountingScheduler::finalCounts/finalLogLike src/qmodel.cpp:2416-2422 sum over the batch, then qf_allreduce_counts across GPUs
  *   QuaffOverlapScores ctor          src/qoverlap.cpp:9-75    (built inside qf_overlap_resident, once per strand flag)
  *   QuaffOverlapViterbiMatrix ctor   src/qoverlap.cpp:77-160  qf_overlap_resident (overlap fill kernel)
  *   QuaffOverlapViterbiMatrix::alignment :162-290, scoreAdjustedAlignment :292-302   qf_overlap_resident
@@ -199,6 +199,12 @@ typedef struct qf_count_result {
   uint64_t backward_cells;
   uint64_t forward_bytes;       /* Forward matrix bytes materialised */
   float ms_prep, ms_seed, ms_forward, ms_plan, ms_backward, ms_total;
+  /* per fill-kernel class (qf_fill_class_name gives the Viterbi name of the same (lanes, diagonals-per-lane) geometry):
+   * launch durations of the Forward and the Backward kernel, cells and bands the class holds */
+  float ms_forward_class[QF_MAX_FILL_CLASSES], ms_backward_class[QF_MAX_FILL_CLASSES];
+  uint64_t cells_class[QF_MAX_FILL_CLASSES];
+  uint32_t units_class[QF_MAX_FILL_CLASSES];
+  uint32_t n_fill_classes;
 } qf_count_result;
 
 /* One E-step over the resident reads.  sort_in / sort_n_in (optional, [n_reads*n_refs] / [n_reads]) give each
@@ -206,6 +212,26 @@ typedef struct qf_count_result {
 int qf_count_resident(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t flags, const uint32_t *sort_in,
                       const uint32_t *sort_n_in, qf_count_result *out);
 uint32_t qf_counts_size(const qf_ctx *ctx);
+
+/* ---- E-step reduction across GPUs (quaff train on several devices) ------------------------- */
+/* The reference sums the counts and log-likelihoods of all worker threads after every E-step
+ * (QuaffCountingScheduler::finalCounts / finalLogLike, src/qmodel.cpp:2416-2422).  With the reads sharded over GPUs that sum
+ * is one RCCL all-reduce(sum, fp64) over xGMI of the flattened counts (qf_count_result.counts) and the log-likelihood.  One
+ * rank per GPU.  RCCL is loaded at the first qf_comm_* call (an RCCL already in the process, e.g. PyTorch's, is shared).
+ *   several processes: rank 0 calls qf_comm_unique_id, hands the 128 bytes to the other ranks by whatever channel launched
+ *                      them, and every rank calls qf_comm_init_rank (collective: returns when all n_ranks have called it);
+ *   one process:       qf_comm_init_all over one context per device (the `quaff train -gpus N` shell), then one host thread
+ *                      per context calls qf_allreduce_counts. */
+#define QF_COMM_ID_BYTES 128
+int qf_comm_unique_id(uint8_t *id /* [QF_COMM_ID_BYTES] */);
+int qf_comm_init_rank(qf_ctx *ctx, const uint8_t *id, int rank, int n_ranks);
+int qf_comm_init_all(qf_ctx *const *ctxs, int n);
+int qf_comm_size(const qf_ctx *ctx);   /* ranks of the context's communicator; 0 without one */
+void qf_comm_destroy(qf_ctx *ctx);     /* also done by qf_ctx_destroy */
+/* In place over host arrays: counts[n] (and *loglike, if not NULL) become the sums over all ranks.  Collective: every rank
+ * calls it with the same n.  Summation order inside RCCL depends on the rank count, so sums agree between runs on
+ * different numbers of GPUs to rounding (1e-15 relative), not bit for bit. */
+int qf_allreduce_counts(qf_ctx *ctx, double *counts, uint32_t n, double *loglike);
 
 /* ---- read-vs-read overlap (quaff overlap) -------------------------------------------------- */
 typedef struct qf_overlap_alignment {
@@ -231,6 +257,10 @@ typedef struct qf_overlap_result {
   const uint32_t *state_runs;
   float ms_prep, ms_seed, ms_fill, ms_traceback, ms_total;
   uint64_t traceback_bytes;
+  float ms_fill_class[QF_MAX_FILL_CLASSES];   /* per fill-kernel class, as in qf_align_result */
+  uint64_t cells_class[QF_MAX_FILL_CLASSES];
+  uint32_t units_class[QF_MAX_FILL_CLASSES];
+  uint32_t n_fill_classes;
 } qf_overlap_result;
 
 /* Align pairs of the resident sequences (qf_upload_reads: originals followed, if wanted, by their reverse complements,

@@ -62,7 +62,9 @@ class _CountResult(C.Structure):
                 ("counts", C.POINTER(C.c_double)), ("counts_size", C.c_uint32), ("loglike", C.c_double),
                 ("total_cells", C.c_uint64), ("backward_cells", C.c_uint64), ("forward_bytes", C.c_uint64),
                 ("ms_prep", C.c_float), ("ms_seed", C.c_float), ("ms_forward", C.c_float), ("ms_plan", C.c_float),
-                ("ms_backward", C.c_float), ("ms_total", C.c_float)]
+                ("ms_backward", C.c_float), ("ms_total", C.c_float),
+                ("ms_forward_class", C.c_float * 16), ("ms_backward_class", C.c_float * 16), ("cells_class", C.c_uint64 * 16),
+                ("units_class", C.c_uint32 * 16), ("n_fill_classes", C.c_uint32)]
 
 
 class _OverlapAlignment(C.Structure):
@@ -76,14 +78,17 @@ class _OverlapResult(C.Structure):
                 ("cells", C.POINTER(C.c_uint64)), ("n_diagonals", C.POINTER(C.c_uint32)), ("total_cells", C.c_uint64),
                 ("n_alignments", C.c_uint32), ("alignments", C.POINTER(_OverlapAlignment)),
                 ("state_runs", C.POINTER(C.c_uint32)), ("ms_prep", C.c_float), ("ms_seed", C.c_float),
-                ("ms_fill", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float), ("traceback_bytes", C.c_uint64)]
+                ("ms_fill", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float), ("traceback_bytes", C.c_uint64),
+                ("ms_fill_class", C.c_float * 16), ("cells_class", C.c_uint64 * 16), ("units_class", C.c_uint32 * 16),
+                ("n_fill_classes", C.c_uint32)]
 
 
 EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
            "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks",
-           "qf_device_count", "qf_set_score_threshold"]
+           "qf_device_count", "qf_set_score_threshold", "qf_comm_unique_id", "qf_comm_init_rank", "qf_comm_init_all",
+           "qf_comm_size", "qf_comm_destroy", "qf_allreduce_counts"]
 
 
 def load_library():
@@ -129,6 +134,12 @@ def load_library():
         L.qf_counts_size.argtypes = [C.c_void_p]
         L.qf_fill_class_name.restype = C.c_char_p
         L.qf_fill_class_name.argtypes = [C.c_uint32]
+        L.qf_comm_unique_id.argtypes = [C.c_char_p]
+        L.qf_comm_init_rank.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.qf_comm_size.argtypes = [C.c_void_p]
+        L.qf_comm_destroy.argtypes = [C.c_void_p]
+        L.qf_comm_destroy.restype = None
+        L.qf_allreduce_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -219,6 +230,32 @@ class Context:
         """Tests / A-B only (csrc/qf_internal.h, not part of the public ABI): force a kernel variant; results never change."""
         self.L.qf_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         self._chk(self.L.qf_debug_set_flags(self.h, flags))
+
+    # ---- E-step reduction across GPUs (RCCL)
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from rank 0 (ncclGetUniqueId) for every rank's comm_init_rank."""
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        rc = L.qf_comm_unique_id(buf)
+        if rc:
+            raise QuaffHipError(rc, L.qf_last_error(None).decode())
+        return buf.raw
+
+    def comm_init_rank(self, unique_id, rank, n_ranks):
+        """Collective: returns when all n_ranks contexts (one per GPU, any processes) have called it."""
+        assert len(unique_id) == 128
+        self._chk(self.L.qf_comm_init_rank(self.h, unique_id, rank, n_ranks))
+
+    def comm_size(self):
+        return int(self.L.qf_comm_size(self.h))
+
+    def allreduce_counts(self, counts, loglike):
+        """Sum the flattened E-step counts and the log-likelihood over all ranks (RCCL all-reduce, fp64); returns (counts, loglike)."""
+        v = np.ascontiguousarray(counts, dtype=np.float64).copy()
+        ll = C.c_double(float(loglike))
+        self._chk(self.L.qf_allreduce_counts(self.h, v.ctypes.data, len(v), C.byref(ll)))
+        return v, ll.value
 
     def set_score_threshold(self, min_score):
         """Alignments scoring below min_score are not traced back / returned (-inf = all; the CLI's -threshold)."""
@@ -331,7 +368,11 @@ class Context:
                               else [list(map(int, order[r, :int(cnt[r])])) for r in range(res.n_reads)],
                 "counts": arr(res.counts, res.counts_size), "loglike": res.loglike, "total_cells": int(res.total_cells),
                 "backward_cells": int(res.backward_cells), "forward_bytes": int(res.forward_bytes),
-                "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "forward", "plan", "backward", "total")}}
+                "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "forward", "plan", "backward", "total")},
+                "classes": [{"cls": k, "geometry": self.L.qf_fill_class_name(k).decode().replace("k_viterbi_", ""),
+                             "ms_forward": res.ms_forward_class[k], "ms_backward": res.ms_backward_class[k],
+                             "cells": int(res.cells_class[k]), "units": int(res.units_class[k])}
+                            for k in range(res.n_fill_classes) if res.units_class[k]]}
 
     def overlap_resident(self, pairs, cfg=None, raw=False):
         """pairs: list of (x index, y index, y_complemented) over the resident sequences, or a tuple of three numpy arrays

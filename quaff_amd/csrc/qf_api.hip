@@ -1,6 +1,8 @@
 // qf_api.hip — the C ABI of include/quaff_hip.h: context, device memory, batch orchestration.
 // No kernels here (qf_kernels.hip) and no model arithmetic (qf_model.cpp).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -96,6 +98,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};   // [6]: pair results final (their copy to the host overlaps selection and traceback); [7]: class lists final
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
+  hipEvent_t cls_ev2[kNumClasses] = {}, cls_end2[kNumClasses] = {};   // E-step: the Backward kernels (cls_ev / cls_end time Forward)
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   hipStream_t hi[3] = {};                                          // high priority: classes too small to fill the chip (latency-bound chains)
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
@@ -111,6 +114,8 @@ struct Slot {
     for (auto& e : ev) (void)hipEventCreate(&e);
     for (auto& e : cls_ev) (void)hipEventCreate(&e);
     for (auto& e : cls_end) (void)hipEventCreate(&e);
+    for (auto& e : cls_ev2) (void)hipEventCreate(&e);
+    for (auto& e : cls_end2) (void)hipEventCreate(&e);
     // side streams at the lowest priority: the small fill classes they carry should fill the gaps of the dominant class
     // (main stream), not compete with it
     int least = 0, greatest = 0;
@@ -128,6 +133,8 @@ struct Slot {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_end) if (e) (void)hipEventDestroy(e);
+    for (auto& e : cls_ev2) if (e) (void)hipEventDestroy(e);
+    for (auto& e : cls_end2) if (e) (void)hipEventDestroy(e);
     for (auto& s : aux) if (s) (void)hipStreamDestroy(s);
     for (auto& s : hi) if (s) (void)hipStreamDestroy(s);
     if (stream) (void)hipStreamDestroy(stream);
@@ -191,6 +198,10 @@ struct qf_ctx : Slot {
   HostBuf<double> h_ov_result, h_ov_score;
   std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
+  // E-step reduction over RCCL (qf_comm_*): communicator, this context's rank, a device staging buffer
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+  DevBuf d_comm;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -287,6 +298,7 @@ void qf_ctx_destroy(qf_ctx* c) {
                     &c->d_gap0, &c->d_gap1, &c->d_pair_result, &c->d_pair_ij, &c->d_skmer64, &c->d_skeys, &c->d_keys_tmp,
                     &c->d_vals_tmp, &c->d_off32, &c->d_rskeys, &c->d_roff32})
     b->release();
+  qf_comm_destroy(c);
   if (c->sort_temp) (void)hipFree(c->sort_temp);
   if (c->ev_tok) (void)hipEventDestroy(c->ev_tok);
   if (c->ev_nll) (void)hipEventDestroy(c->ev_nll);
@@ -1145,7 +1157,8 @@ uint32_t qf_counts_size(const qf_ctx* c) {
 // priority side streams), joined back into the main stream: small classes fill the tail of the big one.
 static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool serial,
                                        const std::function<void(int, hipStream_t)>& launch, int first_cls = 1,
-                                       bool small_first = false) {
+                                       bool small_first = false, hipEvent_t* ev_begin = nullptr, hipEvent_t* ev_end = nullptr) {
+  if (!ev_begin) { ev_begin = c->cls_ev; ev_end = c->cls_end; }
   int order[kNumClasses], n_used = 0;
   for (int cls = first_cls; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
   std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
@@ -1169,8 +1182,9 @@ static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool 
       const int cls = order[k];
       if (waves_of(cls) > 4096) continue;
       hipStream_t s = c->hi[k_small++ % 3];
+      HIPCHK(c, hipEventRecord(ev_begin[cls], s));
       launch(cls, s);
-      HIPCHK(c, hipEventRecord(c->cls_end[cls], s));
+      HIPCHK(c, hipEventRecord(ev_end[cls], s));
       joins[n_join++] = cls;      // the main stream joins them after its own class has been queued
       order[k] = -1;
     }
@@ -1180,13 +1194,12 @@ static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool 
     const int lane = serial ? 0 : (k_big < 4 ? k_big : 1 + (k_big - 1) % 3);
     ++k_big;
     hipStream_t s = lane == 0 ? c->stream : c->aux[lane - 1];
+    HIPCHK(c, hipEventRecord(ev_begin[cls], s));
     launch(cls, s);
-    if (lane) {
-      HIPCHK(c, hipEventRecord(c->cls_end[cls], s));
-      HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[cls], 0));
-    }
+    HIPCHK(c, hipEventRecord(ev_end[cls], s));
+    if (lane) HIPCHK(c, hipStreamWaitEvent(c->stream, ev_end[cls], 0));
   }
-  for (int k = 0; k < n_join; ++k) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_end[joins[k]], 0));
+  for (int k = 0; k < n_join; ++k) HIPCHK(c, hipStreamWaitEvent(c->stream, ev_end[joins[k]], 0));
   return QF_OK;
 }
 
@@ -1318,7 +1331,7 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
         f2.n_cls_units = bc.cls_count[cls];
         f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
         launch_backward_fill(cls, f2, s);
-      }, 0))
+      }, 0, false, c->cls_ev2, c->cls_end2))
     return rc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -1338,6 +1351,14 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_plan += ms;
   (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); out->ms_backward += ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    if (!bc.cls_count[cls]) continue;
+    ms = 0; (void)hipEventElapsedTime(&ms, c->cls_ev[cls], c->cls_end[cls]); out->ms_forward_class[cls] += ms;
+    ms = 0; (void)hipEventElapsedTime(&ms, c->cls_ev2[cls], c->cls_end2[cls]); out->ms_backward_class[cls] += ms;
+    out->cells_class[cls] += bc.cls_cells[cls];
+    out->units_class[cls] += bc.cls_count[cls];
+  }
+  out->n_fill_classes = kNumClasses;
   (void)csize;
   return QF_OK;
 }
@@ -1614,6 +1635,13 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); out->ms_fill += ms;
   (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_traceback += ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    if (!seed_bc.cls_count[cls] || (cls > 10 && cls != kRowClass)) continue;
+    ms = 0; (void)hipEventElapsedTime(&ms, c->cls_ev[cls], c->cls_end[cls]); out->ms_fill_class[cls] += ms;
+    out->cells_class[cls] += seed_bc.cls_cells[cls];
+    out->units_class[cls] += seed_bc.cls_count[cls];
+  }
+  out->n_fill_classes = kNumClasses;
   return QF_OK;
 }
 
@@ -1784,6 +1812,124 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   out->n_alignments = n_recs;
   out->alignments = c->h_ov_align.data();
   out->state_runs = c->h_runs.data();
+  return QF_OK;
+}
+
+// ------------------------------------------------------------------------------ E-step reduction (RCCL)
+// QuaffCountingScheduler::finalCounts / finalLogLike (src/qmodel.cpp:2416-2422) sum the per-read counts and log-likelihoods
+// of all worker threads; with reads sharded over GPUs that sum is one all-reduce(sum, fp64) of the flattened counts and the
+// log-likelihood per EM iteration.  RCCL is bound at run time (dlopen): a process that already carries an RCCL (PyTorch's)
+// shares it, and single-GPU users never load it.
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+  bool load() {
+    if (h) return true;
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) err = std::string("RCCL lacks ") + n; return p; };
+    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+    AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommInitAll || !AllReduce || !CommDestroy || !GetErrorString) { h = nullptr; return false; }
+    return true;
+  }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+}  // namespace
+
+int qf_comm_unique_id(uint8_t* id) {
+  static_assert(QF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "QF_COMM_ID_BYTES mirrors ncclUniqueId");
+  if (!id) return QF_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!g_rccl.load()) { g_create_error = g_rccl.err; return QF_ERR_DEVICE; }
+  ncclUniqueId u;
+  const ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return QF_ERR_DEVICE; }
+  memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return QF_OK;
+}
+
+int qf_comm_init_rank(qf_ctx* c, const uint8_t* id, int rank, int n_ranks) {
+  if (!c || !id) return QF_ERR_ARG;
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, QF_ERR_ARG, "rank out of range");
+  {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.load()) return fail(c, QF_ERR_DEVICE, g_rccl.err);
+  }
+  qf_comm_destroy(c);
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  const ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, u, rank);   // blocks until all n_ranks have called it
+  if (r != ncclSuccess) { c->comm = nullptr; return fail(c, QF_ERR_DEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+  c->comm_rank = rank;
+  c->comm_size = n_ranks;
+  return QF_OK;
+}
+
+int qf_comm_init_all(qf_ctx* const* ctxs, int n) {
+  if (!ctxs || n < 1) return QF_ERR_ARG;
+  for (int k = 0; k < n; ++k) if (!ctxs[k]) return QF_ERR_ARG;
+  qf_ctx* c0 = ctxs[0];
+  std::vector<int> dev(n);
+  for (int k = 0; k < n; ++k) {
+    dev[k] = ctxs[k]->device;
+    for (int q = 0; q < k; ++q)
+      if (dev[q] == dev[k]) return fail(c0, QF_ERR_UNSUPPORTED, "two contexts on one device cannot share an RCCL communicator (one rank per GPU)");
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.load()) return fail(c0, QF_ERR_DEVICE, g_rccl.err);
+  }
+  for (int k = 0; k < n; ++k) qf_comm_destroy(ctxs[k]);
+  std::vector<ncclComm_t> comms(n, nullptr);
+  const ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, dev.data());
+  if (r != ncclSuccess) return fail(c0, QF_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+  for (int k = 0; k < n; ++k) { ctxs[k]->comm = comms[k]; ctxs[k]->comm_rank = k; ctxs[k]->comm_size = n; }
+  return QF_OK;
+}
+
+int qf_comm_size(const qf_ctx* c) { return c && c->comm ? c->comm_size : 0; }
+
+void qf_comm_destroy(qf_ctx* c) {
+  if (!c || !c->comm) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_size = 1;
+  c->d_comm.release();
+}
+
+int qf_allreduce_counts(qf_ctx* c, double* counts, uint32_t n, double* loglike) {
+  if (!c || (n && !counts)) return QF_ERR_ARG;
+  if (!c->comm) return fail(c, QF_ERR_STATE, "no communicator (qf_comm_init_rank / qf_comm_init_all)");
+  const size_t m = (size_t)n + (loglike ? 1 : 0);
+  if (!m) return QF_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_comm.reserve(m * 8));
+  double* d = c->d_comm.as<double>();
+  if (n) HIPCHK(c, hipMemcpyAsync(d, counts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  if (loglike) HIPCHK(c, hipMemcpyAsync(d + n, loglike, 8, hipMemcpyHostToDevice, c->stream));
+  const ncclResult_t r = g_rccl.AllReduce(d, d, m, ncclDouble, ncclSum, c->comm, c->stream);
+  if (r != ncclSuccess) return fail(c, QF_ERR_DEVICE, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  if (n) HIPCHK(c, hipMemcpyAsync(counts, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (loglike) HIPCHK(c, hipMemcpyAsync(loglike, d + n, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return QF_OK;
 }
 

@@ -273,6 +273,7 @@ struct Opts {
   bool autoMem = false;
   uint64_t memTotal = 0;
   unsigned threads = 1;
+  bool wantComm = false;   // train / count: the device contexts share an RCCL communicator
   int gpus = 1;   // -gpus <n|all>: devices the read batches are spread over (this build's counterpart of -threads)
   vector<string> refFiles, readFiles;
   bool fwdstrand = false, noquals = false;
@@ -436,7 +437,16 @@ struct Session {
       ctxs.push_back(c);
     }
     ctx = ctxs[0];
+    // E-step sums of `train` / `count` go over RCCL when every context has a GPU of its own (one rank per GPU); several
+    // contexts on one GPU (QUAFF_HIP_DEVICES=0,0: a test arrangement) are summed by the host instead
+    bool distinct = ctxs.size() > 1;
+    for (size_t a = 0; a < dev.size(); ++a) for (size_t b = 0; b < a; ++b) distinct = distinct && dev[a] != dev[b];
+    if (distinct && o.wantComm) {
+      if (qf_comm_init_all(ctxs.data(), (int)ctxs.size()) != QF_OK) Fail(string("libquaffhip: ") + qf_last_error(ctxs[0]));
+      rccl = true;
+    }
   }
+  bool rccl = false;
   ~Session() { for (qf_ctx* c : ctxs) qf_ctx_destroy(c); }
   size_t devices() const { return ctxs.size(); }
   // the printer's -threshold, applied on the device before the traceback (the printer still checks it)
@@ -551,8 +561,10 @@ static int cmdAlign(Opts& o) {
 static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_refs, bool useNull, vector<vector<uint32_t>>& sortOrder, double& logLike) {
   ParamCounts total(s.params.match_len, s.params.gap_len);
   logLike = 0;
-  // read blocks spread over the devices; block sums are added in read order (QuaffParamCounts::operator+ over tasks,
-  // src/qmodel.cpp:2416-2422), so the result does not depend on the device count
+  // read blocks spread over the devices, one round of blocks at a time; a round's block sums are combined by RCCL
+  // (qf_allreduce_counts) or, for several contexts on one GPU, added by the host in block order.  The device kernels add
+  // their count terms with floating-point atomics, so totals are reproducible to rounding (~1e-12 relative), not bit for
+  // bit, between runs and between device counts ("count reproducibility")
   const size_t G = s.devices(), n = reads.seqs.size();
   const size_t perCall = max<size_t>(1, ((size_t)1 << 28) / max<size_t>(1, (size_t)n_refs));   // the library takes 2^28 pairs per call
   const size_t batch = max<size_t>(1, min<size_t>({(size_t)16384, perCall, (n + G - 1) / G}));
@@ -560,37 +572,50 @@ static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_re
   if (!haveOrder) sortOrder.assign(n, vector<uint32_t>());
   for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
     const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
-    vector<vector<double>> counts(nrun);
-    vector<double> ll(nrun, 0.);
-    onDevices(nrun, [&](size_t k) {
-      const size_t lo = lo0 + k * batch, hi = min(n, lo + batch);
+    const size_t nact = s.rccl ? G : nrun;   // an all-reduce needs every rank, also those without a block in the last round
+    vector<vector<double>> counts(nact);
+    vector<double> ll(nact, 0.);
+    onDevices(nact, [&](size_t k) {
       qf_ctx* c = s.ctxs[k];
-      string seq, qual;
-      vector<uint64_t> off;
-      bool allQual;
-      packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
-      QFT(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo)));
-      vector<uint32_t> sin, snin;
-      if (haveOrder) {
-        for (size_t r = lo; r < hi; ++r) {
-          vector<uint32_t> row = sortOrder[r];
-          snin.push_back((uint32_t)row.size());
-          row.resize(n_refs, 0);
-          sin.insert(sin.end(), row.begin(), row.end());
+      string failure;
+      auto countBlock = [&]() {
+        if (k >= nrun) return;
+        const size_t lo = lo0 + k * batch, hi = min(n, lo + batch);
+        string seq, qual;
+        vector<uint64_t> off;
+        bool allQual;
+        packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
+        QFT(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo)));
+        vector<uint32_t> sin, snin;
+        if (haveOrder) {
+          for (size_t r = lo; r < hi; ++r) {
+            vector<uint32_t> row = sortOrder[r];
+            snin.push_back((uint32_t)row.size());
+            row.resize(n_refs, 0);
+            sin.insert(sin.end(), row.begin(), row.end());
+          }
         }
-      }
-      qf_count_result res;
-      QFT(c, qf_count_resident(c, &o.cfg, useNull ? 0 : QF_COUNT_FORCE, sin.empty() ? nullptr : sin.data(),
-                               snin.empty() ? nullptr : snin.data(), &res));
-      counts[k].assign(res.counts, res.counts + res.counts_size);
-      ll[k] = res.loglike;
-      for (size_t r = lo; r < hi; ++r) {   // each block owns its reads' rows
-        vector<uint32_t>& so = sortOrder[r];
-        so.clear();
-        for (uint32_t q = 0; q < res.sort_count[r - lo]; ++q) so.push_back(res.sort_order[(r - lo) * res.n_refs + q]);
-      }
+        qf_count_result res;
+        QFT(c, qf_count_resident(c, &o.cfg, useNull ? 0 : QF_COUNT_FORCE, sin.empty() ? nullptr : sin.data(),
+                                 snin.empty() ? nullptr : snin.data(), &res));
+        counts[k].assign(res.counts, res.counts + res.counts_size);
+        ll[k] = res.loglike;
+        for (size_t r = lo; r < hi; ++r) {   // each block owns its reads' rows
+          vector<uint32_t>& so = sortOrder[r];
+          so.clear();
+          for (uint32_t q = 0; q < res.sort_count[r - lo]; ++q) so.push_back(res.sort_order[(r - lo) * res.n_refs + q]);
+        }
+      };
+      if (!s.rccl) { countBlock(); return; }
+      // QuaffCountingScheduler::finalCounts / finalLogLike (src/qmodel.cpp:2416-2422) across the devices: one RCCL
+      // all-reduce per round.  It is a collective: a device whose block failed (or that has no block in the last round)
+      // still takes part, with zeros, and reports afterwards - the others must not be left waiting for it.
+      try { countBlock(); } catch (const std::exception& e) { failure = e.what(); }
+      if (counts[k].size() != total.v.size() || failure.size()) { counts[k].assign(total.v.size(), 0.); ll[k] = 0; }
+      QFT(c, qf_allreduce_counts(c, counts[k].data(), (uint32_t)counts[k].size(), &ll[k]));
+      if (failure.size()) throw std::runtime_error(failure);
     });
-    for (size_t k = 0; k < nrun; ++k) {
+    for (size_t k = 0; k < (s.rccl ? (size_t)1 : nrun); ++k) {
       for (size_t q = 0; q < counts[k].size(); ++q) total.v[q] += counts[k][q];
       logLike += ll[k];
     }
@@ -646,6 +671,7 @@ static int cmdTrainOrCount(Opts& o, bool training) {
   SeqSet reads, refs;
   reads.load(o.readFiles, "read", "-read", true, false, false);
   refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, false);
+  o.wantComm = true;
   Session s(o);
   s.loadNull(o, reads.seqs);
   if (!training) {

@@ -72,10 +72,47 @@ def allreduce_max(x):
     return float(t.item())
 
 
-def estep_allreduce(counts, loglike):
-    """The train E-step exchange: returns (global counts, global log-likelihood)."""
+def attach_rccl(ctx):
+    """Give the context (one per rank, one rank per GPU) the library's own RCCL communicator: rank 0's unique id travels
+    over the process group that launched the ranks.  Not possible when several ranks share one GPU (the one-GPU rehearsal
+    with gloo): RCCL wants a GPU per rank, and estep_allreduce then goes through torch.distributed instead."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    if dist.get_backend() != "nccl":
+        return False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init_rank(box[0], rank, world)
+    return True
+
+
+def estep_allreduce(counts, loglike, ctx=None):
+    """The train E-step exchange (QuaffCountingScheduler::finalCounts / finalLogLike, src/qmodel.cpp:2416-2422): returns
+    (global counts, global log-likelihood).  Through the library's qf_allreduce_counts when the context carries a
+    communicator (attach_rccl), else through the process group (gloo rehearsals on CPU / one GPU)."""
+    if ctx is not None and ctx.comm_size() > 0:
+        return ctx.allreduce_counts(counts, loglike)
     out = allreduce_sum(np.concatenate([np.asarray(counts, np.float64), [loglike]]))
     return out[:-1], float(out[-1])
+
+
+def balanced_blocks(weights, world):
+    """Cut items 0..n-1 (rows of the overlap pair triangle, reads of a full-DP batch) into `world` contiguous blocks of
+    nearly equal total weight: block r = [cuts[r], cuts[r+1]).  The reference balances dynamically (a shared task queue,
+    src/qoverlap.cpp:528-547, src/qmodel.cpp:2870-2882); ranks that share nothing at run time balance by weight instead."""
+    w = np.asarray(weights, dtype=np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    targets = cum[-1] * np.arange(1, world) / world
+    cuts = np.searchsorted(cum, targets, side="left")
+    # the boundary item goes to whichever side leaves the blocks closer to the target
+    for k, t in enumerate(targets):
+        c = int(cuts[k])
+        if c > 0 and abs(cum[c - 1] - t) <= abs(cum[min(c, len(w))] - t):
+            cuts[k] = c - 1
+    cuts = np.concatenate([[0], np.maximum.accumulate(cuts), [len(w)]]).astype(np.int64)
+    return cuts
 
 
 def finalize():

@@ -209,3 +209,74 @@ def test_cli_errors_exit_nonzero_with_the_reference_messages(tmp_path):
     (tmp_path / "short.fa").write_text(">tiny\nACG\n>r1\n" + ref[300:500] + "\n")
     ok = subprocess.run([QUAFF, "align", fa, str(tmp_path / "short.fa"), "-noquals", "-nothreshold"], capture_output=True, text=True, timeout=120)
     assert ok.returncode == 0 and ok.stdout.count("# STOCKHOLM") == 2, ok.stderr[-500:]
+
+
+def _overlap_expected(reads, cfg_kw=None):
+    """`quaff overlap` output as the reference would print it single-threaded: QuaffOverlapScheduler's pair order
+    (src/qoverlap.cpp:475-480,528-547) over originals + reverse complements, one Stockholm block per finite alignment,
+    rows re-paired by the indel squashing of src/qoverlap.cpp:231-267 (oracle: overlap_rows / overlap_stockholm)."""
+    params = O.Params.from_json(open(os.path.join(GOLDEN, "defaultparams.json")).read())
+    sc = O.Scores(params)
+    null = O.NullParams.fit(reads)                                   # `quaff overlap` without -null fits it to the reads
+    osc = [O.OverlapScores(params, sc, False), O.OverlapScores(params, sc, True)]
+    seqs = list(reads) + [r.revcomp() for r in reads]
+    cfg = O.DPConfig(kmer_threshold=14, **(cfg_kw or {}))
+    out, pairs = "", []
+    for nx, ny, comp in O.overlap_task_pairs(len(reads), len(seqs)):
+        al = O.overlap_pair(seqs[nx], seqs[ny], comp, osc[int(comp)], sc, null, cfg)
+        if al is not None:
+            out += O.overlap_stockholm(seqs[nx], seqs[ny], al)
+            pairs.append((seqs[nx].name, seqs[ny].name))
+    return out, pairs
+
+
+def test_overlap_rows_with_real_indels_match_the_oracle(tmp_path):
+    """12 reads (both strands) of one 1.6 kb stretch with 4 % insertions and 4 % deletions each: the overlaps' gap states come
+    in mixed insert / delete stretches, which the writer re-pairs (squashes).  Every Stockholm block byte for byte."""
+    rng = np.random.default_rng(57)
+    ref = rand_seq(rng, 1600)
+    reads = make_reads(rng, ref, 12, 900, sub=0.03, ins=0.04, dele=0.04)
+    fq = tmp_path / "reads.fq"
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    want, _ = _overlap_expected(reads)
+    got = run("overlap", str(fq), "-nothreshold")
+    assert want.count("# STOCKHOLM") > 60
+    # squashing happened: some block pairs bases that the raw state path had as separate insert and delete columns
+    assert got == want
+    assert run("overlap", str(fq), "-nothreshold", env_extra={"QUAFF_HIP_OVERLAP_CHUNK": "7"}) == want
+
+
+def test_overlap_pair_order_five_reads(tmp_path):
+    """Pair enumeration for N = 5 originals (+ 5 reverse complements): (nx, ny) with nx < N - 1... the order of the blocks
+    in the output is the order of O.overlap_task_pairs, which restates QuaffOverlapScheduler."""
+    import re
+    rng = np.random.default_rng(58)
+    ref = rand_seq(rng, 700)
+    reads = make_reads(rng, ref, 5, 500, sub=0.02, ins=0.01, dele=0.01)
+    fq = tmp_path / "reads.fq"
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    want, pairs = _overlap_expected(reads)
+    got = run("overlap", str(fq), "-nothreshold")
+    assert got == want
+    names = re.findall(r"#=GS CC read_x substr\((.+),\d+\.\.\d+\)\n#=GS CC read_y substr\((.+),\d+\.\.\d+\)", got)
+    assert names == pairs and len(pairs) == len(O.overlap_task_pairs(5, 10)) == 4 * 9 - 6   # every pair of overlapping 500-base reads aligns
+
+
+def test_config1_tiny_sequences_shorter_than_k():
+    """BASELINE config 1: `quaff align data/tiny.fasta data/tiny.fastq` — 4-base sequences, shorter than k = 6.  The reference
+    underflows an unsigned loop bound there (src/fastseq.cpp:247) and crashes; here such sequences simply have no k-mers, the
+    short-sequence rule (src/diagenv.cpp:23-29) gives them the full envelope, and the run is defined: exit 0, the four
+    alignments the oracle finds, byte for byte."""
+    fa, fq = os.path.join(GOLDEN, "tiny.fasta"), os.path.join(GOLDEN, "tiny.fastq")
+    got = run("align", fa, fq, "-nothreshold")
+    refs, reads = O.read_fastx(fa), O.read_fastx(fq)
+    refs = refs + [r.revcomp() for r in refs]
+    sc = O.Scores(O.Params.from_json(open(os.path.join(GOLDEN, "defaultparams.json")).read()))
+    null = O.NullParams.fit(reads)
+    want = ""
+    for rd in reads:
+        for al in O.align_read(refs, rd, sc, null, O.DPConfig()):
+            want += O.stockholm(refs[al["ref"]], rd, al)
+    assert got == want and got.count("# STOCKHOLM") == len(reads)
+    assert run("align", fa, fq) == "".join(b + "//\n" for b in want.split("//\n")[:-1]
+                                            if float(b.split("#=GF Score ")[1].split()[0]) >= 0)

@@ -1,0 +1,117 @@
+"""N > 1 on the device: the HIP E-step sharded over two ranks (one process each, both on this box's one GPU, process group
+gloo — RCCL wants a GPU per rank) must reproduce the one-rank result; the library's own RCCL path (qf_comm_*,
+qf_allreduce_counts) is exercised with a one-rank communicator; `bench.py --gpus 2` launches its ranks itself."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+WORKER = textwrap.dedent("""
+    import sys, json, os
+    import numpy as np
+    sys.path.insert(0, %r)
+    from quaff_amd import dist
+    rank, world, local = dist.init("gloo")
+    import quaff_amd as Q
+    from quaff_amd import api
+    ctx = Q.Context(0)
+    ctx.set_params_json(None)
+    ctx.set_null_json(open(%r).read())
+    ref = api.synth_ref(1, 6000)
+    ctx.set_refs([ref, api.revcomp(ref)])
+    seq, qual, off = api.synth_reads(2, ref, 3001, 600)
+    lo, hi = dist.shard_range(3001, rank, world)
+    b0, b1 = int(off[lo]), int(off[hi])
+    ctx.upload_reads_packed(seq[b0:b1], qual[b0:b1], (off[lo:hi + 1] - off[lo]).astype(np.uint64))
+    order = None
+    out = []
+    for it in range(2):                                   # second iteration on the pruned reference order
+        res = ctx.count_resident(Q.DPConfig(), sort_order=order, packed_order=True)
+        order = res["sort_order"]
+        counts, ll = dist.estep_allreduce(res["counts"], res["loglike"], ctx)
+        out.append({"counts": counts.tolist(), "ll": ll, "local_ll": res["loglike"]})
+    dist.barrier()
+    open(sys.argv[1] + "/rank%%d.json" %% rank, "w").write(json.dumps({"rank": rank, "lo": lo, "hi": hi, "its": out}))
+    ctx.close()
+    dist.finalize()
+""") % (ROOT, os.path.join(GOLDEN, "testquaffnullparams.json"))
+
+
+def test_hip_estep_on_two_ranks_matches_one_rank(tmp_path):
+    import quaff_amd as Q
+    from quaff_amd import api
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(tmp_path)],
+                         capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    rows = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(2)]
+    assert rows[0]["lo"] == 0 and rows[0]["hi"] == rows[1]["lo"] and rows[1]["hi"] == 3001
+    # one rank, whole batch
+    ctx = Q.Context(0)
+    ctx.set_params_json(None)
+    ctx.set_null_json(open(os.path.join(GOLDEN, "testquaffnullparams.json")).read())
+    ref = api.synth_ref(1, 6000)
+    ctx.set_refs([ref, api.revcomp(ref)])
+    seq, qual, off = api.synth_reads(2, ref, 3001, 600)
+    ctx.upload_reads_packed(seq, qual, off)
+    order = None
+    for it in range(2):
+        res = ctx.count_resident(Q.DPConfig(), sort_order=order, packed_order=True)
+        order = res["sort_order"]
+        for r in rows:
+            got = np.array(r["its"][it]["counts"])
+            assert np.array_equal(got, np.array(rows[0]["its"][it]["counts"]))          # every rank holds the same sum
+            big = np.abs(res["counts"]) > 1e-6
+            rel = np.abs(got - res["counts"])[big] / np.abs(res["counts"])[big]
+            assert rel.max() < 1e-4, (it, rel.max())
+            assert rel.max() < 1e-9, (it, rel.max())                                      # in fact: rounding of the atomic adds only
+            assert abs(r["its"][it]["ll"] - res["loglike"]) <= 1e-12 * abs(res["loglike"])
+        assert abs(rows[0]["its"][it]["local_ll"] + rows[1]["its"][it]["local_ll"] - res["loglike"]) <= 1e-12 * abs(res["loglike"])
+    ctx.close()
+
+
+def test_rccl_allreduce_counts_one_rank_communicator():
+    """qf_comm_unique_id -> qf_comm_init_rank -> qf_allreduce_counts through the C ABI with a communicator of one rank (the most
+    this box's single GPU allows): loads RCCL, creates the communicator, runs ncclAllReduce(sum, fp64) on the context's stream."""
+    import quaff_amd as Q
+    ctx = Q.Context(0)
+    ctx.set_params_json(None)
+    assert ctx.comm_size() == 0
+    with pytest.raises(Exception, match="no communicator"):
+        ctx.allreduce_counts(np.zeros(4), 0.0)
+    uid = Q.Context.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init_rank(uid, 0, 1)
+    assert ctx.comm_size() == 1
+    v = np.random.default_rng(1).random(24508)
+    got, ll = ctx.allreduce_counts(v, -1234.5)
+    assert np.array_equal(got, v) and ll == -1234.5
+    got, ll = ctx.allreduce_counts(np.zeros(0), 7.0)
+    assert len(got) == 0 and ll == 7.0
+    ctx.close()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 --single-device`: the parent starts two ranks (torch.distributed.run as a child process) and
+    relays rank 0's JSON line; n_gpus = 2, whole-job cells = both ranks' work."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--reads", "4000",
+                          "--steps", "2", "--warmup", "1", "--cpu-sample", "200"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["cpu_baseline"]["gpu_parity_mismatches"] == 0
+    assert j["config"]["cells_per_step"] > 2 * 4000 * 60000 and 0 < j["roofline"]["frac"] <= 1
+    assert j["roofline"]["bound"] == "fp64_valu" and "k_viterbi_fill<16,5,false,true>" in j["roofline"]["kernel"]
