@@ -214,7 +214,7 @@ struct qf_ctx : Slot {
   } while (0)
 
 constexpr uint64_t kMaxPairsPerCall = 1ull << 28;   // unit tables are sized 4 x pairs + slack in 32 bits
-constexpr size_t kLseHermiteOffset = 100002;  // doubles: the exact table (100001) padded to even, then the spline nodes
+constexpr size_t kLseHermiteOffset = 100002;  // doubles: the exact table (100001) padded to even, then the quadratic pieces
 
 static int fail(Slot* c, int code, const std::string& msg) {
   c->err = msg;
@@ -1148,6 +1148,37 @@ int qf_align_batch(qf_ctx* c, const qf_dp_config* cfg, const char* seq, const ch
 }
 
 // ------------------------------------------------------------------------- Forward-Backward E-step
+// Device copy of the reference's 100 001-entry log(1 + exp(-x)) table (src/logsumexp.cpp:20-28; exact-bits paths: overlap
+// gap states, per-read / per-pair sums) followed by the same function as kLsePieces quadratic pieces on a 1/128 grid for the
+// 1e-4-tolerance Forward / Backward fills (qf_fb.hip: lseh).  Piece n covers x in [n/128, (n+1)/128): the quadratic through
+// the function at the three Chebyshev nodes of the piece, in t = 128 x - n, with the linear and quadratic coefficients
+// rounded to fp32 (16 bytes per piece): within 3.3e-10 of log1p(exp(-x)) everywhere, the accuracy of the reference's own
+// 1e-4-step linear table.  The last piece is all zero: x >= 10 is the reference's cut-off (:84-90).
+static int ensure_lse(qf_ctx* c) {
+  if (c->lse_uploaded) return QF_OK;
+  std::vector<double> t = lse_table();
+  t.resize(kLseHermiteOffset, 0.0);
+  static_assert(sizeof(LsePiece) == 16, "one 16-byte LDS read per lookup");
+  std::vector<LsePiece> pieces(kLsePieces);
+  const double h = 1.0 / 128.0;
+  auto g = [](double x) { return std::log1p(std::exp(-x)); };
+  const double tn[3] = {0.5 - 0.5 * std::cos(M_PI / 6), 0.5, 0.5 - 0.5 * std::cos(5 * M_PI / 6)};   // Chebyshev nodes on [0, 1]
+  for (int n = 0; n < kLsePieces - 1; ++n) {
+    const double y0 = g((n + tn[0]) * h), y1 = g((n + tn[1]) * h), y2 = g((n + tn[2]) * h);
+    // Newton form through (tn[k], yk), expanded to monomials in t
+    const double d01 = (y1 - y0) / (tn[1] - tn[0]), d12 = (y2 - y1) / (tn[2] - tn[1]), d012 = (d12 - d01) / (tn[2] - tn[0]);
+    const double c2 = d012, c1 = d01 - d012 * (tn[0] + tn[1]), c0 = y0 - tn[0] * d01 + d012 * tn[0] * tn[1];
+    pieces[n] = LsePiece{c0, (float)c1, (float)c2};
+  }
+  pieces[kLsePieces - 1] = LsePiece{0.0, 0.f, 0.f};
+  const size_t bytes = kLseHermiteOffset * 8 + pieces.size() * sizeof(LsePiece);
+  HIPCHK(c, c->d_lse.reserve(bytes));
+  HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), kLseHermiteOffset * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_lse.as<char>() + kLseHermiteOffset * 8, pieces.data(), pieces.size() * sizeof(LsePiece), hipMemcpyHostToDevice));
+  c->lse_uploaded = true;
+  return QF_OK;
+}
+
 uint32_t qf_counts_size(const qf_ctx* c) {
   if (!c || !c->have_params) return 0;
   return (uint32_t)((4 + 4 * c->scores.Km) * kNQual + 4 * c->scores.Kg + 4);
@@ -1258,7 +1289,9 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.n_refs = n_refs;
   fa.units = c->d_units.as<Unit>();
   fa.ref_off = c->d_ref_off.as<uint64_t>();
+  fa.ref_woff = c->d_ref_woff.as<uint64_t>();
   fa.ref_tok = c->d_ref_tok.as<uint8_t>();
+  fa.ref_packed = c->d_ref_packed.as<uint32_t>();
   fa.read_off = d_roff;
   fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
   fa.fw = c->d_fw.as<double>();
@@ -1387,18 +1420,7 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   if (use_null && !c->have_null) return fail(c, QF_ERR_STATE, "no null model set (qf_set_null_json) and QF_COUNT_FORCE not given");
   const bool sparse = cfg->sparse != 0;
   if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
-  if (!c->lse_uploaded) {
-    std::vector<double> t = lse_table();
-    t.resize(kLseHermiteOffset, 0.0);
-    for (int k = 0; k <= 640; ++k) {   // Hermite nodes of log(1 + exp(-x)) on a 1/64 grid: value, slope
-      const double x = k / 64.0;
-      t.push_back(std::log1p(std::exp(-x)));
-      t.push_back(-1.0 / (1.0 + std::exp(x)));
-    }
-    HIPCHK(c, c->d_lse.reserve(t.size() * 8));
-    HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
-    c->lse_uploaded = true;
-  }
+  if (int rc = ensure_lse(c)) return rc;
 
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
@@ -1491,21 +1513,6 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
 }
 
 // ------------------------------------------------------------------------------ read-vs-read overlap
-static int ensure_lse(qf_ctx* c) {
-  if (c->lse_uploaded) return QF_OK;
-  std::vector<double> t = lse_table();
-  t.resize(kLseHermiteOffset, 0.0);
-  for (int k = 0; k <= 640; ++k) {
-    const double x = k / 64.0;
-    t.push_back(std::log1p(std::exp(-x)));
-    t.push_back(-1.0 / (1.0 + std::exp(x)));
-  }
-  HIPCHK(c, c->d_lse.reserve(t.size() * 8));
-  HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
-  c->lse_uploaded = true;
-  return QF_OK;
-}
-
 // Pairs [lo, hi) of the uploaded pair list.  Results go to the host arrays at the chunk's offsets; *too_big (nothing done)
 // when the chunk's traceback exceeds the memory budget.
 static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t lo, uint32_t hi,

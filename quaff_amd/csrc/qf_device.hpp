@@ -156,6 +156,8 @@ struct BatchCounters {
   unsigned long long total_runs_out;  // compacted CIGAR runs written by the traceback kernel
 };
 
+constexpr int kLsePieces = 1281;   // quadratic pieces of log(1 + exp(-x)) on a 1/128 grid over [0, 10) + the all-zero piece of the cut-off
+struct LsePiece { double c0; float c1, c2; };   // c0 + t (c1 + t c2), t = 128 x - n in [0, 1): 16 bytes, one ds_read_b128 per lookup
 constexpr uint32_t kInsRows = 4 * 95;  // insert-emission table: [token * 95 + quality]
 
 struct DpParams {  // kernel argument block for the fills

@@ -1,0 +1,34 @@
+// qf_dpp.hpp — neighbour-lane exchange by DPP row / wave shifts (gfx950), shared by the fill kernels.
+// One v_mov_b32_dpp per dword instead of a ds_bpermute through LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace qf {
+
+// ZERO: the group's edge lane receives 0.0 (both dwords zero-filled by bound_ctrl) instead of -inf
+template <int G, bool ZERO>
+__device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf (or 0) in the group's lane 0
+  constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
+  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
+                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int G, bool ZERO>
+__device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf (or 0) in the group's last lane
+  constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
+  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
+                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int G>
+__device__ __forceinline__ float dpp_f32_from_above(float v) {  // lane l+1's value; 0 in the group's last lane
+  constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true));
+}
+
+}  // namespace qf

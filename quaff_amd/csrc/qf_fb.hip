@@ -8,13 +8,16 @@
 // be re-associated: per-column count partials are combined in an LDS ring and flushed with fp64 atomics.
 #include <hip/hip_runtime.h>
 
+#include "qf_dpp.hpp"
 #include "qf_kernels.hpp"
 
 namespace qf {
 
+struct __attribute__((packed, aligned(4))) U32x4f { uint32_t v[4]; };   // 16-byte load from a 4-byte aligned address
+
 #define QF_NEG_INF (-__builtin_huge_val())
 #ifndef QF_BWD_WAVES
-#define QF_BWD_WAVES 3
+#define QF_BWD_WAVES 1
 #endif
 
 // log_sum_exp, src/logsumexp.cpp:34-50 + log_sum_exp_unary :84-103 (x >= 10, NaN, inf -> 0).
@@ -33,38 +36,72 @@ __device__ __forceinline__ double lse2(const double* __restrict__ tab, double a,
 // Expected counts are compared at 1e-4 relative: their exponential goes through the single-precision hardware exp2
 // (relative error ~1e-7 for the terms that matter, |x| of a few units; <= 1e-5 for the negligible ones near underflow;
 // below ~-87 the count flushes to 0).  The double-precision software exp was ~250 of Backward's ~300 VALU per cell.
+__device__ __forceinline__ float count_expf(double x) { return __expf((float)x); }
 __device__ __forceinline__ double count_exp(double x) { return (double)__expf((float)x); }
 
-
 // Forward / Backward are compared at 1e-4 relative, so their log(1 + exp(-x)) need not be the reference's table
-// interpolant bit for bit.  The 800 KB table is a 64-way L2 gather per call (a third of Forward's time, measured); the
-// same function as a cubic Hermite spline on a 1/64 grid (641 nodes of value and slope, 10 KB) sits in LDS.  It is
-// within 2e-11 of log1p(exp(-x)); the reference's own 1e-4-step linear interpolant is within 3e-10 of it.  The x >= 10
-// cut-off and the a == b rule are the reference's (src/logsumexp.cpp:34-50, :84-103).
-constexpr int kLseNodes = 641;
+// interpolant bit for bit.  The 800 KB table is a 64-way L2 gather per call; the same function as kLsePieces quadratic
+// pieces on a 1/128 grid (20 KB; host: ensure_lse, qf_api.hip) sits in LDS: within 3.3e-10 of log1p(exp(-x)), the
+// accuracy of the reference's own 1e-4-step linear interpolant.  What these kernels spend their time on is exactly this
+// lookup -- a 64-lane LDS gather with bank conflicts (~38 cycles of the CU's LDS per 16-byte-per-lane read, measured) --
+// so a piece is 16 bytes (fp64 constant term, fp32 linear and quadratic terms): one ds_read_b128 per call.  The x >= 10
+// cut-off is the reference's (src/logsumexp.cpp:84-90): the last piece is all zero and x is clamped onto it; -inf - -inf =
+// NaN and +-inf land there too (v_min_f64 returns its non-NaN operand), which gives max + 0 like the reference's a == b /
+// isinf rules.
+constexpr int kLseDoubles = kLsePieces * 2;   // LDS footprint in doubles
 __device__ __forceinline__ void lseh_load(double* s_h, const double* __restrict__ g_h, int tid, int nthreads) {
-  for (int k = tid; k < 2 * kLseNodes; k += nthreads) s_h[k] = g_h[k];
+  for (int k = tid; k < kLseDoubles; k += nthreads) s_h[k] = g_h[k];
+}
+// v_max_f64 / v_min_f64 as they are: the compiler's fmax / fmin first canonicalise both operands (one more v_max_f64 each)
+// to quiet signalling NaNs, which these values never are; the instructions themselves return the non-NaN operand.
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 __device__ __forceinline__ double lseh(const double* hs, double a, double b) {
-  // branch-free: the spline is evaluated at a clamped argument and discarded when the cut-off (or -inf - -inf = NaN)
-  // applies, so the several calls of a cell overlap instead of each taking its own divergent branch
-  const double mx = fmax(a, b), mn = fmin(a, b);
-  const double diff = mx - mn;
-  const double u = fmin(diff * 64.0, 639.984375);   // NaN -> the bound
+  const double mx = vmax_f64(a, b);
+  const double u = vmin_f64(fabs(a - b) * 128.0, (double)(kLsePieces - 1));
   const int n = (int)u;
-  const double t = u - (double)n, s = 1.0 - t;
-  const double g0 = hs[2 * n], d0 = hs[2 * n + 1], g1 = hs[2 * n + 2], d1 = hs[2 * n + 3];
-  const double t2 = t * t, s2 = s * s;
-  const double p = (g0 * (1.0 + 2.0 * t) + d0 * (t * (1.0 / 64.0))) * s2 + (g1 * (3.0 - 2.0 * t) - d1 * (s * (1.0 / 64.0))) * t2;
-  return mx + (diff < 10.0 ? p : (a == b ? hs[0] : 0.0));
+  const double t = __builtin_amdgcn_fract(u);
+  const LsePiece q = ((const LsePiece*)hs)[n];
+  return mx + fma(t, fma(t, (double)q.c2, (double)q.c1), q.c0);
 }
 
-template <int G, int B>
-__global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
-  __shared__ double s_lseh[2 * kLseNodes];
-  lseh_load(s_lseh, a.lse_h, threadIdx.x, 256);
+// ------------------------------------------------------------------------------------------------
+// Forward fill: the skewed G x B wavefront of k_viterbi_fill (qf_kernels.hip) with log-sum-exp for max.
+//  * dynamic LDS: the lse pieces, the context-dependent transition scores, and (EMLDS) the emission tables;
+//  * the context word, reference-token window and emission scores of step t+1 are fetched at step t;
+//  * no per-cell validity masks: cells above the band's last diagonal or outside the reference read a -inf match emission,
+//    which keeps them at -inf (see emis below); the start term and the end terms sit in wave-uniform branches that are
+//    taken only while some lane is on its first / last column;
+//  * neighbour lanes exchange by DPP shifts.
+// Storage: fw[((t * B + b) * 3 + state) * G + lane] (step-major: every store instruction of a wavefront covers four
+// contiguous 128-byte segments).
+// ------------------------------------------------------------------------------------------------
+#ifndef QF_FWD_WAVES
+#define QF_FWD_WAVES 3
+#endif
+template <int G, int B, bool GAPCTX, bool EMLDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF_FWD_WAVES : B <= 8 ? 2 : 1))) void k_forward_fill(FbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_fb[];
+  const uint32_t Kg = a.dp.Kg;
+  const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
+  double* s_trans = lds_fb + kLseDoubles;
+  double* s_em = s_trans + ((4 * Kg + 1) & ~1u);
+  lseh_load(lds_fb, a.lse_h, threadIdx.x, 256);
+  for (uint32_t k = threadIdx.x; k < 4 * Kg; k += 256) s_trans[k] = a.dp.trans[k];
+  if (EMLDS) {
+    for (uint32_t k = threadIdx.x; k < n_em; k += 256) s_em[k] = a.dp.ematch[k];
+    for (uint32_t k = threadIdx.x; k < kInsRows; k += 256) s_em[n_em + k] = a.dp.eins[k];
+  }
   __syncthreads();
-  const double* hs = s_lseh;
+  const double* hs = lds_fb;
   constexpr int UPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -73,26 +110,25 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
   const bool active = uidx < a.n_cls_units;
   uint32_t uid = 0;
   int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
-  uint64_t xb = 0, yb = 0, fw_off = 0;
+  uint64_t xb = 0, yb = 0, xw = 0, fw_off = 0;
   if (active) {
     uid = a.cls_list[uidx];
     const Unit u = a.units[uid];
     const uint32_t r = u.pair / a.n_refs, x = u.pair % a.n_refs;
-    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb);
+    xb = a.ref_off[x]; xLen = (int)(a.ref_off[x + 1] - xb); xw = a.ref_woff[x];
     yb = a.read_off[r]; yLen = (int)(a.read_off[r + 1] - yb);
     dlo = u.dlo; dhi = u.dhi; fw_off = u.tb_off;
   }
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   const int d0 = dlo + l * B;
+  const int bmax = active ? dhi - d0 : -1;  // slots b > bmax are outside the band
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
-  const double* __restrict__ ematch = a.dp.ematch;
-  const double* __restrict__ eins = a.dp.eins;
-  const double* __restrict__ trans = a.dp.trans;
-  const uint32_t Kg = a.dp.Kg;
+  const double* __restrict__ ematch = EMLDS ? s_em : a.dp.ematch;
+  const double* __restrict__ eins = EMLDS ? s_em + n_em : a.dp.eins;
+  const double* __restrict__ trans = s_trans;
   const bool local = a.dp.local != 0;
-  const uint8_t* __restrict__ xt = a.ref_tok + xb;
-  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg];
   double* __restrict__ fw = a.fw + fw_off;
 
   double M[B], I[B], D[B];
@@ -102,56 +138,114 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
   double endTerm[B];  // mat(i,yLen) + m2e for this lane's rows of the last column
 #pragma unroll
   for (int b = 0; b < B; ++b) endTerm[b] = QF_NEG_INF;
-  uint32_t gkPrev = 0;
-  // reference tokens of the lane's B rows as a sliding 2-bit window: the rows move down by one per step, so one new token
-  // per step (fetched a step ahead) instead of B byte gathers
-  auto xtok = [&](int idx0) -> uint32_t { return (idx0 >= 0 && idx0 < xLen) ? (uint32_t)xt[idx0] : 0u; };
-  unsigned long long win = 0;
-#pragma unroll
-  for (int b = 0; b < B; ++b) win |= (unsigned long long)xtok(d0 + b + (0 - l + 1) - 1) << (2 * b);
-  uint32_t tokNext = xtok(d0 + B - 1 + (0 - l + 1));   // slot B-1's token at the next step
-  for (int t = 0; t < T; ++t) {
-    const int j = t - l + 1;
-    const bool colvalid = active && j >= 1 && j <= yLen;
-    const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
-    const uint32_t erow4 = (w & 0x7FFFu) * 4u, insrow = (w >> 15) & 0x1FFu, gk = w >> 24;
-    const uint32_t gp = j > 1 ? gkPrev : 0u;  // yIndelKmer is padded with a leading 0 (qmodel.cpp:1322)
-    const double m2m = trans[gp], m2i = trans[Kg + gp], m2d = trans[2 * Kg + gk];
-    gkPrev = gk;
-    const double insE = eins[insrow];
-    double lowM = __shfl_up(pubM, 1, G), lowD = __shfl_up(pubD, 1, G);
-    if (l == 0) { lowM = QF_NEG_INF; lowD = QF_NEG_INF; }
-    double upM = 0, upI = 0, prevM = lowM, prevD = lowD;
+
+  // reference tokens: a window of the lane's B rows (slot b at bits 2b), one new token per step taken from the 2-bit packed
+  // reference (a 64-bit pair of words per 16 steps, the next word fetched a chunk ahead) -- as k_viterbi_fill
+  const uint32_t* __restrict__ xp = a.ref_packed + xw;
+  const int nxw = (xLen + 15) / 16 + 2;
+  const int rtop0 = d0 - l + B - 1;
+  const int q0 = rtop0 >> 4, sh0 = 2 * (rtop0 & 15);
+  auto xword = [&](int q) -> uint32_t { return xp[min(max(q, 0), nxw - 1)]; };
+  uint32_t xlo, xhi = xword(q0), xnx = xword(q0 + 1);
+  uint32_t win = 0;
+  {
+    const uint8_t* xt = a.ref_tok + xb;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      const int d = d0 + b, i = d + j;
-      const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
-      const uint32_t tok = (uint32_t)(win >> (2 * b)) & 3u;
-      const double e = ematch[erow4 + tok];
-      // mat(i,j) = lse(lse(mat' + m2m, del' + d2m), ins' + i2m) [lse with start at column 1] + emit
-      double nm = lseh(hs, lseh(hs, M[b] + m2m, D[b] + d2m), I[b] + i2m);
-      if (j == 1 && (i == 1 || local)) nm = lseh(hs, nm, 0.0);
-      nm += e;
-      double srcM, srcI;
-      if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
-      double ni = insE + lseh(hs, srcI + i2i, srcM + m2i);
-      double ndl = lseh(hs, prevD + d2d, prevM + m2d);
-      if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
-      M[b] = nm; I[b] = ni; D[b] = ndl;
-      prevM = nm; prevD = ndl;
-      if (colvalid) {
-        const uint64_t base = ((uint64_t)t * B + b) * 3 * G + l;
-        fw[base] = nm; fw[base + G] = ni; fw[base + 2 * G] = ndl;
-      }
-      if (j == yLen && valid && (local || i == xLen)) endTerm[b] = nm + trans[3 * Kg + gk];
-      if (b == 0) {
-        upM = __shfl_down(nm, 1, G); upI = __shfl_down(ni, 1, G);
-        if (l == G - 1) { upM = QF_NEG_INF; upI = QF_NEG_INF; }
-      }
+      const int row = d0 - l - 1 + b;
+      const uint32_t t = (row >= 0 && row < xLen) ? xt[row] : 0u;
+      win |= t << (2 * b);
     }
-    pubM = prevM; pubD = prevD;
-    win = (win >> 2) | ((unsigned long long)tokNext << (2 * (B - 1)));
-    tokNext = xtok(d0 + B - 1 + j + 1);
+  }
+  const uint32_t* __restrict__ ctx = a.ctx + yb;
+  // context words: the word of step t (column j = t - l + 1, index j - 1 = t - l) is loaded two steps ahead, because the
+  // emission scores of step t+1 are fetched at step t
+  auto ctxword = [&](int t) -> uint32_t { return ctx[min(t - l, yLen + 4)]; };
+  uint32_t gkPrev = 0;
+  const uint32_t ninf_off = a.dp.ematch_ninf_off;
+  // match emission of slot b at reference row i: -inf above the band's last diagonal and outside the reference.  That alone
+  // keeps every cell outside the band / matrix at -inf (match by its emission, insert and delete by induction from -inf
+  // neighbours), except the delete state just outside, which a cell of the band never reads.
+  auto emis = [&](uint32_t w, uint32_t window, int b, int i) -> double {
+    uint32_t off = ((w & 0x7FFFu) << 5) | (((window >> (2 * b)) & 3u) << 3);
+    if (b > bmax || (uint32_t)(i - 1) >= (uint32_t)xLen) off = ninf_off;
+    return *(const double*)((const char*)ematch + off);
+  };
+  uint32_t wN = ctxword(0), wNN = ctxword(1);
+  const uint32_t tok0 = (uint32_t)((((unsigned long long)xnx << 32) | xhi) >> sh0) & 3u;
+  uint32_t winN = (win >> 2) | (tok0 << (2 * (B - 1)));
+  double eN[B], insEN = eins[(wN >> 15) & 0x1FFu];
+#pragma unroll
+  for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b, d0 + b + 1 - l);
+
+  // lanes are on column 1 at steps 0 .. G-1 (start term) and on their last column at steps endLo .. endHi (end terms)
+  int endLo = active ? yLen + l - 1 : 0x7FFFFFFF, endHi = active ? yLen + l - 1 : -1;
+  for (int o = 32; o; o >>= 1) {
+    endLo = min(endLo, __shfl_xor(endLo, o));
+    endHi = max(endHi, __shfl_xor(endHi, o));
+  }
+  endLo = __builtin_amdgcn_readfirstlane(endLo);
+  endHi = __builtin_amdgcn_readfirstlane(endHi);
+
+  int chunk = 0;
+  for (int t0 = 0; t0 <= endHi; t0 += 16, ++chunk) {
+    xlo = xhi; xhi = xnx; xnx = xword(q0 + chunk + 2);
+    const unsigned long long xpair = ((unsigned long long)xhi << 32) | xlo;
+#pragma unroll 1
+    for (int s = 0; s < 16; ++s) {
+      const int t = t0 + s;
+      if (t > endHi) break;
+      const int j = t - l + 1;
+      const uint32_t w = wN;
+      double e[B];
+      const double insE = insEN;
+#pragma unroll
+      for (int b = 0; b < B; ++b) e[b] = eN[b];
+      // step t+1's fetches (the token of step 16 of a chunk is the next chunk's first: still inside the 64-bit window)
+      wN = wNN;
+      wNN = ctxword(t + 2);
+      winN = (winN >> 2) | (((uint32_t)(xpair >> (sh0 + 2 * (s + 1))) & 3u) << (2 * (B - 1)));
+      insEN = eins[(wN >> 15) & 0x1FFu];
+#pragma unroll
+      for (int b = 0; b < B; ++b) eN[b] = emis(wN, winN, b, d0 + b + j + 1);
+      const uint32_t gk = w >> 24;
+      double m2m, m2i, m2d;
+      if (GAPCTX) {
+        const uint32_t gp = j <= 1 ? 0u : gkPrev;   // yIndelKmer is padded with a leading 0 (qmodel.cpp:1322)
+        m2m = trans[gp]; m2i = trans[Kg + gp]; m2d = trans[2 * Kg + gk];
+        gkPrev = gk;
+      } else {
+        m2m = c_m2m; m2i = c_m2i; m2d = c_m2d;
+      }
+      double prevM = dpp_from_below<G, false>(pubM), prevD = dpp_from_below<G, false>(pubD);
+      double upM = 0, upI = 0;
+      const bool colvalid = active && j >= 1 && j <= yLen;
+      const bool startStep = t < G, endStep = t >= endLo;   // wave-uniform
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        // mat(i,j) = lse(lse(mat' + m2m, del' + d2m), ins' + i2m) [lse with start on column 1] + emit  (src/qmodel.cpp:1363-1372)
+        double nm = lseh(hs, lseh(hs, M[b] + m2m, D[b] + d2m), I[b] + i2m);
+        if (startStep) {
+          if (j == 1 && (d0 + b == 0 || local)) nm = lseh(hs, nm, 0.0);
+        }
+        nm += e[b];
+        double srcM, srcI;
+        if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
+        const double ni = insE + lseh(hs, srcI + i2i, srcM + m2i);
+        const double ndl = lseh(hs, prevD + d2d, prevM + m2d);
+        M[b] = nm; I[b] = ni; D[b] = ndl;
+        prevM = nm; prevD = ndl;
+        if (colvalid && b <= bmax) {
+          const uint64_t base = ((uint64_t)t * B + b) * 3 * G + l;
+          fw[base] = nm; fw[base + G] = ni; fw[base + 2 * G] = ndl;
+        }
+        if (endStep) {
+          if (colvalid && j == yLen && (local || d0 + b + j == xLen)) endTerm[b] = nm + trans[3 * Kg + gk];   // (-inf outside band / matrix)
+        }
+        if (b == 0) { upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); }
+      }
+      pubM = prevM; pubD = prevD;
+    }
   }
   // end = lse(end, mat(i,yLen) + m2e) accumulated over rows in ascending order (src/qmodel.cpp:1379-1381): chain the
   // lanes one after the other
@@ -170,7 +264,7 @@ __global__ __launch_bounds__(256) void k_forward_fill(FbArgs a) {
 // a 16 x 2 wavefront group with 31 of its 32 slots idle.  The values go where slot 0 of lane 0 of the (16,2) layout keeps
 // them (k_backward_fill<16,2> reads only the band's own diagonal), same arithmetic as k_forward_fill.
 __global__ __launch_bounds__(256) void k_forward_single(FbArgs a) {
-  __shared__ double s_lseh[2 * kLseNodes];
+  __shared__ __attribute__((aligned(16))) double s_lseh[kLseDoubles];
   lseh_load(s_lseh, a.lse_h, threadIdx.x, 256);
   __syncthreads();
   const double* hs = s_lseh;
@@ -305,26 +399,48 @@ __global__ void k_count_plan(CountPlanArgs a) {
   a.read_loglike[r] = ylog;
 }
 
-// Backward sweep.  Lane l handles column j = yLen - (t - (G-1-l)); slots run from high diagonal to low, so
+// ------------------------------------------------------------------------------------------------
+// Backward sweep with the E-step counts.  Lane l handles column j = yLen - (t - (G-1-l)); slots run from high diagonal to
+// low, so
 //   (i+1,j+1): same diagonal, previous step (own registers)
 //   (i+1,j  ): diagonal d+1, same column   (own slot b+1 this step, or lane l+1's slot 0 from the previous step)
 //   (i,  j+1): diagonal d-1, next column   (own slot b-1 from the previous step, or lane l-1's last slot, which that
 //                                           lane finishes first in this very step)
 // Each cell is treated as a SOURCE: its Backward values are the lse of (transition + emission + Backward of the
-// destination), and the expected count of each of those transitions is exp(F_src + term - F_result) — the same
+// destination), and the expected count of each of those transitions is exp(F_src + term - F_result) -- the same
 // operands, in the same association, as transCount (src/qmodel.cpp:1504-1510).
-template <int G, int B>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF_BWD_WAVES : 1))) void k_backward_fill(FbArgs a) {
-  __shared__ double s_lseh[2 * kLseNodes];
-  lseh_load(s_lseh, a.lse_h, threadIdx.x, 256);
+//  * same LDS tables and one-step-ahead fetches (context word, token, emissions, and the cell's three Forward values) as
+//    k_forward_fill, and no per-cell validity masks either: a destination above the band's last diagonal or outside the
+//    reference has a -inf match emission.  By induction (down the rows from the band's top edge for the delete state, along
+//    the row from the last column for the insert state) every source cell above the band or below the last reference row
+//    then stays at -inf, which is all a cell of the band reads from them; source rows above row 1 are read by nobody.
+//    Cells that do not exist read a -inf Forward value, so their counts are exp(-inf) = 0.  End transitions and the
+//    start term sit in wave-uniform branches taken only while some lane is on its last / first column;
+//  * count terms are formed in fp32 (hardware exp2; fp32 partial sums over the B cells of one step), converted once per
+//    step and accumulated in fp64; the pair's posterior weight multiplies at the flush, not per term.
+// ------------------------------------------------------------------------------------------------
+template <int G, int B, bool GAPCTX, bool EMLDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 : 1))) void k_backward_fill(FbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_fb[];
+  const uint32_t Kg = a.dp.Kg, Km = a.Km;
+  const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
+  double* s_trans = lds_fb + kLseDoubles;
+  double* s_acc_all = s_trans + ((4 * Kg + 1) & ~1u);             // [4 waves][4][64 lanes] i2m, d2m, i2i, d2d counts of each lane
+  double* s_tr_all = s_acc_all + 4 * 4 * 64;                      // [4 waves][3 Kg] context-dependent transition counts
+  double* s_em = s_tr_all + (GAPCTX ? ((4 * 3 * Kg + 1) & ~1u) : 0u);
+  lseh_load(lds_fb, a.lse_h, threadIdx.x, 256);
+  for (uint32_t k = threadIdx.x; k < 4 * Kg; k += 256) s_trans[k] = a.dp.trans[k];
+  if (GAPCTX) for (uint32_t k = threadIdx.x; k < 4 * 3 * Kg; k += 256) s_tr_all[k] = 0.0;
+  for (uint32_t k = threadIdx.x; k < 4 * 4 * 64; k += 256) s_acc_all[k] = 0.0;
+  if (EMLDS) {
+    for (uint32_t k = threadIdx.x; k < n_em; k += 256) s_em[k] = a.dp.ematch[k];
+    for (uint32_t k = threadIdx.x; k < kInsRows; k += 256) s_em[n_em + k] = a.dp.eins[k];
+  }
   __syncthreads();
-  const double* hs = s_lseh;
+  const double* hs = lds_fb;
   constexpr int UPW = 64 / G;
-  // context-dependent transition counts (m2m / m2i / m2d by indel context): a handful of addresses that every column of
-  // every band would hit with a global atomic; they are summed per wavefront in LDS (registers when there is one context)
-  // and flushed once at the end
-  extern __shared__ double s_tr_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* s_acc = s_acc_all + (size_t)wv * 4 * 64 + lane;   // this lane's four running sums, 64 doubles apart
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int grp = lane / G, l = lane % G, rl = G - 1 - l;
   const uint32_t uidx = wave * UPW + grp;
@@ -351,18 +467,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   if (T == 0) return;
-  double* s_tr = s_tr_all + (size_t)wv * 3 * a.dp.Kg;
-  if (a.dp.Kg > 1) for (uint32_t c = lane; c < 3 * a.dp.Kg; c += 64) s_tr[c] = 0.0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
+  double* s_tr = s_tr_all + (size_t)wv * 3 * Kg;
 
   const int d0 = dlo + l * B;
+  const int bmax = active ? dhi - d0 : -1;
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
-  const double* __restrict__ ematch = a.dp.ematch;
-  const double* __restrict__ eins = a.dp.eins;
-  const double* __restrict__ trans = a.dp.trans;
-  const uint32_t Kg = a.dp.Kg, Km = a.Km;
+  const double* __restrict__ ematch = EMLDS ? s_em : a.dp.ematch;
+  const double* __restrict__ eins = EMLDS ? s_em + n_em : a.dp.eins;
+  const double* __restrict__ trans = s_trans;
   const bool local = a.dp.local != 0;
+  const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg];
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
   const double* __restrict__ fw = a.fw + fw_off;
@@ -373,113 +487,169 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
 #pragma unroll
   for (int b = 0; b < B; ++b) Bm[b] = Bi[b] = Bd[b] = QF_NEG_INF;
   double pubD = QF_NEG_INF;     // slot 0's del after this lane's latest step (for lane l-1)
-  double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
-  double acc_m2m = 0, acc_m2i = 0, acc_m2d = 0;   // Kg == 1 only
-  double colsum[5] = {0, 0, 0, 0, 0};             // running match-by-token[4] / insert sums of the column this lane is on
-  uint32_t wNext = 0;           // context word of column j+1 (this lane's previous step)
+  double acc_m2e = 0, startv = QF_NEG_INF;
+  double acc_m2m = 0, acc_m2i = 0, acc_m2d = 0;   // !GAPCTX only
+  // running match-by-token[4] / insert sums of the column this lane is on: at most G x B terms each, fp32 like the partials
+  float colsum[5] = {0, 0, 0, 0, 0};
   uint32_t gkEnd = 0;
 
   // tokens of rows i+1 of the lane's B slots as a sliding 2-bit window (the rows move up by one per step)
   auto xtok = [&](int idx0) -> uint32_t { return (idx0 >= 0 && idx0 < xLen) ? (uint32_t)xt[idx0] : 0u; };
+  const uint32_t ninf_off = a.dp.ematch_ninf_off;
+  // match emission of the destination (row i + 1, word w of column j + 1): -inf above the band's last diagonal and outside
+  // the reference.  With that, every source cell outside the band / below the last reference row stays at -inf by itself
+  // (see the header comment); no per-cell masks.
+  auto emis = [&](uint32_t w, unsigned long long window, int b, int idest) -> double {
+    uint32_t off = ((w & 0x7FFFu) << 5) | (((uint32_t)(window >> (2 * b)) & 3u) << 3);
+    if (b > bmax || (uint32_t)(idest - 1) >= (uint32_t)xLen) off = ninf_off;
+    return *(const double*)((const char*)ematch + off);
+  };
+  constexpr unsigned long long winMask = (B < 32 ? (1ull << (2 * B)) : 0ull) - 1ull;
   unsigned long long win = 0;
 #pragma unroll
   for (int b = 0; b < B; ++b) win |= (unsigned long long)xtok(d0 + b + (yLen + rl)) << (2 * b);
   uint32_t tokNext = xtok(d0 + (yLen + rl) - 1);   // slot 0's token at the next step
-  for (int t = 0; t < T; ++t) {
+  // context words: the lane's column falls by one per step; the word of column j is ctx[j - 1], loaded a step ahead
+  auto ctxword = [&](int t) -> uint32_t { return ctx[max(yLen - 1 - t + rl, -100)]; };
+  uint32_t wA = ctxword(0);
+  uint32_t wNext = 0;            // context word of column j+1 (this lane's previous step)
+  // F[b], e[b]: this step's operands, fetched during the previous step -- each slot's registers are reloaded for the next
+  // step as soon as the slot has used them (one buffer, a whole step of distance between load and use).  Forward values
+  // of cells that do not exist (not started / finished lanes, slots above the band) read as -inf: their counts are 0.
+  auto fwbase = [&](int j, int b) -> uint64_t { return ((uint64_t)(j - 1 + l) * B + b) * 3 * G + l; };
+  double F[B][3];
+  {
+    const int j = yLen + rl;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const bool ok = active && b <= bmax && j <= yLen;
+      const uint64_t base = ok ? fwbase(j, b) : 0;
+      F[b][0] = ok ? fw[base] - Fres : QF_NEG_INF; F[b][1] = ok ? fw[base + G] - Fres : QF_NEG_INF; F[b][2] = ok ? fw[base + 2 * G] - Fres : QF_NEG_INF;
+    }
+  }
+  double e[B], insE = eins[0];   // emissions of the destination column j+1: none before the first step (the Backward values there are -inf)
+#pragma unroll
+  for (int b = 0; b < B; ++b) e[b] = QF_NEG_INF;
+
+  // lanes are on their last column (end transitions) at steps 0 .. G-1 and on column 1 (start) at steps startLo .. startHi
+  int startLo = active ? yLen + rl - 1 : 0x7FFFFFFF, startHi = active ? yLen + rl - 1 : -1;
+  for (int o = 32; o; o >>= 1) {
+    startLo = min(startLo, __shfl_xor(startLo, o));
+    startHi = max(startHi, __shfl_xor(startHi, o));
+  }
+  startLo = __builtin_amdgcn_readfirstlane(startLo);
+  startHi = __builtin_amdgcn_readfirstlane(startHi);
+
+#pragma unroll 1
+  for (int t = 0; t <= startHi; ++t) {
     const int j = yLen - (t - rl);
-    const bool colvalid = active && j >= 1 && j <= yLen;
-    const uint32_t w = ctx[min(max(j - 1, -kCtxPad + 1), yLen + 4)];
+    const uint32_t w = wA;
+    wA = ctxword(t + 1);
     const uint32_t gk = w >> 24;
-    if (j == yLen) gkEnd = gk;
-    const double m2m = trans[gk], m2i = trans[Kg + gk], m2d = trans[2 * Kg + gk];
-    const uint32_t erowN4 = (wNext & 0x7FFFu) * 4u;
-    const double insEN = eins[(wNext >> 15) & 0x1FFu];
+    double m2m, m2i, m2d;
+    if (GAPCTX) { m2m = trans[gk]; m2i = trans[Kg + gk]; m2d = trans[2 * Kg + gk]; }
+    else { m2m = c_m2m; m2i = c_m2i; m2d = c_m2d; }
+    const unsigned long long winCur = win;
+    // the next step's destination column is this step's column
+    win = ((win << 2) | tokNext) & winMask;
+    tokNext = xtok(d0 + j - 2);
+    const bool more = active && j - 1 >= 1 && j - 1 <= yLen;
+    auto refill = [&](int b) {   // slot b's operands for the next step (source row i - 1 ... destination row i)
+      e[b] = emis(w, win, b, d0 + b + j);
+      const bool ok = more && b <= bmax;
+      const uint64_t base = ok ? fwbase(j - 1, b) : 0;
+      const double f0 = fw[base], f1 = fw[base + G], f2 = fw[base + 2 * G];
+      F[b][0] = ok ? f0 - Fres : QF_NEG_INF; F[b][1] = ok ? f1 - Fres : QF_NEG_INF; F[b][2] = ok ? f2 - Fres : QF_NEG_INF;
+    };
     // (i+1, j) for the top slot: lane l+1's slot 0 at column j, finished in the previous step
-    double hiD = __shfl_down(pubD, 1, G);
-    if (l == G - 1) hiD = QF_NEG_INF;
-    double pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // match-by-token[4], insert, m2m, m2i, m2d partial counts (source column j)
-    double pc0[4] = {0, 0, 0, 0};             // start -> mat(i,1) counts by token (source "column 0")
+    const double hiD = dpp_from_above<G, false>(pubD);
+    const double mi_e = m2i + insE, ii_e = i2i + insE;
+    insE = eins[(w >> 15) & 0x1FFu];
+    float pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // match-by-token[4], insert, m2m, m2i, m2d partial counts (source column j)
+    float pa[4] = {0, 0, 0, 0};               // i2m, d2m, i2i, d2d
+    float pc0[4] = {0, 0, 0, 0};              // start -> mat(i,1) counts by token (source "column 0")
     double loI = QF_NEG_INF;                   // Bi(i, j+1) for slot 0: lane l-1's top slot, exchanged below
     double nextD = hiD;                        // Bd(i+1, j): slot b+1 of this step, or lane l+1's slot 0
+    const bool colvalid = active && j >= 1 && j <= yLen;
+    const bool endStep = t < G, startStep = t >= startLo;   // wave-uniform
+    if (endStep && j == yLen) gkEnd = gk;
 #pragma unroll
     for (int b = B - 1; b >= 0; --b) {
-      const int d = d0 + b, i = d + j;
-      const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
-      const uint32_t tokN = (uint32_t)(win >> (2 * b)) & 3u;   // token of row i+1
-      const double eN = ematch[erowN4 + tokN];
+      const int i = d0 + b + j;
+      const uint32_t tokN = (uint32_t)(winCur >> (2 * b)) & 3u;   // token of row i+1
       const double BmN = Bm[b];                                   // Bm(i+1, j+1), own diagonal, previous step
       const double BiN = b > 0 ? Bi[b - 1] : loI;                 // Bi(i, j+1), diagonal d-1 (not yet overwritten)
-      const double BdN = nextD;                                   // Bd(i+1, j), diagonal d+1
-      const double T_mm = (m2m + eN) + BmN, T_im = (i2m + eN) + BmN, T_dm = (d2m + eN) + BmN;
-      const double T_mi = (m2i + insEN) + BiN, T_ii = (i2i + insEN) + BiN;
-      const double T_md = m2d + BdN, T_dd = d2d + BdN;
-      const bool isEnd = j == yLen && (local || i == xLen);
-      const double T_me = isEnd ? trans[3 * Kg + gk] : QF_NEG_INF;
+      const double T_mm = (m2m + e[b]) + BmN, T_im = (i2m + e[b]) + BmN, T_dm = (d2m + e[b]) + BmN;
+      const double T_mi = mi_e + BiN, T_ii = ii_e + BiN;
+      const double T_md = m2d + nextD, T_dd = d2d + nextD;
       // accumulation order of the reference's push-style sweep (columns descending, rows descending): the
       // contribution from mat(i+1,j+1) arrives first, then ins(i,j+1), then del(i+1,j), then the end transition.
       // The table log-sum-exp is not associative at the 1e-4 level (its x >= 10 cut-off drops up to 4.5e-5 per
       // call), so the order is part of the numerical contract.
       double nbm = lseh(hs, lseh(hs, T_mm, T_mi), T_md);
-      if (isEnd) nbm = lseh(hs, nbm, T_me);
-      double nbi = lseh(hs, T_im, T_ii);
-      double nbd = lseh(hs, T_dm, T_dd);
-      if (!valid) { nbm = QF_NEG_INF; nbi = QF_NEG_INF; nbd = QF_NEG_INF; }
-      if (valid) {
-        const uint64_t base = ((uint64_t)(j - 1 + l) * B + b) * 3 * G + l;
-        const double Fm = fw[base] - Fres, Fi = fw[base + G] - Fres, Fd = fw[base + 2 * G] - Fres;
-        // NB (F - Fres) + T differs from the reference's (F + T) - Fres only in rounding
-        const double c_mm = wgt * count_exp(Fm + T_mm), c_im = wgt * count_exp(Fi + T_im), c_dm = wgt * count_exp(Fd + T_dm);
-        const double c_mi = wgt * count_exp(Fm + T_mi), c_ii = wgt * count_exp(Fi + T_ii);
-        const double c_md = wgt * count_exp(Fm + T_md), c_dd = wgt * count_exp(Fd + T_dd);
-        const double cmat = c_mm + c_im + c_dm;
-        pc[0] += tokN == 0 ? cmat : 0.0; pc[1] += tokN == 1 ? cmat : 0.0;
-        pc[2] += tokN == 2 ? cmat : 0.0; pc[3] += tokN == 3 ? cmat : 0.0;
-        pc[4] += c_mi + c_ii;
-        pc[5] += c_mm; pc[6] += c_mi; pc[7] += c_md;
-        acc_i2m += c_im; acc_d2m += c_dm; acc_i2i += c_ii; acc_d2d += c_dd;
-        if (isEnd) acc_m2e += wgt * count_exp(Fm + T_me);
-        if (j == 1 && (i == 1 || local)) {  // start -> mat(i,1), src/qmodel.cpp:1448-1454
+      const double Fm = F[b][0], Fi = F[b][1], Fd = F[b][2];
+      if (endStep) {
+        if (colvalid && j == yLen && b <= bmax && (uint32_t)(i - 1) < (uint32_t)xLen && (local || i == xLen)) {
+          const double T_me = trans[3 * Kg + gk];
+          nbm = lseh(hs, nbm, T_me);
+          acc_m2e += count_exp(Fm + T_me);
+        }
+      }
+      const double nbi = lseh(hs, T_im, T_ii);
+      const double nbd = lseh(hs, T_dm, T_dd);
+      // NB (F - Fres) + T differs from the reference's (F + T) - Fres only in rounding
+      const float c_mm = count_expf(Fm + T_mm), c_im = count_expf(Fi + T_im), c_dm = count_expf(Fd + T_dm);
+      const float c_mi = count_expf(Fm + T_mi), c_ii = count_expf(Fi + T_ii);
+      const float c_md = count_expf(Fm + T_md), c_dd = count_expf(Fd + T_dd);
+      const float cmat = c_mm + c_im + c_dm;
+      pf[0] += tokN == 0 ? cmat : 0.f; pf[1] += tokN == 1 ? cmat : 0.f;
+      pf[2] += tokN == 2 ? cmat : 0.f; pf[3] += tokN == 3 ? cmat : 0.f;
+      pf[4] += c_mi + c_ii;
+      pf[5] += c_mm; pf[6] += c_mi; pf[7] += c_md;
+      pa[0] += c_im; pa[1] += c_dm; pa[2] += c_ii; pa[3] += c_dd;
+      if (startStep) {
+        if (colvalid && j == 1 && b <= bmax && (uint32_t)(i - 1) < (uint32_t)xLen && (i == 1 || local)) {  // start -> mat(i,1), src/qmodel.cpp:1448-1454
           const uint32_t tok = xt[i - 1];
           const double S = ematch[(w & 0x7FFFu) * 4u + tok] + nbm;
-          const double cs = wgt * count_exp(S - Fres);
-          pc0[0] += tok == 0 ? cs : 0.0; pc0[1] += tok == 1 ? cs : 0.0;
-          pc0[2] += tok == 2 ? cs : 0.0; pc0[3] += tok == 3 ? cs : 0.0;
+          const float cs = count_expf(S - Fres);
+          pc0[0] += tok == 0 ? cs : 0.f; pc0[1] += tok == 1 ? cs : 0.f;
+          pc0[2] += tok == 2 ? cs : 0.f; pc0[3] += tok == 3 ? cs : 0.f;
           startv = lseh(hs, startv, S);
         }
       }
+      refill(b);
       Bm[b] = nbm; Bi[b] = nbi; Bd[b] = nbd;
       nextD = nbd;
-      if (b == B - 1) {  // lane l-1 (one column behind) has just produced Bi of its top slot at column j+1
-        loI = __shfl_up(nbi, 1, G);
-        if (l == 0) loI = QF_NEG_INF;
-      }
+      if (b == B - 1) loI = dpp_from_below<G, false>(nbi);   // lane l-1 (on column j+1) has just produced Bi of its top slot
+#ifdef QF_BWD_SLOT_BARRIER
+      __builtin_amdgcn_sched_barrier(0);   // one slot at a time: interleaving the slots costs more registers than it hides latency
+#endif
     }
     pubD = Bd[0];
+    // the context-free transition counts accumulate in fp64 in the lane's own LDS words (conflict-free; registers are what
+    // limits this kernel's occupancy)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(&s_acc[c * 64], (double)pa[c]);
     // ---- per-column partials travel with the column: lane l+1 was on column j one step ago and hands its running sums
     // to lane l; the unit's lane 0 is the last on every column and flushes the complete sums (no LDS, no barriers)
-    {
-      double in[5];
 #pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        in[c] = __shfl_down(colsum[c], 1, G);
-        if (l == G - 1) in[c] = 0.0;
-      }
-#pragma unroll
-      for (int c = 0; c < 5; ++c) colsum[c] = colvalid ? in[c] + pc[c] : 0.0;
+    for (int c = 0; c < 5; ++c) {
+      const float in = dpp_f32_from_above<G>(colsum[c]);
+      colsum[c] = colvalid ? in + pf[c] : 0.f;
     }
     if (colvalid) {
-      if (Kg == 1) { acc_m2m += pc[5]; acc_m2i += pc[6]; acc_m2d += pc[7]; }
+      if (!GAPCTX) { acc_m2m += (double)pf[5]; acc_m2i += (double)pf[6]; acc_m2d += (double)pf[7]; }
       else {
-        if (pc[5] != 0.0) unsafeAtomicAdd(&s_tr[gk], pc[5]);
-        if (pc[6] != 0.0) unsafeAtomicAdd(&s_tr[Kg + gk], pc[6]);
-        if (pc[7] != 0.0) unsafeAtomicAdd(&s_tr[2 * Kg + gk], pc[7]);
+        if (pf[5] != 0.f) unsafeAtomicAdd(&s_tr[gk], wgt * (double)pf[5]);
+        if (pf[6] != 0.f) unsafeAtomicAdd(&s_tr[Kg + gk], wgt * (double)pf[6]);
+        if (pf[7] != 0.f) unsafeAtomicAdd(&s_tr[2 * Kg + gk], wgt * (double)pf[7]);
       }
-      if (j == 1) {  // start -> mat(i,1): emission counts of column 1, once per lane
+      if (startStep && j == 1) {  // start -> mat(i,1): emission counts of column 1, once per lane
         const uint32_t er = w & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
         if (q < (uint32_t)kNQualDev) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (pc0[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], pc0[c]);
+            if (pc0[c] != 0.f) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], wgt * (double)pc0[c]);
         }
       }
       if (l == 0 && j < yLen) {
@@ -489,16 +659,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
         if (q < (uint32_t)kNQualDev) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (colsum[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], colsum[c]);
-          if (colsum[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], colsum[4]);
+            if (colsum[c] != 0.f) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], wgt * (double)colsum[c]);
+          if (colsum[4] != 0.f) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], wgt * (double)colsum[4]);
         }
       }
     }
     wNext = w;
-    win = ((win << 2) | tokNext) & ((B < 32 ? (1ull << (2 * B)) : 0ull) - 1ull);
-    tokNext = xtok(d0 + j - 2);
   }
   // context-free transitions, m2e and the Backward result (start), reduced over the unit's lanes
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  double acc_i2m = s_acc[0], acc_d2m = s_acc[64], acc_i2i = s_acc[128], acc_d2d = s_acc[192];
   for (int o = 1; o < G; o <<= 1) {
     acc_i2m += __shfl_xor(acc_i2m, o, G); acc_d2m += __shfl_xor(acc_d2m, o, G);
     acc_i2i += __shfl_xor(acc_i2i, o, G); acc_d2d += __shfl_xor(acc_d2d, o, G);
@@ -507,21 +678,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
     startv = lseh(hs, startv, __shfl_xor(startv, o, G));
     gkEnd = max(gkEnd, (uint32_t)__shfl_xor((int)gkEnd, o, G));
   }
-  if (Kg > 1) {
+  if (GAPCTX) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     for (uint32_t c = lane; c < 3 * Kg; c += 64) if (s_tr[c] != 0.0) unsafeAtomicAdd(&cnt[cTr + c], s_tr[c]);
   } else if (active && l == 0) {
-    if (acc_m2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 0], acc_m2m);
-    if (acc_m2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 1], acc_m2i);
-    if (acc_m2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 2], acc_m2d);
+    if (acc_m2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 0], wgt * acc_m2m);
+    if (acc_m2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 1], wgt * acc_m2i);
+    if (acc_m2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 2], wgt * acc_m2d);
   }
   if (active && l == 0) {
-    if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], acc_m2e);
-    if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], acc_d2d);
-    if (acc_d2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 1], acc_d2m);
-    if (acc_i2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 2], acc_i2i);
-    if (acc_i2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 3], acc_i2m);
+    if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], wgt * acc_m2e);
+    if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], wgt * acc_d2d);
+    if (acc_d2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 1], wgt * acc_d2m);
+    if (acc_i2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 2], wgt * acc_i2i);
+    if (acc_i2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 3], wgt * acc_i2m);
     a.units[uid].end_val = startv;  // Backward result of this band (diagnostic: should equal Forward's)
   }
 }
@@ -535,7 +706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
 //   stripe_off[s] + (((j - jlo + l) * 8 + b) * 3 + state) * 64 + l          (l = lane, b = row slot)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_forward_rows(FbArgs a) {
-  __shared__ double s_lseh[2 * kLseNodes];
+  __shared__ __attribute__((aligned(16))) double s_lseh[kLseDoubles];
   lseh_load(s_lseh, a.lse_h, threadIdx.x, 64);
   __syncthreads();
   const double* hs = s_lseh;
@@ -655,7 +826,7 @@ __global__ __launch_bounds__(64) void k_forward_rows(FbArgs a) {
 // Backward over a row-space unit: stripes bottom-up, columns right-to-left, lane l one column behind lane l+1; the
 // arithmetic, association order and count bookkeeping of k_backward_fill.
 __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
-  __shared__ double s_lseh[2 * kLseNodes];
+  __shared__ __attribute__((aligned(16))) double s_lseh[kLseDoubles];
   lseh_load(s_lseh, a.lse_h, threadIdx.x, 64);
   __syncthreads();
   const double* hs = s_lseh;
@@ -842,15 +1013,38 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
 }
 
 
+// dynamic LDS of the diagonal-space kernels: lse pieces | transition scores | (Backward, gap contexts) per-wavefront transition
+// counts | (EMLDS) emission tables.  The emission tables go to LDS when three workgroups still fit a CU (<= 52 KB each).
+static uint32_t fb_lds_bytes(const FbArgs& a, bool backward, bool& emlds) {
+  const uint32_t Kg = a.dp.Kg;
+  uint32_t d = kLseDoubles + ((4 * Kg + 1) & ~1u);
+  if (backward) d += 4 * 4 * 64;
+  if (backward && Kg > 1) d += (4 * 3 * Kg + 1) & ~1u;
+  const uint32_t em = a.dp.ematch_ninf_off / 8 + 4 + kInsRows;
+  emlds = (d + em) * 8 <= 48 * 1024;
+  return (d + (emlds ? em : 0)) * 8;
+}
 template <int G, int B>
 static void launch_fwd_gb(const FbArgs& a, hipStream_t s) {
   const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL((k_forward_fill<G, B>), dim3(blocks), dim3(256), 0, s, a);
+  bool emlds;
+  const uint32_t lds = fb_lds_bytes(a, false, emlds);
+  const bool gap = a.dp.Kg > 1;
+  if (gap && emlds) hipLaunchKernelGGL((k_forward_fill<G, B, true, true>), dim3(blocks), dim3(256), lds, s, a);
+  else if (gap) hipLaunchKernelGGL((k_forward_fill<G, B, true, false>), dim3(blocks), dim3(256), lds, s, a);
+  else if (emlds) hipLaunchKernelGGL((k_forward_fill<G, B, false, true>), dim3(blocks), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((k_forward_fill<G, B, false, false>), dim3(blocks), dim3(256), lds, s, a);
 }
 template <int G, int B>
 static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL((k_backward_fill<G, B>), dim3(blocks), dim3(256), (size_t)4 * 3 * a.dp.Kg * 8, s, a);
+  bool emlds;
+  const uint32_t lds = fb_lds_bytes(a, true, emlds);
+  const bool gap = a.dp.Kg > 1;
+  if (gap && emlds) hipLaunchKernelGGL((k_backward_fill<G, B, true, true>), dim3(blocks), dim3(256), lds, s, a);
+  else if (gap) hipLaunchKernelGGL((k_backward_fill<G, B, true, false>), dim3(blocks), dim3(256), lds, s, a);
+  else if (emlds) hipLaunchKernelGGL((k_backward_fill<G, B, false, true>), dim3(blocks), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((k_backward_fill<G, B, false, false>), dim3(blocks), dim3(256), lds, s, a);
 }
 #define QF_FB_DISPATCH(FN)                         \
   switch (cls) {                                   \

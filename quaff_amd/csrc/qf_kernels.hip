@@ -6,6 +6,7 @@
 
 #include <type_traits>
 
+#include "qf_dpp.hpp"
 #include "qf_kernels.hpp"
 
 namespace qf {
@@ -965,26 +966,6 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
 //    reference's M, I, D order) instead of value/flag select chains.
 //  * Lane exchange by DPP row/wave shifts (a -inf "old" value fills the group's edge lane) instead of ds_bpermute.
 // ------------------------------------------------------------------------------------------------
-// ZERO: the group's edge lane receives 0.0 (both dwords zero-filled by bound_ctrl) instead of -inf
-template <int G, bool ZERO>
-__device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf (or 0) in the group's lane 0
-  constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
-  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
-                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-template <int G, bool ZERO>
-__device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf (or 0) in the group's last lane
-  constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
-  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
-                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // acc = 2 * acc + (x > y): the compare's lane mask goes straight into an add-with-carry (no select / shift / or)
 __device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y) {
   const unsigned long long mask = __builtin_amdgcn_fcmp(x, y, 2 /* ordered > */);

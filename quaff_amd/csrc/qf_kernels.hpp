@@ -94,12 +94,14 @@ struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
   const uint32_t* cls_list;
   Unit* units;
   const uint64_t* ref_off;
+  const uint64_t* ref_woff;
   const uint8_t* ref_tok;
+  const uint32_t* ref_packed;
   const uint64_t* read_off;
   const uint32_t* ctx;
   double* fw;                  // Forward matrix, unit u at fw + units[u].tb_off
   const double* lse;           // 100001-entry log(1+exp(-x)) table
-  const double* lse_h;         // the same function as 641 (value, slope) nodes on a 1/64 grid (qf_fb.hip)
+  const double* lse_h;         // the same function as kLsePieces cubic pieces on a 1/32 grid (qf_fb.hip: lseh)
   DpParams dp;
   const double* pair_fwd;      // [n_pairs] Forward result (Backward only)
   const double* pair_weight;   // [n_pairs] posterior weight, 0 = no Backward

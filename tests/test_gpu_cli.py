@@ -217,9 +217,9 @@ def _overlap_expected(reads, cfg_kw=None):
     rows re-paired by the indel squashing of src/qoverlap.cpp:231-267 (oracle: overlap_rows / overlap_stockholm)."""
     params = O.Params.from_json(open(os.path.join(GOLDEN, "defaultparams.json")).read())
     sc = O.Scores(params)
-    null = O.NullParams.fit(reads)                                   # `quaff overlap` without -null fits it to the reads
-    osc = [O.OverlapScores(params, sc, False), O.OverlapScores(params, sc, True)]
     seqs = list(reads) + [r.revcomp() for r in reads]
+    null = O.NullParams.fit(seqs)      # without -null it is fitted to the loaded sequences, complements included (t/quaff.cpp:230-232)
+    osc = [O.OverlapScores(params, sc, False), O.OverlapScores(params, sc, True)]
     cfg = O.DPConfig(kmer_threshold=14, **(cfg_kw or {}))
     out, pairs = "", []
     for nx, ny, comp in O.overlap_task_pairs(len(reads), len(seqs)):
