@@ -134,12 +134,25 @@ __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   return (uint64_t)((yLen + fc.G - 1 + 7) & ~7u) * fc.G;
 }
 
-// Forward-matrix doubles a unit occupies (3 states x B slots x G lanes per step); single-diagonal bands run on
-// the (16,2) kernel in Forward/Backward mode.
+// Forward storage of a diagonal-space unit (single-diagonal bands use the (16,2) geometry).  Per step and lane one row of
+// fw_row_floats(B) fp32 values: [0] an anchor (the largest of the row's values, rounded to fp32), then for slot B-1 down
+// to 0 the offsets (mat, ins, del) - anchor.  A row is written / read as 16-byte chunks, chunk c of step t and lane l at
+// float index ((t * chunks + c) * G + l) * 4 (a wavefront's store covers 256 contiguous bytes per band), which is what the
+// store path of the device wants: 4 wide stores per step instead of 15 narrow ones, and half the bytes.  The offsets'
+// rounding (2^-24 relative to their distance from the row's best value) is 6e-8 x that distance in the exponent of a count:
+// < 1e-5 for anything within e^-150 of the row's best state, against the 1e-4 tolerance of the counts.  After the steps
+// come G x B fp64 values: mat(i, yLen) of every diagonal of the band, exactly, for the pair's Forward result
+// (k_pair_forward).
 __host__ __device__ inline int fb_class(int cls) { return cls == 0 ? 1 : cls; }
+__host__ __device__ constexpr int fw_row_floats(int B) { return (3 * B + 1 + 3) / 4 * 4; }
+__host__ __device__ constexpr int fw_float_index(int B, int b, int state) { return 1 + 3 * (B - 1 - b) + state; }
+__host__ __device__ inline uint64_t unit_fw_steps_doubles(int cls, uint32_t yLen) {   // the per-step rows, in doubles
+  const FillClass fc = fill_class(fb_class(cls));
+  return (uint64_t)(yLen + fc.G - 1) * fc.G * fw_row_floats(fc.B) / 2;
+}
 __host__ __device__ inline uint64_t unit_fw_doubles(int cls, uint32_t yLen) {
   const FillClass fc = fill_class(fb_class(cls));
-  return (uint64_t)(yLen + fc.G - 1) * fc.G * fc.B * 3;
+  return unit_fw_steps_doubles(cls, yLen) + (uint64_t)fc.G * fc.B;
 }
 
 struct BatchCounters {

@@ -8,6 +8,8 @@
 // be re-associated: per-column count partials are combined in an LDS ring and flushed with fp64 atomics.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "qf_dpp.hpp"
 #include "qf_kernels.hpp"
 
@@ -17,7 +19,7 @@ struct __attribute__((packed, aligned(4))) U32x4f { uint32_t v[4]; };   // 16-by
 
 #define QF_NEG_INF (-__builtin_huge_val())
 #ifndef QF_BWD_WAVES
-#define QF_BWD_WAVES 1
+#define QF_BWD_WAVES 2
 #endif
 
 // log_sum_exp, src/logsumexp.cpp:34-50 + log_sum_exp_unary :84-103 (x >= 10, NaN, inf -> 0).
@@ -81,8 +83,8 @@ __device__ __forceinline__ double lseh(const double* hs, double a, double b) {
 //    which keeps them at -inf (see emis below); the start term and the end terms sit in wave-uniform branches that are
 //    taken only while some lane is on its first / last column;
 //  * neighbour lanes exchange by DPP shifts.
-// Storage: fw[((t * B + b) * 3 + state) * G + lane] (step-major: every store instruction of a wavefront covers four
-// contiguous 128-byte segments).
+// Storage: packed fp32 rows (qf_device.hpp: fw_row_floats) -- the store path, not arithmetic, bounds this kernel
+// (measured: 15 eight-byte stores per step cost 11 of its 19 ms), so a step writes 4 sixteen-byte stores per lane.
 // ------------------------------------------------------------------------------------------------
 #ifndef QF_FWD_WAVES
 #define QF_FWD_WAVES 3
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   const double* __restrict__ trans = s_trans;
   const bool local = a.dp.local != 0;
   const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg];
-  double* __restrict__ fw = a.fw + fw_off;
+  constexpr int NF = fw_row_floats(B);
+  float4* __restrict__ fwrow = (float4*)(a.fw + fw_off);
+  double* __restrict__ fwend = a.fw + fw_off + (uint64_t)(yLen + G - 1) * G * NF / 2;
 
   double M[B], I[B], D[B];
 #pragma unroll
@@ -221,30 +225,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
       double upM = 0, upI = 0;
       const bool colvalid = active && j >= 1 && j <= yLen;
       const bool startStep = t < G, endStep = t >= endLo;   // wave-uniform
+      if (!startStep && !endStep) {
+        // the common step: straight-line code over the B slots (no branches: the compiler overlaps the slots' table lookups)
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        // mat(i,j) = lse(lse(mat' + m2m, del' + d2m), ins' + i2m) [lse with start on column 1] + emit  (src/qmodel.cpp:1363-1372)
-        double nm = lseh(hs, lseh(hs, M[b] + m2m, D[b] + d2m), I[b] + i2m);
-        if (startStep) {
+        for (int b = 0; b < B; ++b) {
+          // mat(i,j) = lse(lse(mat' + m2m, del' + d2m), ins' + i2m) + emit  (src/qmodel.cpp:1363-1372)
+          const double nm = lseh(hs, lseh(hs, M[b] + m2m, D[b] + d2m), I[b] + i2m) + e[b];
+          double srcM, srcI;
+          if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
+          const double ni = insE + lseh(hs, srcI + i2i, srcM + m2i);
+          const double ndl = lseh(hs, prevD + d2d, prevM + m2d);
+          M[b] = nm; I[b] = ni; D[b] = ndl;
+          prevM = nm; prevD = ndl;
+          if (b == 0) { upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); }
+        }
+      } else {
+        // some lane is on its first column (start term) or its last (end terms, the exact last-column values)
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          double nm = lseh(hs, lseh(hs, M[b] + m2m, D[b] + d2m), I[b] + i2m);
           if (j == 1 && (d0 + b == 0 || local)) nm = lseh(hs, nm, 0.0);
+          nm += e[b];
+          double srcM, srcI;
+          if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
+          const double ni = insE + lseh(hs, srcI + i2i, srcM + m2i);
+          const double ndl = lseh(hs, prevD + d2d, prevM + m2d);
+          M[b] = nm; I[b] = ni; D[b] = ndl;
+          prevM = nm; prevD = ndl;
+          if (colvalid && j == yLen) {
+            if (b <= bmax) fwend[l * B + b] = nm;   // mat(i, yLen), exactly, for k_pair_forward
+            if (local || d0 + b + j == xLen) endTerm[b] = nm + trans[3 * Kg + gk];   // (-inf outside band / matrix)
+          }
+          if (b == 0) { upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); }
         }
-        nm += e[b];
-        double srcM, srcI;
-        if (b + 1 < B) { srcM = M[b + 1]; srcI = I[b + 1]; } else { srcM = upM; srcI = upI; }
-        const double ni = insE + lseh(hs, srcI + i2i, srcM + m2i);
-        const double ndl = lseh(hs, prevD + d2d, prevM + m2d);
-        M[b] = nm; I[b] = ni; D[b] = ndl;
-        prevM = nm; prevD = ndl;
-        if (colvalid && b <= bmax) {
-          const uint64_t base = ((uint64_t)t * B + b) * 3 * G + l;
-          fw[base] = nm; fw[base + G] = ni; fw[base + 2 * G] = ndl;
-        }
-        if (endStep) {
-          if (colvalid && j == yLen && (local || d0 + b + j == xLen)) endTerm[b] = nm + trans[3 * Kg + gk];   // (-inf outside band / matrix)
-        }
-        if (b == 0) { upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); }
       }
       pubM = prevM; pubD = prevD;
+      if (colvalid && bmax >= 0) {
+        // the step's row: anchor = the largest value (fp32), then the offsets of slot B-1 .. 0
+        double anchor = M[0];
+#pragma unroll
+        for (int b = 0; b < B; ++b) anchor = vmax_f64(vmax_f64(anchor, M[b]), vmax_f64(I[b], D[b]));
+        const float af = anchor > QF_NEG_INF ? (float)anchor : 0.f;
+        const double ad = (double)af;
+        float row[NF];
+        row[0] = af;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          row[fw_float_index(B, b, 0)] = (float)(M[b] - ad);
+          row[fw_float_index(B, b, 1)] = (float)(I[b] - ad);
+          row[fw_float_index(B, b, 2)] = (float)(D[b] - ad);
+        }
+#pragma unroll
+        for (int k = 3 * B + 1; k < NF; ++k) row[k] = 0.f;
+        float4* dst = fwrow + ((uint64_t)t * (NF / 4)) * G + l;
+#pragma unroll
+        for (int c = 0; c < NF / 4; ++c) dst[(uint64_t)c * G] = make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]);
+      }
     }
   }
   // end = lse(end, mat(i,yLen) + m2e) accumulated over rows in ascending order (src/qmodel.cpp:1379-1381): chain the
@@ -290,7 +326,9 @@ __global__ __launch_bounds__(256) void k_forward_single(FbArgs a) {
   const bool local = a.dp.local != 0;
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
-  double* __restrict__ fw = a.fw + fw_off;
+  constexpr int NF = fw_row_floats(B);
+  float4* __restrict__ fwrow = (float4*)(a.fw + fw_off);
+  double* __restrict__ fwend = a.fw + fw_off + (uint64_t)(yLen + G - 1) * G * NF / 2;
   double M = QF_NEG_INF, endTerm = QF_NEG_INF;
   uint32_t gkPrev = 0;
   for (int j = 1; j <= T; ++j) {
@@ -306,9 +344,13 @@ __global__ __launch_bounds__(256) void k_forward_single(FbArgs a) {
     nm += ematch[erow4 + tok];
     if (!valid) nm = QF_NEG_INF;
     M = nm;
-    if (colvalid) {
-      const uint64_t base = (uint64_t)(j - 1) * B * 3 * G;   // step t = j - 1 of lane 0, slot 0
-      fw[base] = nm; fw[base + G] = QF_NEG_INF; fw[base + 2 * G] = QF_NEG_INF;
+    if (colvalid) {   // the (16,2) row of step t = j - 1, lane 0: slot 0 holds the diagonal, everything else is -inf
+      const float af = nm > QF_NEG_INF ? (float)nm : 0.f;
+      float4* dst = fwrow + ((uint64_t)(j - 1) * (NF / 4)) * G;
+      const float ninf = -__builtin_huge_valf();
+      dst[0] = make_float4(af, ninf, ninf, ninf);                                  // anchor | slot 1: mat, ins, del
+      dst[G] = make_float4((float)(nm - (double)af), ninf, ninf, 0.f);            // slot 0: mat, ins, del | pad
+      if (j == yLen) fwend[0] = nm;
     }
     if (j == yLen && valid && (local || i == xLen)) endTerm = nm + trans[3 * Kg + gk];
   }
@@ -343,13 +385,11 @@ __global__ void k_pair_forward(FinalArgs a, const double* __restrict__ tab) {
       if (u.end_val > QF_NEG_INF) v = lse2(tab, v, u.end_val);
       continue;
     }
-    const FillClass fc = fill_class(fb_class((int)u.cls));
-    const double* __restrict__ fw = a.fw + u.tb_off;
+    const double* __restrict__ fwend = a.fw + u.tb_off + unit_fw_steps_doubles((int)u.cls, (uint32_t)yLen);
     for (int d = u.dlo; d <= u.dhi; ++d) {
       const int i = d + yLen;
       if (i < 1 || i > xLen || !(a.local || i == xLen)) continue;
-      const int l = (d - u.dlo) / fc.B, b = (d - u.dlo) % fc.B;
-      const double m = fw[((uint64_t)(yLen - 1 + l) * fc.B + b) * 3 * fc.G + l];   // mat(i, yLen): step yLen-1+l of lane l, slot b
+      const double m = fwend[d - u.dlo];   // mat(i, yLen), as the Forward kernel left it (fp64)
       const double term = m + m2e;
       if (term > QF_NEG_INF) v = lse2(tab, v, term);
     }
@@ -420,7 +460,7 @@ __global__ void k_count_plan(CountPlanArgs a) {
 //    step and accumulated in fp64; the pair's posterior weight multiplies at the flush, not per term.
 // ------------------------------------------------------------------------------------------------
 template <int G, int B, bool GAPCTX, bool EMLDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 : 1))) void k_backward_fill(FbArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 3 ? 2 : B <= 5 ? QF_BWD_WAVES : 1))) void k_backward_fill(FbArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_fb[];
   const uint32_t Kg = a.dp.Kg, Km = a.Km;
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
@@ -479,7 +519,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
   const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg];
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
-  const double* __restrict__ fw = a.fw + fw_off;
   double* __restrict__ cnt = a.counts + (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // contention: see kCountReplicas
   const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
 
@@ -513,19 +552,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
   auto ctxword = [&](int t) -> uint32_t { return ctx[max(yLen - 1 - t + rl, -100)]; };
   uint32_t wA = ctxword(0);
   uint32_t wNext = 0;            // context word of column j+1 (this lane's previous step)
-  // F[b], e[b]: this step's operands, fetched during the previous step -- each slot's registers are reloaded for the next
-  // step as soon as the slot has used them (one buffer, a whole step of distance between load and use).  Forward values
-  // of cells that do not exist (not started / finished lanes, slots above the band) read as -inf: their counts are 0.
-  auto fwbase = [&](int j, int b) -> uint64_t { return ((uint64_t)(j - 1 + l) * B + b) * 3 * G + l; };
-  double F[B][3];
+  // Fq[c], e[b]: this step's operands, fetched during the previous step.  Fq = the cell row of the Forward storage (packed
+  // fp32: anchor, then (mat, ins, del) offsets of slot B-1 .. 0, NF / 4 sixteen-byte chunks); a chunk is reloaded for the
+  // next step as soon as the slot loop (which runs from slot B-1 down) has used its last value: one buffer, a whole step of
+  // distance between load and use.  Forward values of cells that do not exist (not started / finished lanes, slots above
+  // the band) read as -inf: their counts are 0.
+  constexpr int NF = fw_row_floats(B);
+  const float4* __restrict__ fwrow = (const float4*)(a.fw + fw_off);
+  auto rowptr = [&](int j) -> const float4* { return fwrow + ((uint64_t)(j - 1 + l) * (NF / 4)) * G + l; };
+  const float4 ninf4 = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+  float4 Fq[NF / 4];
   {
     const int j = yLen + rl;
+    const bool ok = active && bmax >= 0 && j <= yLen;
+    const float4* src = ok ? rowptr(j) : fwrow;
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const bool ok = active && b <= bmax && j <= yLen;
-      const uint64_t base = ok ? fwbase(j, b) : 0;
-      F[b][0] = ok ? fw[base] - Fres : QF_NEG_INF; F[b][1] = ok ? fw[base + G] - Fres : QF_NEG_INF; F[b][2] = ok ? fw[base + 2 * G] - Fres : QF_NEG_INF;
-    }
+    for (int c = 0; c < NF / 4; ++c) { const float4 v = src[(uint64_t)c * G]; Fq[c] = ok ? v : ninf4; }
   }
   double e[B], insE = eins[0];   // emissions of the destination column j+1: none before the first step (the Backward values there are -inf)
 #pragma unroll
@@ -554,12 +596,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
     win = ((win << 2) | tokNext) & winMask;
     tokNext = xtok(d0 + j - 2);
     const bool more = active && j - 1 >= 1 && j - 1 <= yLen;
-    auto refill = [&](int b) {   // slot b's operands for the next step (source row i - 1 ... destination row i)
+    const bool moreF = more && bmax >= 0;
+    const float4* nsrc = moreF ? rowptr(j - 1) : fwrow;
+    // anchor - Fres: a cell's F - Fres is this plus its fp32 offset
+    const double adF = (double)Fq[0].x - Fres;
+    auto Fval = [&](int b, int st) -> double {
+      const int k = fw_float_index(B, b, st);
+      const float4 q = Fq[k >> 2];
+      const float o = (k & 3) == 0 ? q.x : (k & 3) == 1 ? q.y : (k & 3) == 2 ? q.z : q.w;
+      return b <= bmax ? adF + (double)o : QF_NEG_INF;
+    };
+    auto refill = [&](int b) {   // slot b's operands for the next step, and the row chunks slot b was the last to use
       e[b] = emis(w, win, b, d0 + b + j);
-      const bool ok = more && b <= bmax;
-      const uint64_t base = ok ? fwbase(j - 1, b) : 0;
-      const double f0 = fw[base], f1 = fw[base + G], f2 = fw[base + 2 * G];
-      F[b][0] = ok ? f0 - Fres : QF_NEG_INF; F[b][1] = ok ? f1 - Fres : QF_NEG_INF; F[b][2] = ok ? f2 - Fres : QF_NEG_INF;
+#pragma unroll
+      for (int c = 0; c < NF / 4; ++c) {
+        // chunk c holds float indices 4c .. 4c+3; slot b's last index is fw_float_index(B, b, 2).  The chunk is free once
+        // that index has passed its end; chunks that reach beyond slot 0's values are free after slot 0.
+        const int hiK = fw_float_index(B, b, 2), prevHiK = b == B - 1 ? 0 : fw_float_index(B, b + 1, 2);
+        const bool freed = 4 * c + 3 <= hiK && 4 * c + 3 > prevHiK;
+        const bool tail = b == 0 && 4 * c + 3 > hiK;
+        if (freed || tail) { const float4 v = nsrc[(uint64_t)c * G]; Fq[c] = moreF ? v : ninf4; }
+      }
     };
     // (i+1, j) for the top slot: lane l+1's slot 0 at column j, finished in the previous step
     const double hiD = dpp_from_above<G, false>(pubD);
@@ -573,8 +630,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
     const bool colvalid = active && j >= 1 && j <= yLen;
     const bool endStep = t < G, startStep = t >= startLo;   // wave-uniform
     if (endStep && j == yLen) gkEnd = gk;
-#pragma unroll
-    for (int b = B - 1; b >= 0; --b) {
+    // One cell as a source.  EDGE: some lane of the wavefront is on its last column (end transition) or on column 1 (start
+    // term); the common step is straight-line code over the B slots, so the compiler overlaps their table lookups.
+    auto cell = [&](int b, auto edge) {
+      constexpr bool EDGE = decltype(edge)::value;
       const int i = d0 + b + j;
       const uint32_t tokN = (uint32_t)(winCur >> (2 * b)) & 3u;   // token of row i+1
       const double BmN = Bm[b];                                   // Bm(i+1, j+1), own diagonal, previous step
@@ -587,8 +646,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
       // The table log-sum-exp is not associative at the 1e-4 level (its x >= 10 cut-off drops up to 4.5e-5 per
       // call), so the order is part of the numerical contract.
       double nbm = lseh(hs, lseh(hs, T_mm, T_mi), T_md);
-      const double Fm = F[b][0], Fi = F[b][1], Fd = F[b][2];
-      if (endStep) {
+      const double Fm = Fval(b, 0), Fi = Fval(b, 1), Fd = Fval(b, 2);
+      if (EDGE) {
         if (colvalid && j == yLen && b <= bmax && (uint32_t)(i - 1) < (uint32_t)xLen && (local || i == xLen)) {
           const double T_me = trans[3 * Kg + gk];
           nbm = lseh(hs, nbm, T_me);
@@ -607,7 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
       pf[4] += c_mi + c_ii;
       pf[5] += c_mm; pf[6] += c_mi; pf[7] += c_md;
       pa[0] += c_im; pa[1] += c_dm; pa[2] += c_ii; pa[3] += c_dd;
-      if (startStep) {
+      if (EDGE) {
         if (colvalid && j == 1 && b <= bmax && (uint32_t)(i - 1) < (uint32_t)xLen && (i == 1 || local)) {  // start -> mat(i,1), src/qmodel.cpp:1448-1454
           const uint32_t tok = xt[i - 1];
           const double S = ematch[(w & 0x7FFFu) * 4u + tok] + nbm;
@@ -621,9 +680,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 2 
       Bm[b] = nbm; Bi[b] = nbi; Bd[b] = nbd;
       nextD = nbd;
       if (b == B - 1) loI = dpp_from_below<G, false>(nbi);   // lane l-1 (on column j+1) has just produced Bi of its top slot
-#ifdef QF_BWD_SLOT_BARRIER
-      __builtin_amdgcn_sched_barrier(0);   // one slot at a time: interleaving the slots costs more registers than it hides latency
-#endif
+    };
+    // (Two copies of the slot loop -- a straight-line one for the common step -- let the compiler overlap the slots'
+    // lookups but cost ~50 more registers: measured 17.3 ms at one wavefront per SIMD against 13.9 ms for this single loop
+    // with its wave-uniform EDGE branches at two.)
+#pragma unroll
+    for (int b = B - 1; b >= 0; --b) {
+      if (endStep || startStep) cell(b, std::true_type());
+      else cell(b, std::false_type());
     }
     pubD = Bd[0];
     // the context-free transition counts accumulate in fp64 in the lane's own LDS words (conflict-free; registers are what
