@@ -358,6 +358,7 @@ class TrainJob(Job):
         self.seq, self.qual, self.off = seq[b0:b1], qual[b0:b1], (off[lo:hi + 1] - off[lo]).astype(np.uint64)
         self.n, self.total_reads = hi - lo, total
         ctx.upload_reads_packed(self.seq, self.qual, self.off)
+        ctx.set_pipeline_chunks(a.chunks)
         ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
         self.cfg = Q.DPConfig(band_size=a.band)
         self.dist = dist

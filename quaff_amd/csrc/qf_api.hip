@@ -102,7 +102,8 @@ struct Slot {
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   hipStream_t hi[3] = {};                                          // high priority: classes too small to fill the chip (latency-bound chains)
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
-      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws, d_align_out, d_cls_key, d_sort_k, d_sort_v;
+      d_pair_end_unit, d_bc, d_tb, d_recs, d_runs_tmp, d_runs_out, d_seed_ws, d_align_out, d_cls_key, d_sort_k, d_sort_v,
+      d_fw, d_weight, d_fwd_out, d_order_out, d_order_n_out, d_rll;   // E-step: Forward storage and per-pair / per-read results of the chunk
   void* sort_tmp = nullptr;
   size_t sort_tmp_cap = 0;
   HostBuf<AlignRec> h_recs;
@@ -126,7 +127,8 @@ struct Slot {
   }
   void destroy() {
     for (DevBuf* b : {&d_units, &d_cls_list, &d_pair_head, &d_pair_bands, &d_pair_nbands, &d_ovf, &d_pair_ndiag, &d_pair_cells,
-                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws, &d_align_out, &d_cls_key, &d_sort_k, &d_sort_v})
+                      &d_pair_score, &d_pair_end_unit, &d_bc, &d_tb, &d_recs, &d_runs_tmp, &d_runs_out, &d_seed_ws, &d_align_out, &d_cls_key, &d_sort_k, &d_sort_v,
+                      &d_fw, &d_weight, &d_fwd_out, &d_order_out, &d_order_n_out, &d_rll})
       b->release();
     if (sort_tmp) (void)hipFree(sort_tmp);
     sort_tmp = nullptr;
@@ -171,8 +173,8 @@ struct qf_ctx : Slot {
   bool reads_have_qual = false;
   DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll;
   // batch state
-  DevBuf d_cover, d_lse, d_fw, d_weight, d_fwd_out, d_counts, d_order_in, d_order_n_in,
-      d_order_out, d_order_n_out, d_rll, d_skip, d_ctxc, d_ins_sum, d_ins_sum_c, d_nll_c, d_rbucket, d_rcursor, d_rpos,
+  DevBuf d_cover, d_lse, d_counts, d_order_in, d_order_n_in,
+      d_skip, d_ctxc, d_ins_sum, d_ins_sum_c, d_nll_c, d_rbucket, d_rcursor, d_rpos,
       d_px, d_py, d_pc, d_mmi0, d_mmi1, d_gap0, d_gap1, d_pair_result, d_pair_ij, d_skmer64, d_skeys, d_keys_tmp, d_vals_tmp,
       d_off32, d_rskeys, d_roff32;
   void* sort_temp = nullptr;
@@ -237,6 +239,8 @@ static uint64_t chunk_budget(const qf_ctx* c, const DevBuf& own, int slots_in_fl
 static hipError_t reserve_big(DevBuf& buf, size_t bytes, std::initializer_list<DevBuf*> idle) {
   hipError_t e = buf.reserve(bytes);
   if (e == hipSuccess) return e;
+  static std::mutex mu;   // two slots can run out of memory at the same moment
+  std::lock_guard<std::mutex> lk(mu);
   (void)hipGetLastError();
   for (DevBuf* other : idle)
     if (other != &buf) other->release();
@@ -291,9 +295,9 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_fw,
-                    &c->d_weight, &c->d_fwd_out, &c->d_counts, &c->d_order_in, &c->d_order_n_in, &c->d_order_out,
-                    &c->d_order_n_out, &c->d_rll, &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse,
+                    &c->d_counts, &c->d_order_in, &c->d_order_n_in,
+                    &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
                     &c->d_gap0, &c->d_gap1, &c->d_pair_result, &c->d_pair_ij, &c->d_skmer64, &c->d_skeys, &c->d_keys_tmp,
                     &c->d_vals_tmp, &c->d_off32, &c->d_rskeys, &c->d_roff32})
@@ -787,7 +791,7 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     *too_big = true;
     return QF_OK;
   }
-  if (reserve_big(S->d_tb, tb_bytes + 64, {&c->d_fw}) != hipSuccess) {   // less memory than the budget assumed: halve the chunk
+  if (reserve_big(S->d_tb, tb_bytes + 64, {&c->d_fw, &c->second.d_fw}) != hipSuccess) {   // less memory than the budget assumed: halve the chunk
     if (n_reads == 1) return fail(S, QF_ERR_MEMORY, "cannot allocate " + std::to_string(tb_bytes >> 20) + " MiB of traceback for one read");
     *too_big = true;
     return QF_OK;
@@ -1186,7 +1190,7 @@ uint32_t qf_counts_size(const qf_ctx* c) {
 
 // Classes of one phase on concurrent streams (the class with the most cells on the main stream, the others on the low-
 // priority side streams), joined back into the main stream: small classes fill the tail of the big one.
-static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool serial,
+static int launch_classes_concurrently(Slot* c, const BatchCounters& bc, bool serial,
                                        const std::function<void(int, hipStream_t)>& launch, int first_cls = 1,
                                        bool small_first = false, hipEvent_t* ev_begin = nullptr, hipEvent_t* ev_end = nullptr) {
   if (!ev_begin) { ev_begin = c->cls_ev; ev_end = c->cls_end; }
@@ -1236,8 +1240,8 @@ static int launch_classes_concurrently(qf_ctx* c, const BatchCounters& bc, bool 
 
 // Forward-Backward over reads [lo, hi) of the resident set; counts accumulate in d_counts, per-read / per-pair results go to
 // the host arrays at the chunk's offsets.  Sets *too_big (and does nothing) when the Forward matrices exceed the budget.
-static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
-                       qf_count_result* out, bool* too_big) {
+static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
+                       int slots_in_flight, qf_count_result* out, std::mutex& out_mu, bool* too_big) {
   *too_big = false;
   const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
   const uint32_t n_pairs = n_reads * n_refs;
@@ -1248,53 +1252,53 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   const uint32_t csize = qf_counts_size(c);
   const uint64_t* d_roff = c->d_roff.as<uint64_t>() + lo;
   const uint8_t* d_skip = have_sort ? c->d_skip.as<uint8_t>() + p0 : nullptr;
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(S, hipEventRecord(S->ev[1], S->stream));
 
   // ---- seeding (cellSize = 2 * 24 for counting, qmodel.cpp:2249; only matters in memory mode)
   const int max_nd = (int)(c->ref_maxlen + c->read_maxlen - 1);
   SeedArgs sa;
   BatchCounters bc;
-  if (int rc = seed_pairs(c, c, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
+  if (int rc = seed_pairs(c, S, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
         s.read_off = d_roff;
         s.cell_size = 48;
         s.storage_mode = 1;
         s.pair_skip = d_skip;
       }, max_units, sa, bc))
     return rc;
-  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  HIPCHK(S, hipEventRecord(S->ev[2], S->stream));
+  if (bc.error & 4u) return fail(S, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u)
-    return fail(c, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels");
+    return fail(S, QF_ERR_UNSUPPORTED, "envelope band of " + std::to_string(bc.error_detail) + " diagonals exceeds the diagonal-space kernels");
 
   // ---- Forward
   const uint64_t fw_bytes = (uint64_t)bc.tb_words * 8;
-  if (fw_bytes > chunk_budget(c, c->d_fw, 1)) {
-    if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "one read needs " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices, over the memory budget");
+  if (fw_bytes > chunk_budget(c, S->d_fw, slots_in_flight)) {
+    if (n_reads == 1) return fail(S, QF_ERR_MEMORY, "one read needs " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices, over the memory budget");
     *too_big = true;
     return QF_OK;
   }
-  if (reserve_big(c->d_fw, fw_bytes + 64, {&c->d_tb, &c->second.d_tb}) != hipSuccess) {
-    if (n_reads == 1) return fail(c, QF_ERR_MEMORY, "cannot allocate " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices for one read");
+  if (reserve_big(S->d_fw, fw_bytes + 64, {&c->d_tb, &c->second.d_tb}) != hipSuccess) {
+    if (n_reads == 1) return fail(S, QF_ERR_MEMORY, "cannot allocate " + std::to_string(fw_bytes >> 20) + " MiB of Forward matrices for one read");
     *too_big = true;
     return QF_OK;
   }
-  if (int rc = sort_class_lists(c, c, bc, max_units)) return rc;
-  HIPCHK(c, c->d_weight.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_fwd_out.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_order_out.reserve((size_t)n_pairs * 4));
-  HIPCHK(c, c->d_order_n_out.reserve((size_t)n_reads * 4));
-  HIPCHK(c, c->d_rll.reserve((size_t)n_reads * 8));
+  if (int rc = sort_class_lists(c, S, bc, max_units)) return rc;
+  HIPCHK(S, S->d_weight.reserve((size_t)n_pairs * 8));
+  HIPCHK(S, S->d_fwd_out.reserve((size_t)n_pairs * 8));
+  HIPCHK(S, S->d_order_out.reserve((size_t)n_pairs * 4));
+  HIPCHK(S, S->d_order_n_out.reserve((size_t)n_reads * 4));
+  HIPCHK(S, S->d_rll.reserve((size_t)n_reads * 8));
   const Scores& sc = c->scores;
   FbArgs fa{};
   fa.n_refs = n_refs;
-  fa.units = c->d_units.as<Unit>();
+  fa.units = S->d_units.as<Unit>();
   fa.ref_off = c->d_ref_off.as<uint64_t>();
   fa.ref_woff = c->d_ref_woff.as<uint64_t>();
   fa.ref_tok = c->d_ref_tok.as<uint8_t>();
   fa.ref_packed = c->d_ref_packed.as<uint32_t>();
   fa.read_off = d_roff;
   fa.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
-  fa.fw = c->d_fw.as<double>();
+  fa.fw = S->d_fw.as<double>();
   fa.lse = c->d_lse.as<double>();
   fa.lse_h = c->d_lse.as<double>() + kLseHermiteOffset;
   fa.dp.ematch = c->d_ematch.as<double>();
@@ -1307,37 +1311,37 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   fa.dp.i2m = sc.trans[4 * sc.Kg + 3];
   fa.dp.Kg = sc.Kg;
   fa.dp.local = cfg->local;
-  fa.pair_fwd = c->d_pair_score.as<double>();
-  fa.pair_weight = c->d_weight.as<double>();
+  fa.pair_fwd = S->d_pair_score.as<double>();
+  fa.pair_weight = S->d_weight.as<double>();
   fa.counts = c->d_counts.as<double>();
   fa.counts_stride = (csize + 31) & ~31ull;
   fa.Km = sc.Km;
   fa.no_band_shortcuts = (c->debug & QF_DEBUG_NO_BAND_SHORTCUTS) != 0;
   const bool serial_classes = (c->debug & QF_DEBUG_SERIAL_CLASSES) != 0;
-  if (int rc = launch_classes_concurrently(c, bc, serial_classes, [&](int cls, hipStream_t s) {
+  if (int rc = launch_classes_concurrently(S, bc, serial_classes, [&](int cls, hipStream_t s) {
         FbArgs f2 = fa;
         f2.n_cls_units = bc.cls_count[cls];
-        f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+        f2.cls_list = S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
         launch_forward_fill(cls, f2, s);
-      }, 0))
+      }, 0, true))   // classes with few wavefronts first, on the high-priority streams: each of their wavefronts still runs its ~1 000 dependent steps
     return rc;
   FinalArgs fin{};
   fin.n_pairs = n_pairs;
   fin.n_reads = n_reads;
   fin.n_refs = n_refs;
-  fin.units = c->d_units.as<Unit>();
-  fin.pair_head = c->d_pair_head.as<uint32_t>();
-  fin.pair_score = c->d_pair_score.as<double>();
+  fin.units = S->d_units.as<Unit>();
+  fin.pair_head = S->d_pair_head.as<uint32_t>();
+  fin.pair_score = S->d_pair_score.as<double>();
   fin.read_off = d_roff;
   fin.ref_off = c->d_ref_off.as<uint64_t>();
-  fin.fw = c->d_fw.as<double>();
+  fin.fw = S->d_fw.as<double>();
   fin.ctx = c->d_ctx.as<uint32_t>() + kCtxPad;
   fin.trans = fa.dp.trans;
   fin.Kg = fa.dp.Kg;
   fin.local = fa.dp.local;
-  launch_pair_forward(fin, c->d_lse.as<double>(), c->stream);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  launch_pair_forward(fin, c->d_lse.as<double>(), S->stream);
+  HIPCHK(S, hipGetLastError());
+  HIPCHK(S, hipEventRecord(S->ev[3], S->stream));
 
   // ---- per-read plan: running log-likelihood, Backward flags, weights, next order
   CountPlanArgs pa{};
@@ -1346,48 +1350,49 @@ static int count_chunk(qf_ctx* c, const qf_dp_config* cfg, bool use_null, bool h
   pa.use_null = use_null;
   pa.nll = c->d_nll.as<double>() + lo;
   pa.lse = c->d_lse.as<double>();
-  pa.pair_fwd = c->d_pair_score.as<double>();
-  pa.pair_fwd_out = c->d_fwd_out.as<double>();
-  pa.weight = c->d_weight.as<double>();
+  pa.pair_fwd = S->d_pair_score.as<double>();
+  pa.pair_fwd_out = S->d_fwd_out.as<double>();
+  pa.weight = S->d_weight.as<double>();
   pa.order_in = have_sort ? c->d_order_in.as<uint32_t>() + p0 : nullptr;
   pa.order_n_in = have_sort ? c->d_order_n_in.as<uint32_t>() + lo : nullptr;
-  pa.order_out = c->d_order_out.as<uint32_t>();
-  pa.order_n_out = c->d_order_n_out.as<uint32_t>();
-  pa.read_loglike = c->d_rll.as<double>();
-  launch_count_plan(pa, c->stream);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  pa.order_out = S->d_order_out.as<uint32_t>();
+  pa.order_n_out = S->d_order_n_out.as<uint32_t>();
+  pa.read_loglike = S->d_rll.as<double>();
+  launch_count_plan(pa, S->stream);
+  HIPCHK(S, hipGetLastError());
+  HIPCHK(S, hipEventRecord(S->ev[4], S->stream));
 
   // ---- Backward + counts
-  if (int rc = launch_classes_concurrently(c, bc, serial_classes, [&](int cls, hipStream_t s) {
+  if (int rc = launch_classes_concurrently(S, bc, serial_classes, [&](int cls, hipStream_t s) {
         FbArgs f2 = fa;
         f2.n_cls_units = bc.cls_count[cls];
-        f2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+        f2.cls_list = S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
         launch_backward_fill(cls, f2, s);
-      }, 0, false, c->cls_ev2, c->cls_end2))
+      }, 0, true, S->cls_ev2, S->cls_end2))
     return rc;
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  HIPCHK(S, hipGetLastError());
+  HIPCHK(S, hipEventRecord(S->ev[5], S->stream));
 
-  HIPCHK(c, hipMemcpyAsync(c->h_fwd.data() + p0, c->d_fwd_out.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_weight.data() + p0, c->d_weight.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_rll.data() + lo, c->d_rll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_order.data() + p0, c->d_order_out.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_order_n.data() + lo, c->d_order_n_out.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + p0, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_fwd.data() + p0, S->d_fwd_out.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_weight.data() + p0, S->d_weight.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_rll.data() + lo, S->d_rll.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_order.data() + p0, S->d_order_out.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_order_n.data() + lo, S->d_order_n_out.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipMemcpyAsync(c->h_cells.data() + p0, S->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(S, hipStreamSynchronize(S->stream));
+  std::lock_guard<std::mutex> lk(out_mu);
   out->total_cells += bc.total_cells;
   out->forward_bytes += fw_bytes;
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); out->ms_seed += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); out->ms_forward += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_plan += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); out->ms_backward += ms;
-  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
+  (void)hipEventElapsedTime(&ms, S->ev[1], S->ev[2]); out->ms_seed += ms;
+  (void)hipEventElapsedTime(&ms, S->ev[2], S->ev[3]); out->ms_forward += ms;
+  (void)hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); out->ms_plan += ms;
+  (void)hipEventElapsedTime(&ms, S->ev[4], S->ev[5]); out->ms_backward += ms;
+  (void)hipEventElapsedTime(&ms, S->ev[1], S->ev[5]); out->ms_total += ms;
   for (int cls = 0; cls < kNumClasses; ++cls) {
     if (!bc.cls_count[cls]) continue;
-    ms = 0; (void)hipEventElapsedTime(&ms, c->cls_ev[cls], c->cls_end[cls]); out->ms_forward_class[cls] += ms;
-    ms = 0; (void)hipEventElapsedTime(&ms, c->cls_ev2[cls], c->cls_end2[cls]); out->ms_backward_class[cls] += ms;
+    ms = 0; (void)hipEventElapsedTime(&ms, S->cls_ev[cls], S->cls_end[cls]); out->ms_forward_class[cls] += ms;
+    ms = 0; (void)hipEventElapsedTime(&ms, S->cls_ev2[cls], S->cls_end2[cls]); out->ms_backward_class[cls] += ms;
     out->cells_class[cls] += bc.cls_cells[cls];
     out->units_class[cls] += bc.cls_count[cls];
   }
@@ -1464,18 +1469,67 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   c->h_cells.resize(n_pairs);
   (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
   out->ms_total = out->ms_prep;
-  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n_reads}};
-  while (!todo.empty()) {
-    const auto [lo, hi] = todo.back();
-    todo.pop_back();
-    bool too_big = false;
-    if (int rc = count_chunk(c, cfg, use_null, sort_in != nullptr, lo, hi, out, &too_big)) return rc;
-    if (too_big) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      todo.push_back({mid, hi});
-      todo.push_back({lo, mid});
+  // Work list: the batch in `n_chunks` pieces (qf_set_pipeline_chunks; default one), two in flight (one slot = stream +
+  // buffers each, one host thread per slot); a piece whose Forward storage exceeds the memory budget is halved.  Measured on
+  // config 4 (MI355X): both fills are bound by fp64 issue and LDS lookups, not by the tails of their grids, so pieces in
+  // flight buy nothing there (31.1 / 30.4 / 37.1 ms per E-step with 1 / 2 / 4 pieces); what they do is bound the memory.
+  uint32_t n_chunks = c->pipeline_chunks ? c->pipeline_chunks : 1u;
+  if (c->debug & QF_DEBUG_SERIAL_CLASSES) n_chunks = 1;
+  n_chunks = std::min(n_chunks, n_reads);
+  const auto t_begin = std::chrono::steady_clock::now();
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> todo;
+    for (uint32_t k = n_chunks; k-- > 0;)
+      todo.push_back({(uint32_t)((uint64_t)n_reads * k / n_chunks), (uint32_t)((uint64_t)n_reads * (k + 1) / n_chunks)});
+    std::mutex mu, out_mu;
+    int in_flight = 0, rc_all = QF_OK;
+    std::condition_variable cv;
+    const int slots = n_chunks > 1 ? 2 : 1;
+    auto worker = [&](Slot* S) {
+      (void)hipSetDevice(c->device);
+      for (;;) {
+        std::pair<uint32_t, uint32_t> job;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !todo.empty() || in_flight == 0 || rc_all != QF_OK; });
+          if (rc_all != QF_OK || todo.empty()) return;
+          job = todo.back();
+          todo.pop_back();
+          ++in_flight;
+        }
+        bool too_big = false;
+        const int rc = count_chunk(c, S, cfg, use_null, sort_in != nullptr, job.first, job.second, slots, out, out_mu, &too_big);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          --in_flight;
+          if (rc != QF_OK && rc_all == QF_OK) {
+            rc_all = rc;
+            if (S != static_cast<Slot*>(c)) c->err = S->err;
+          }
+          if (too_big) {
+            const uint32_t mid = job.first + (job.second - job.first) / 2;
+            todo.push_back({mid, job.second});
+            todo.push_back({job.first, mid});
+          }
+        }
+        cv.notify_all();
+      }
+    };
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // prep, orders and the cleared accumulators are in place before either slot starts
+    if (slots > 1) {
+      if (!c->second_ready) {
+        if (c->second.create()) return fail(c, QF_ERR_DEVICE, "cannot create the second stream");
+        c->second_ready = true;
+      }
+      std::thread t(worker, &c->second);
+      worker(c);
+      t.join();
+    } else {
+      worker(c);
     }
+    if (rc_all != QF_OK) return rc_all;
   }
+  out->ms_total = out->ms_prep + (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   launch_sum_count_replicas(c->d_counts.as<double>(), csize, counts_stride, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1553,7 +1607,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     *too_big = true;
     return QF_OK;
   }
-  if (reserve_big(c->d_tb, tb_bytes + 64, {&c->d_fw, &c->second.d_tb}) != hipSuccess) {
+  if (reserve_big(c->d_tb, tb_bytes + 64, {&c->d_fw, &c->second.d_fw, &c->second.d_tb}) != hipSuccess) {
     if (n_pairs == 1) return fail(c, QF_ERR_MEMORY, "cannot allocate " + std::to_string(tb_bytes >> 20) + " MiB of traceback for one pair");
     *too_big = true;
     return QF_OK;

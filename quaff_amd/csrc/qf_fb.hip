@@ -460,7 +460,7 @@ __global__ void k_count_plan(CountPlanArgs a) {
 //    step and accumulated in fp64; the pair's posterior weight multiplies at the flush, not per term.
 // ------------------------------------------------------------------------------------------------
 template <int G, int B, bool GAPCTX, bool EMLDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 3 ? 2 : B <= 5 ? QF_BWD_WAVES : 1))) void k_backward_fill(FbArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF_BWD_WAVES : 1, B <= 5 ? 8 : 1))) void k_backward_fill(FbArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_fb[];
   const uint32_t Kg = a.dp.Kg, Km = a.Km;
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
