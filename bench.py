@@ -62,6 +62,8 @@ def parse(argv=None):
     ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
     ap.add_argument("--debug-flags", type=int, default=0, help="developer: csrc/qf_internal.h switches (A/B)")
     ap.add_argument("--chunks", type=int, default=0, help="pieces per batch kept two in flight (0 = library default)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="align: batches in flight per GPU (one context and one host thread each, as the CLI's -gpus sharding does)")
     ap.add_argument("--align-flags", type=int, default=0, help="developer: QF_ALIGN_* flags (2 = scores only, not a valid bench)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 and the process group is gloo (RCCL wants one GPU per rank)")

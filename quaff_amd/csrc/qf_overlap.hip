@@ -7,6 +7,7 @@
 // literally.  Bit-exact: the log-sum-exp uses the host-built table with IEEE division, as src/logsumexp.cpp does.
 #include <hip/hip_runtime.h>
 
+#include "qf_dpp.hpp"
 #include "qf_kernels.hpp"
 
 namespace qf {
@@ -18,18 +19,32 @@ __device__ __forceinline__ int tokc(int c) {
   return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
 }
 
-// log_sum_exp(a,b), src/logsumexp.cpp:34-50,84-103, bit-for-bit (exact division, no contraction)
+// x / 1e-4 as IEEE division rounds it, in three operations: q0 = x * RN(1 / c), r = x - c * q0 (exact in an fma),
+// q = q0 + r * RN(1 / c).  With RN(1 / c) the correctly rounded reciprocal and q0 within an ulp, q is the correctly rounded
+// quotient (Markstein's division theorem; the divisor's significand is not all ones); checked against `/` on every
+// x = n * 1e-4 +- 40 ulps for n <= 100 001 and 4e8 random x in [0, 10) (tools/dev/divtest.c).  The compiler's own
+// expansion of `/` is ~12 instructions with two of the slow ones (v_div_scale, v_rcp).
+__device__ __forceinline__ double div_1e4(double x) {
+  const double c = .0001, rc = 1.0 / .0001;
+  const double q0 = x * rc;
+  const double r = fma(-c, q0, x);
+  return fma(r, rc, q0);
+}
+struct __attribute__((packed, aligned(8))) D2 { double v[2]; };   // 16-byte load from an 8-byte aligned address
+
+// log_sum_exp(a,b), src/logsumexp.cpp:34-50,84-103, bit-for-bit (the reference's divisions, no contraction), without
+// branches: one 16-byte gather of the two table entries; x >= 10, NaN and infinities take max + 0 (:86-87).
 __device__ __forceinline__ double lse_exact(const double* __restrict__ tab, double a, double b) {
-  double mx, diff;
-  if (a == b) { mx = a; diff = 0; }
-  else if (a < b) { mx = b; diff = b - a; }
-  else { mx = a; diff = a - b; }
-  if (!(diff < 10.0)) return mx;           // x >= 10, NaN, inf -> log_sum_exp_unary returns 0
-  const int n = (int)(diff / .0001);
-  const double dx = diff - (n * .0001);
-  const double f0 = tab[n], f1 = tab[n + 1];
-  const double df = f1 - f0;
-  return mx + (f0 + df * (dx / .0001));
+  const double mx = a < b ? b : a;                          // (a == b: either)
+  const double diff = a == b ? 0.0 : fabs(a - b);           // -inf - -inf = NaN is the a == b case
+  const bool small = diff < 10.0;
+  const double x = small ? diff : 0.0;
+  const int n = (int)div_1e4(x);
+  const double dx = x - (n * .0001);
+  const D2 f = *(const D2*)(tab + n);
+  const double df = f.v[1] - f.v[0];
+  const double r = mx + (f.v[0] + df * div_1e4(dx));
+  return small ? r : mx;
 }
 
 // Context words of the reverse-complement strand in this sequence's orientation (src/qoverlap.cpp:91-98: the arrays
@@ -98,8 +113,14 @@ __global__ __launch_bounds__(64) void k_overlap_sums(PrepArgs a, const uint32_t*
   a.nll_c[r] = ll;
 }
 
+// The banded fill.  Every cell carries two dependent look-ups of the exact log-sum-exp table (800 KB: L2), and the delete
+// state's chains through the lane's B slots within a step (del(i,j) needs del(i-1,j)): what bounds the kernel is that
+// chain of L2 latencies, so it is written for occupancy (few registers: the three-operation division above, DPP lane
+// exchanges) and keeps everything that does not depend on the chain out of its way -- the pair emissions of step t+1 and the
+// context words of step t+2 are fetched at step t, and the insert state's look-ups (which read only the previous column)
+// are issued before the delete chain starts.
 template <int G, int B, bool GAPCTX>
-__global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 3 : B <= 8 ? 2 : 2))) void k_overlap_fill(OvArgs a) {
   constexpr int UPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -139,52 +160,54 @@ __global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
   double pubM = QF_NEG_INF, pubI = QF_NEG_INF, pubD = QF_NEG_INF;
   double colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
   uint32_t colI = 0, rowJ = 0;
-  // x-side context words of the rows this lane's slots are on; slides by one row per step
-  // xw[b] = context word of row d0 + b + j - 1 (slot b is on row i = d0 + b + j: xw[b] is row i-1, xw[b+1] row i).  The
-  // rows slide down by one per step, so a step shifts the window and loads one new word (fetched a step ahead).
+  // x-side context words of the rows this lane's slots are on: xw[b] = word of row d0 + b + j - 1 (slot b is on row
+  // i = d0 + b + j: xw[b] is row i-1, xw[b+1] row i).  The rows slide down by one per step: a step shifts the window and
+  // takes one new word, loaded two steps ahead (the next step's emissions are fetched a step ahead).
   auto xword = [&](int row) -> uint32_t { return (row >= 1 && row <= xLen) ? xc[row - 1] : 0u; };
   auto yword = [&](int j) -> uint32_t { return yc[min(max(j - 1, -kCtxPad + 1), yLen + 4)]; };
   uint32_t xw[B + 1];
 #pragma unroll
   for (int b = 0; b <= B; ++b) xw[b] = xword(d0 + b - l);
+  uint32_t xwN = xword(d0 + B + 1 - l), xwNN = xword(d0 + B + 2 - l);   // the words entering at steps 1 and 2
   uint32_t gkyPrev = 0;
-  uint32_t wyNext = yword(1 - l);
+  uint32_t wy = yword(1 - l), wyN = yword(2 - l), wyNN = yword(3 - l);
+  auto emis = [&](uint32_t wxrow, uint32_t wycol) -> double { return mmi[(size_t)(wxrow & 0x7FFFu) * KQ + (wycol & 0x7FFFu)]; };
+  double e[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) e[b] = emis(xw[b + 1], wy);
 
   for (int t = 0; t < T; ++t) {
     const int j = t - l + 1;
     const bool colvalid = active && j >= 1 && j <= yLen;
-    const uint32_t wy = wyNext;
-    wyNext = yword(j + 1);
-    const uint32_t xwNext = xword(d0 + B + j);
-    const uint32_t erowY = wy & 0x7FFFu, gky = wy >> 24;
+    const uint32_t gky = wy >> 24;
     const uint32_t gkyP = j > 1 ? gkyPrev : 0u;   // yIndelKmer[j-1], padded with a leading 0
     gkyPrev = gky;
-    double lowM = __shfl_up(pubM, 1, G), lowI = __shfl_up(pubI, 1, G), lowD = __shfl_up(pubD, 1, G);
-    if (l == 0) { lowM = QF_NEG_INF; lowI = QF_NEG_INF; lowD = QF_NEG_INF; }
+    double prevM = dpp_from_below<G, false>(pubM), prevI = dpp_from_below<G, false>(pubI), prevD = dpp_from_below<G, false>(pubD);
     double upM = 0, upI = 0, upD = 0;
-    double prevM = lowM, prevI = lowI, prevD = lowD;
     uint32_t tbw0 = 0, tbw1 = 0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       const int d = d0 + b, i = d + j;
       const bool valid = colvalid && d <= dhi && i >= 1 && i <= xLen;
       const uint32_t wx = xw[b + 1];                       // row i
-      const uint32_t gkx = GAPCTX ? (wx >> 24) : 0u;       // xIndelKmer[i]
-      const uint32_t gkxP = GAPCTX ? (i > 1 ? (xw[b] >> 24) : 0u) : 0u;  // xIndelKmer[i-1]
-      const double e = mmi[(size_t)(wx & 0x7FFFu) * KQ + erowY];
       double m2m, m2i, m2d;
       if (GAPCTX) {
-        m2m = gap[gkxP * Kg + gkyP];                       // m2mScore(i-1, j-1)
-        m2i = gap[(size_t)Kg * Kg + gkx * Kg + gkyP];      // m2iScore(i,   j-1)
-        m2d = gap[2ull * Kg * Kg + gkxP * Kg + gky];       // m2dScore(i-1, j)
+        const uint32_t gkx = wx >> 24;                       // xIndelKmer[i]
+        const uint32_t gkxP = i > 1 ? (xw[b] >> 24) : 0u;    // xIndelKmer[i-1]
+        m2m = gap[gkxP * Kg + gkyP];                         // m2mScore(i-1, j-1)
+        m2i = gap[(size_t)Kg * Kg + gkx * Kg + gkyP];        // m2iScore(i,   j-1)
+        m2d = gap[2ull * Kg * Kg + gkxP * Kg + gky];         // m2dScore(i-1, j)
       } else { m2m = c_m2m; m2i = c_m2i; m2d = c_m2d; }
+      const double eb = e[b];
+      // this slot's emission for the next step: row i + 1 (the word above it in the window), column j + 1
+      e[b] = emis(b + 1 < B ? xw[b + 2] : xwN, wyN);
       // match state; traceback candidate order M, I, D, Start (strict >), src/qoverlap.cpp:204-209
-      const double tM = (M[b] + m2m) + e, tI = (I[b] + i2mS) + e, tD = (D[b] + d2mS) + e;
+      const double tM = (M[b] + m2m) + eb, tI = (I[b] + i2mS) + eb, tD = (D[b] + d2mS) + eb;
       double nm = tM;
       uint32_t sm = 0;
       if (tI > nm) { nm = tI; sm = 1; }
       if (tD > nm) { nm = tD; sm = 2; }
-      if ((j == 1 || i == 1) && e > nm) { nm = e; sm = 3; }
+      if ((j == 1 || i == 1) && eb > nm) { nm = eb; sm = 3; }
       // insert state: sources at (i, j-1) = diagonal d+1, previous column
       double sM, sI, sD;
       if (b + 1 < B) { sM = M[b + 1]; sI = I[b + 1]; sD = D[b + 1]; } else { sM = upM; sI = upI; sD = upD; }
@@ -192,13 +215,13 @@ __global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
       const double lseI = lse_exact(tab, iI, iD);
       double ni = lseI > iM ? lseI : iM;  // max(lse(...), mat + m2i): std::max returns the first unless it is smaller
       uint32_t si = 0;                     // traceback: M, I, D on the individual terms (:215-217)
-      { double s = iM; if (iI > s) { s = iI; si = 1; } if (iD > s) { s = iD; si = 2; } }
+      { double sx = iM; if (iI > sx) { sx = iI; si = 1; } if (iD > sx) { sx = iD; si = 2; } }
       // delete state: sources at (i-1, j) = diagonal d-1, this column
       const double dM = prevM + m2d, dD = prevD + d2dS, dIfill = prevI + d2iS, dItb = prevI + i2dS;
       const double lseD = lse_exact(tab, dD, dIfill);
       double ndl = lseD > dM ? lseD : dM;
       uint32_t sd = 0;                     // traceback: M, then ins + i2dScore(), then D (:221-223)
-      { double s = dM; if (dItb > s) { s = dItb; sd = 1; } if (dD > s) { s = dD; sd = 2; } }
+      { double sx = dM; if (dItb > sx) { sx = dItb; sd = 1; } if (dD > sx) { sx = dD; sd = 2; } }
       if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
       M[b] = nm; I[b] = ni; D[b] = ndl;
       prevM = nm; prevI = ni; prevD = ndl;
@@ -207,14 +230,18 @@ __global__ __launch_bounds__(256) void k_overlap_fill(OvArgs a) {
       if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
       if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
       if (b == 0) {
-        upM = __shfl_down(nm, 1, G); upI = __shfl_down(ni, 1, G); upD = __shfl_down(ndl, 1, G);
-        if (l == G - 1) { upM = QF_NEG_INF; upI = QF_NEG_INF; upD = QF_NEG_INF; }
+        upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); upD = dpp_from_above<G, false>(ndl);
       }
+      __builtin_amdgcn_sched_barrier(0);   // one slot at a time: registers (occupancy) matter more here than overlap inside a wavefront
     }
     pubM = prevM; pubI = prevI; pubD = prevD;
 #pragma unroll
     for (int b = 0; b < B; ++b) xw[b] = xw[b + 1];
-    xw[B] = xwNext;
+    xw[B] = xwN;
+    xwN = xwNN;
+    xwNN = xword(d0 + B + j + 2);
+    wy = wyN; wyN = wyNN;
+    wyNN = yword(j + 3);
     if (colvalid) {
       tb[((uint64_t)t * G + l) * 2] = tbw0;
       tb[((uint64_t)t * G + l) * 2 + 1] = tbw1;
