@@ -62,8 +62,9 @@ def parse(argv=None):
     ap.add_argument("--serial-classes", action="store_true", help="A/B: fill classes one after another on one stream")
     ap.add_argument("--debug-flags", type=int, default=0, help="developer: csrc/qf_internal.h switches (A/B)")
     ap.add_argument("--chunks", type=int, default=0, help="pieces per batch kept two in flight (0 = library default)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="align: batches in flight per GPU (one context and one host thread each, as the CLI's -gpus sharding does)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="align: batches in flight per GPU, one context (its own streams and result buffers) and one host thread each: "
+                         "a batch's result copy and its latency-bound kernels run beside the next batch's fill.  1 = one step at a time")
     ap.add_argument("--align-flags", type=int, default=0, help="developer: QF_ALIGN_* flags (2 = scores only, not a valid bench)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 and the process group is gloo (RCCL wants one GPU per rank)")
@@ -174,6 +175,10 @@ class Job:
         for k in names:
             self.phase[k] = self.phase.get(k, 0.0) + float(getattr(res, "ms_" + k))
 
+    def run_steps(self, k):
+        """k steps; returns the cells they processed."""
+        return sum(self.step() for _ in range(k))
+
 
 # ------------------------------------------------------------------------------------------------ config 2: align
 class AlignJob(Job):
@@ -184,30 +189,52 @@ class AlignJob(Job):
         self.n = a.reads or 100000
         self.read_len = a.read_len or 1000
         self.ref_len = a.ref_len or 10000
-        self.ctx = ctx = Q.Context(self.local_rank)
-        ctx.set_params_json(None)
-        ctx.set_null_json(golden("testquaffnullparams.json"))
         self.ref = api.synth_ref(1, self.ref_len)
-        ctx.set_refs([self.ref, api.revcomp(self.ref)])
         self.seq, self.qual, self.off = api.synth_reads(2 + self.rank, self.ref, self.n, self.read_len)
-        ctx.upload_reads_packed(self.seq, self.qual, self.off)          # resident in HBM before the timed region
-        ctx.set_pipeline_chunks(a.chunks)
-        ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
+        self.ctxs = []
+        for _ in range(max(1, 1 if a.serial_classes else a.inflight)):
+            ctx = Q.Context(self.local_rank)
+            ctx.set_params_json(None)
+            ctx.set_null_json(golden("testquaffnullparams.json"))
+            ctx.set_refs([self.ref, api.revcomp(self.ref)])
+            ctx.upload_reads_packed(self.seq, self.qual, self.off)          # resident in HBM before the timed region
+            ctx.set_pipeline_chunks(a.chunks)
+            ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
+            self.ctxs.append(ctx)
+        self.ctx = self.ctxs[0]
         self.cfg = Q.DPConfig(band_size=a.band)
         self.cls_ms, self.cls_cells = {}, {}
         self.Q = Q
+        self.turn = 0
+        import threading
+        self.lock = threading.Lock()
+        if len(self.ctxs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(len(self.ctxs))
+            for c in self.ctxs:                       # every context allocates its buffers before the warm-up steps
+                c.align_resident(self.cfg, a.align_flags, raw=True)
 
     def reset(self):
         self.cls_ms, self.cls_cells, self.phase = {}, {}, {}
 
-    def step(self):
-        res = self.ctx.align_resident(self.cfg, self.a.align_flags, raw=True)   # synchronous: returns with the results on the host
-        for k in range(res.n_fill_classes):
-            if res.units_class[k]:
-                self.cls_ms[k] = self.cls_ms.get(k, 0.0) + res.ms_fill_class[k]
-                self.cls_cells[k] = int(res.cells_class[k])
-        self.add_phases(res, ("prep", "seed", "fill", "traceback", "total"))
-        self.last = (int(res.traceback_bytes), int(res.n_units), int(res.n_alignments))
+    def run_steps(self, k):
+        """k steps, len(self.ctxs) of them in flight: step s runs on context s mod n (each call is synchronous and returns with
+        its results on the host; the calls of different contexts overlap on the device)."""
+        if len(self.ctxs) == 1:
+            return sum(self.step() for _ in range(k))
+        futs = [self.pool.submit(self.step, self.ctxs[(self.turn + s) % len(self.ctxs)]) for s in range(k)]
+        self.turn += k
+        return sum(f.result() for f in futs)
+
+    def step(self, ctx=None):
+        res = (ctx or self.ctx).align_resident(self.cfg, self.a.align_flags, raw=True)   # synchronous: returns with the results on the host
+        with self.lock:
+            for k in range(res.n_fill_classes):
+                if res.units_class[k]:
+                    self.cls_ms[k] = self.cls_ms.get(k, 0.0) + res.ms_fill_class[k]
+                    self.cls_cells[k] = int(res.cells_class[k])
+            self.add_phases(res, ("prep", "seed", "fill", "traceback", "total"))
+            self.last = (int(res.traceback_bytes), int(res.n_units), int(res.n_alignments))
         return int(res.total_cells)
 
     def describe(self):
@@ -238,12 +265,23 @@ class AlignJob(Job):
             roof["concurrent_kernels"] = sorted(self.kernel_symbol(k) for k in self.cls_ms if k != dom)
             roof["isolated"] = {"ms_per_launch": iso["ms_per_launch"], "achieved": iso["achieved"], "frac": iso["frac"]}
         tb_bytes, n_units, n_align = self.last
+        # one step at a time, and one step that also uploads its reads (200 MB of characters and qualities over PCIe)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.align_resident(self.cfg, a.align_flags, raw=True)
+        seq_ms = (time.perf_counter() - t0) / 3 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.upload_reads_packed(self.seq, self.qual, self.off)
+            ctx.align_resident(self.cfg, a.align_flags, raw=True)
+        up_ms = (time.perf_counter() - t0) / 3 * 1e3
         self.extra = {"reads_per_gpu": self.n, "pairs_per_gpu": 2 * self.n, "bands": n_units, "alignments": n_align,
-                      "traceback_bytes": tb_bytes,
+                      "traceback_bytes": tb_bytes, "batches_in_flight": len(self.ctxs),
+                      "ms_per_step_one_at_a_time": round(seq_ms, 3), "ms_per_step_with_upload_one_at_a_time": round(up_ms, 3),
                       "fill_kernels": {self.kernel_symbol(k): {"ms": round(self.cls_ms[k] / steps, 4), "cells": self.cls_cells[k]}
                                        for k in sorted(self.cls_ms)}}
         cpu = None
-        n_s = min(3000 if a.cpu_sample < 0 else a.cpu_sample, self.n)
+        n_s = min(30000 if a.cpu_sample < 0 else a.cpu_sample, self.n)   # ~10 s of oracle time on the box's 16 host cores
         if n_s > 0:
             full = ctx.align_resident(self.cfg, 0, reads_below=n_s)   # unpacked view of the same batch for the parity check
             cpu = self.cpu_baseline(n_s, cpu_threads(a), full)
@@ -315,6 +353,9 @@ class FullDPJob(AlignJob):
         self.cfg = Q.DPConfig(sparse=False)
         self.cls_ms, self.cls_cells = {}, {}
         self.Q = Q
+        self.ctxs, self.turn = [ctx], 0
+        import threading
+        self.lock = threading.Lock()
 
     def describe(self):
         return ("BASELINE config 5%s: -kmatchoff full DP, %d bp ref (+revcomp) x %d x %d bp reads sharded over %d GPU(s) by cell count"
@@ -414,7 +455,7 @@ class TrainJob(Job):
                       "kernels": {g: {"ms_forward": round(v["ms_forward"] / steps, 4), "ms_backward": round(v["ms_backward"] / steps, 4),
                                       "cells": v["cells"], "units": v["units"]} for g, v in sorted(self.cls.items())}}
         cpu = None
-        n_s = min(1000 if a.cpu_sample < 0 else a.cpu_sample, self.n)
+        n_s = min(10000 if a.cpu_sample < 0 else a.cpu_sample, self.n)
         if n_s > 0:
             cpu = self.cpu_baseline(n_s, cpu_threads(a))
         return roof, cpu
@@ -525,8 +566,9 @@ class OverlapJob(Job):
 
     def finish(self, steps):
         a = self.a
-        # the kernel the fill phase spends most of its time in
-        dom = max(self.cls, key=lambda k: self.cls[k]["ms"])
+        # the kernel that fills most of the cells (the classes run side by side: a small class's event-bracketed duration is
+        # the length of the whole phase, not its own work)
+        dom = max(self.cls, key=lambda k: self.cls[k]["cells"])
         e = self.cls[dom]
         sym = self.kernel_symbol(dom)
         kind = "overlap_single" if dom == 0 else "overlap"
@@ -536,7 +578,7 @@ class OverlapJob(Job):
                       "fill_kernels": {self.kernel_symbol(k): {"ms": round(v["ms"] / steps, 4), "cells": v["cells"], "bands": v["units"]}
                                        for k, v in sorted(self.cls.items())}}
         cpu = None
-        n_s = min(2000 if a.cpu_sample < 0 else a.cpu_sample, len(self.pairs[0]))
+        n_s = min(100000 if a.cpu_sample < 0 else a.cpu_sample, len(self.pairs[0]))
         if n_s > 0:
             cpu = self.cpu_baseline(n_s, cpu_threads(a))
         return roof, cpu
@@ -623,15 +665,12 @@ def main():
         if "WORLD_SIZE" in os.environ:
             dist.barrier()                    # barrier + torch.cuda.synchronize() on both sides
 
-    for _ in range(a.warmup):
-        job.step()
+    job.run_steps(a.warmup)
     if hasattr(job, "reset"):
         job.reset()
     sync_all()
     t0 = time.perf_counter()
-    total_cells = 0
-    for _ in range(a.steps):
-        total_cells += job.step()
+    total_cells = job.run_steps(a.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -649,7 +688,8 @@ def main():
            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))
     sys.stdout.flush()
-    job.ctx.close()
+    for c in getattr(job, "ctxs", [job.ctx]):
+        c.close()
     dist.finalize()
 
 

@@ -218,6 +218,15 @@ struct qf_ctx : Slot {
 constexpr uint64_t kMaxPairsPerCall = 1ull << 28;   // unit tables are sized 4 x pairs + slack in 32 bits
 constexpr size_t kLseHermiteOffset = 100002;  // doubles: the exact table (100001) padded to even, then the quadratic pieces
 
+// One Viterbi fill at a time per device, whatever context or slot it comes from: two fills side by side only share the
+// fp64 issue slots (each takes twice as long), while a fill next to another batch's seeding, selection, traceback and result
+// copies (latency-bound, little arithmetic) costs neither much.  Callers keep several batches in flight with one context
+// and host thread each (bench.py --inflight, the CLI's -gpus sharding); the token orders their fills.
+static std::mutex& device_fill_token(int device) {
+  static std::mutex tokens[64];
+  return tokens[device & 63];
+}
+
 static int fail(Slot* c, int code, const std::string& msg) {
   c->err = msg;
   return code;
@@ -764,7 +773,7 @@ static int seed_pairs(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t n_pa
 // offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
 // *too_big is set (the caller splits the range).
 static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
-                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, std::mutex* fill_token, bool* too_big) {
+                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool two_in_flight, bool* too_big) {
   *too_big = false;
   const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
   const uint32_t n_pairs = n_reads * n_refs;
@@ -825,13 +834,13 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   // With two chunks in flight only one of them fills at a time: the token keeps the other on its seeding or traceback,
   // which is what overlaps well with a fill (two fills side by side just share the VALUs).
   std::unique_lock<std::mutex> token;
-  if (fill_token) token = std::unique_lock<std::mutex>(*fill_token);
+  token = std::unique_lock<std::mutex>(device_fill_token(c->device));
   {
     int order[kNumClasses], n_used = 0;
     for (int cls = 0; cls < kNumClasses; ++cls) if (bc.cls_count[cls]) order[n_used++] = cls;
     std::sort(order, order + n_used, [&](int p, int q) { return bc.cls_cells[p] > bc.cls_cells[q]; });
     const bool concurrent = !(c->debug & QF_DEBUG_SERIAL_CLASSES);
-    const int n_lanes = fill_token ? 2 : 4;  // two chunks in flight: one side stream each (hardware queues are few)
+    const int n_lanes = two_in_flight ? 2 : 4;  // two chunks in flight: one side stream each (hardware queues are few)
     // the side streams are non-blocking: they must not start before what the main stream still has queued for this chunk
     // (the in-place sorts of the class lists above, and the buffer clears of reserve_pair_buffers)
     if (concurrent && n_used > 1) {
@@ -1000,7 +1009,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   std::vector<std::pair<uint32_t, uint32_t>> todo;
   for (uint32_t k = n_chunks; k-- > 0;)
     todo.push_back({(uint32_t)((uint64_t)n_reads * k / n_chunks), (uint32_t)((uint64_t)n_reads * (k + 1) / n_chunks)});
-  std::mutex mu, out_mu, fill_mu;
+  std::mutex mu, out_mu;
   int in_flight = 0, rc_all = QF_OK;
   std::condition_variable cv;
   auto worker = [&](Slot* S) {
@@ -1017,7 +1026,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
       }
       bool too_big = false;
       const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, chunk_budget(c, S->d_tb, n_chunks > 1 ? 2 : 1), out,
-                                 out_mu, n_chunks > 1 ? &fill_mu : nullptr, &too_big);
+                                 out_mu, n_chunks > 1, &too_big);
       {
         std::lock_guard<std::mutex> lk(mu);
         --in_flight;
