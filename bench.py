@@ -123,9 +123,15 @@ def pmc_for(workload, kernel_prefix):
     path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
     if not os.path.exists(path):
         return None
-    for k in json.load(open(path)).get("kernels", []):
-        if kernel_prefix in k["kernel"].replace(" ", ""):
+    want = kernel_prefix.replace(" ", "")
+    rows = json.load(open(path)).get("kernels", [])
+    for k in rows:
+        if want in k["kernel"].replace(" ", ""):
             return k
+    if want.endswith(">"):            # a template whose trailing arguments the caller did not spell out
+        for k in rows:
+            if want[:-1] + "," in k["kernel"].replace(" ", ""):
+                return k
     return None
 
 
@@ -578,7 +584,7 @@ class OverlapJob(Job):
                       "fill_kernels": {self.kernel_symbol(k): {"ms": round(v["ms"] / steps, 4), "cells": v["cells"], "bands": v["units"]}
                                        for k, v in sorted(self.cls.items())}}
         cpu = None
-        n_s = min(100000 if a.cpu_sample < 0 else a.cpu_sample, len(self.pairs[0]))
+        n_s = min(10000 if a.cpu_sample < 0 else a.cpu_sample, len(self.pairs[0]))
         if n_s > 0:
             cpu = self.cpu_baseline(n_s, cpu_threads(a))
         return roof, cpu
@@ -598,7 +604,10 @@ class OverlapJob(Job):
         res = self.ctx.overlap_resident(self.pairs, self.cfg)
         xs, ys, cs = self.pairs
         rng = np.random.default_rng(5)
-        pick = sorted(set(res["alignments"].keys()) | set(int(p) for p in rng.choice(len(xs), size=n_sample, replace=False)))
+        with_al = sorted(res["alignments"].keys())
+        if len(with_al) > 2000:          # dense read sets: a random 2 000 of the pairs that align (each is a banded 2 kb x 2 kb fill on the CPU)
+            with_al = [with_al[k] for k in sorted(rng.choice(len(with_al), size=2000, replace=False))]
+        pick = sorted(set(with_al) | set(int(p) for p in rng.choice(len(xs), size=n_sample, replace=False)))
         fs = {}
 
         def seq_of(k):
@@ -630,9 +639,9 @@ class OverlapJob(Job):
             elif g is not None:
                 mism += 1
         return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
-                "sample": "%d pairs of the rank-0 block: all %d with a returned alignment + a random %d (%d cells), oracle/quaff_oracle.c, %d "
+                "sample": "%d pairs of the rank-0 block: %d of the %d with a returned alignment + a random %d (%d cells), oracle/quaff_oracle.c, %d "
                           "threads, one pair per task; result, score, coordinates and state path compared with =="
-                          % (len(pick), len(res["alignments"]), n_sample, cells, threads),
+                          % (len(pick), len(with_al), len(res["alignments"]), n_sample, cells, threads),
                 "seconds": round(dt, 3), "gpu_parity_mismatches": int(mism)}
 
 
