@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
 // whose band differs from the first band's (x, diagonal, strand) gathers from global memory as before.  Each lane also
 // takes a whole 128-byte line (32 columns) of its y context words at a time, and stores its traceback nibbles 16 bytes
 // at a time.  (The per-lane gathers of the plain kernel are bound by L1 line fills: one 128-byte line per 8-byte entry.)
-constexpr int kSingleSub = 4;
+constexpr int kSingleSub = 4;    // columns per block (one barrier per block); each of the four wavefronts stages kSingleSub / 4 rows.
+                                 // (8 measured the same 24 ms on config 3 at either 2 or 3 wavefronts per SIMD: the kernel streams ~30 GB of
+                                 // y context words and traceback at 2.7 TB/s; barriers are not what it waits for.)
 template <bool GAPCTX>
 __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
@@ -386,25 +388,37 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   constexpr int kRowRegs = 3;                                         // 16-byte chunks per lane per round: 64 x 3 x 2 = 384 >= 380 doubles
   const uint32_t rowChunks = KQ / 2;                                  // (KQ = Km * 95 with Km a power of four: even)
   const int rowRounds = (int)((rowChunks + 64 * kRowRegs - 1) / (64 * kRowRegs));   // 1 for order 0
-  auto lead_word = [&](int g) -> uint32_t {                           // context word of the first band's x at block g, row srow
-    return xc0[min(max(d0 + 4 * g + (int)srow, -kCtxPad + 8), xLen0)];  // base i = d0 + j, j = 1 + 4g + srow -> index i - 1
-  };
-  D2 R[kRowRegs];
-  auto load_rows = [&](uint32_t word, int round) {
-    const D2* __restrict__ src = (const D2*)(mmi0 + (size_t)(word & 0x7FFFu) * KQ);
+  constexpr int kRowsPerWave = kSingleSub / 4;                        // this wavefront stages rows srow, srow + 4, ...
+  struct Lead { uint32_t w[kRowsPerWave]; };
+  auto lead_word = [&](int g) -> Lead {                               // context words of the first band's x at block g, this wavefront's rows
+    Lead L;
 #pragma unroll
-    for (int q = 0; q < kRowRegs; ++q) R[q] = src[min((uint32_t)(round * kRowRegs + q) * 64 + scol, rowChunks - 1)];
+    for (int rr = 0; rr < kRowsPerWave; ++rr)                         // base i = d0 + j, j = 1 + kSingleSub g + row -> index i - 1
+      L.w[rr] = xc0[min(max(d0 + kSingleSub * g + (int)srow + 4 * rr, -kCtxPad + 8), xLen0)];
+    return L;
+  };
+  D2 R[kRowsPerWave][kRowRegs];
+  auto load_rows = [&](const Lead& L, int round) {
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+      const D2* __restrict__ src = (const D2*)(mmi0 + (size_t)(L.w[rr] & 0x7FFFu) * KQ);
+#pragma unroll
+      for (int q = 0; q < kRowRegs; ++q) R[rr][q] = src[min((uint32_t)(round * kRowRegs + q) * 64 + scol, rowChunks - 1)];
+    }
   };
   auto store_rows = [&](int b, int round) {
-    D2* dst = (D2*)(s_rows + ((size_t)b * kSingleSub + srow) * KQ);
 #pragma unroll
-    for (int q = 0; q < kRowRegs; ++q) {
-      const uint32_t ch = (uint32_t)(round * kRowRegs + q) * 64 + scol;
-      if (ch < rowChunks) dst[ch] = R[q];
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+      D2* dst = (D2*)(s_rows + ((size_t)b * kSingleSub + srow + 4 * rr) * KQ);
+#pragma unroll
+      for (int q = 0; q < kRowRegs; ++q) {
+        const uint32_t ch = (uint32_t)(round * kRowRegs + q) * 64 + scol;
+        if (ch < rowChunks) dst[ch] = R[rr][q];
+      }
     }
   };
   const int nBlocks = (T + kSingleSub - 1) / kSingleSub;
-  uint32_t wordCur = lead_word(0), wordNext = lead_word(1);
+  Lead wordCur = lead_word(0), wordNext = lead_word(1);
   if (rowRounds == 1) load_rows(wordCur, 0);
   W4 yw[8], ywNext[8];
   {
@@ -447,12 +461,17 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
           for (int c = 0; c < kSingleSub; ++c) M = (M + gap0) + rows[(size_t)c * KQ + (wyc[c] & 0x7FFFu)];
         } else {
           const int xi = min(max(d + js - 1, -kCtxPad + 8), xLen);
-          const W4 xa = *(const W4*)(xc + xi);
+          W4 xa4[kSingleSub / 4];
+#pragma unroll
+          for (int q = 0; q < kSingleSub / 4; ++q) xa4[q] = *(const W4*)(xc + min(xi + 4 * q, xLen + 4));
+          uint32_t xav[kSingleSub];
+#pragma unroll
+          for (int c = 0; c < kSingleSub; ++c) xav[c] = xa4[c >> 2].v[c & 3];
           double e[kSingleSub];
 #pragma unroll
           for (int c = 0; c < kSingleSub; ++c) {
             const uint32_t ey = wyc[c] & 0x7FFFu;
-            e[c] = shared_row ? rows[(size_t)c * KQ + ey] : mmi[(size_t)(xa.v[c] & 0x7FFFu) * KQ + ey];
+            e[c] = shared_row ? rows[(size_t)c * KQ + ey] : mmi[(size_t)(xav[c] & 0x7FFFu) * KQ + ey];
           }
           uint32_t nib = 0;
 #pragma unroll
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
             const int j = js + c, i = d + j;
             const bool valid = active && j <= yLen && i >= 1 && i <= xLen;
             const uint32_t gxP = i > 1 ? gxPrev : 0u, gyP = j > 1 ? gyPrev : 0u;  // xIndelKmer[i-1], yIndelKmer[j-1] (padded 0)
-            gxPrev = xa.v[c] >> 24; gyPrev = wyc[c] >> 24;
+            gxPrev = xav[c] >> 24; gyPrev = wyc[c] >> 24;
             const double tM = (M + (GAPCTX ? gap[gxP * Kg + gyP] : gap0)) + e[c];
             double nm = tM;
             uint32_t sm = 0;
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
             if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
             if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
           }
-          words[sub >> 1] |= nib << (16 * (sub & 1));
+          if (kSingleSub == 8) words[sub] = nib; else words[sub >> 1] |= nib << (16 * (sub & 1));
         }
       }
     }

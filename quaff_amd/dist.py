@@ -14,7 +14,7 @@ def env_rank():
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank)."""
     rank, world, local = env_rank()
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:   # under a launcher: also a one-rank job has its process group (rehearsals)
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
