@@ -22,7 +22,23 @@ def init(backend=None):
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
                 torch.cuda.set_device(local)
-            dist.init_process_group(backend)
+            # RCCL prints a version banner on stdout when its first communicator comes up; bench.py's stdout carries one JSON
+            # line and nothing else, so the banner goes to stderr: fd 1 points at fd 2 until the first collective has run
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                if backend == "nccl":
+                    dist.init_process_group(backend, device_id=torch.device("cuda", local))
+                    dist.barrier(device_ids=[local])
+                else:
+                    dist.init_process_group(backend)
+                    dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
     return rank, world, local
 
 
@@ -45,9 +61,10 @@ def barrier():
         import torch
         if dist.get_backend() == "nccl":
             torch.cuda.synchronize()
-        dist.barrier()
-        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
             torch.cuda.synchronize()
+        else:
+            dist.barrier()
 
 
 def allreduce_sum(vec):
