@@ -143,6 +143,8 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     alg_gbs = BYTES_PER_CELL * cells / t / 1e9
     valu = ops * cells / t / 1e12
     pmc = pmc_for(workload, kernel.replace(" ", ""))
+    if pmc and abs(pmc.get("cells_per_launch", 0) - cells) > 0.01 * cells:
+        pmc = None                    # the committed capture is of another problem size (other --reads, another rank count)
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
     out = {"bound": bound, "kernel": kernel, "cells_per_launch": int(cells), "ms_per_launch": round(ms, 4)}
     if bound == "fp64_valu":

@@ -54,3 +54,22 @@ def test_shard_range_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_balanced_blocks_partition():
+    """Strong-scaled workloads cut their items into contiguous blocks of nearly equal weight (rows of the overlap pair
+    triangle by pair count, full-DP reads by cell count): a partition, monotone, and balanced to within one item."""
+    from quaff_amd.dist import balanced_blocks
+    rng = np.random.default_rng(3)
+    n = 50000
+    rows = (2 * n - 1 - np.arange(n - 1)).astype(np.float64)          # config 3: row nx holds 2n - 1 - nx pairs
+    for world in (1, 2, 3, 8):
+        cuts = balanced_blocks(rows, world)
+        assert cuts[0] == 0 and cuts[-1] == len(rows) and len(cuts) == world + 1 and np.all(np.diff(cuts) >= 0)
+        sums = np.array([rows[cuts[k]:cuts[k + 1]].sum() for k in range(world)])
+        assert sums.max() - sums.min() <= 2 * rows.max()
+    w = rng.integers(4000, 6000, 257).astype(np.float64)                # config 5: reads of ~5 kb
+    cuts = balanced_blocks(w, 8)
+    sums = np.array([w[cuts[k]:cuts[k + 1]].sum() for k in range(8)])
+    assert cuts[-1] == 257 and sums.max() - sums.min() <= 2 * w.max()
+    assert list(balanced_blocks([1, 1, 1], 1)) == [0, 3]

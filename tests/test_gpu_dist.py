@@ -115,3 +115,21 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["cpu_baseline"]["gpu_parity_mismatches"] == 0
     assert j["config"]["cells_per_step"] > 2 * 4000 * 60000 and 0 < j["roofline"]["frac"] <= 1
     assert j["roofline"]["bound"] == "fp64_valu" and "k_viterbi_fill<16,5,false,true>" in j["roofline"]["kernel"]
+
+
+def test_comm_init_all_wants_one_gpu_per_context():
+    """qf_comm_init_all is the one-process form (one context per device, `quaff train -gpus n`): RCCL takes one rank per GPU,
+    so two contexts on one device are refused with a message (the CLI then sums on the host)."""
+    import ctypes as C
+    import quaff_amd as Q
+    a, b = Q.Context(0), Q.Context(0)
+    arr = (C.c_void_p * 2)(a.h, b.h)
+    L = a.L
+    L.qf_comm_init_all.argtypes = [C.c_void_p, C.c_int]
+    rc = L.qf_comm_init_all(arr, 2)
+    assert rc == -5 and b"one rank per GPU" in L.qf_last_error(a.h)
+    one = (C.c_void_p * 1)(a.h)
+    assert L.qf_comm_init_all(one, 1) == 0 and a.comm_size() == 1
+    v, ll = a.allreduce_counts(np.arange(10.0), 2.5)
+    assert np.array_equal(v, np.arange(10.0)) and ll == 2.5
+    a.close(); b.close()
