@@ -231,6 +231,12 @@ class Context:
         self.L.qf_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         self._chk(self.L.qf_debug_set_flags(self.h, flags))
 
+    def lse_pack_bytes(self):
+        """Tests only (csrc/qf_internal.h): bytes of the packed log-sum-exp table the overlap fills keep in LDS (0: not used)."""
+        self.L.qf_debug_lse_pack_bytes.argtypes = [C.c_void_p]
+        self.L.qf_debug_lse_pack_bytes.restype = C.c_uint32
+        return int(self.L.qf_debug_lse_pack_bytes(self.h))
+
     # ---- E-step reduction across GPUs (RCCL)
     @staticmethod
     def comm_unique_id():

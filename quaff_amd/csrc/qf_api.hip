@@ -189,6 +189,8 @@ struct qf_ctx : Slot {
   std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
+  DevBuf d_lse_pack;            // the exact table packed for LDS (qf_device.hpp: kLsePack*); 0 bytes: not usable on this device
+  uint32_t lse_pack_bytes = 0;
   double min_score = -INFINITY;   // qf_set_score_threshold
   uint64_t tb_budget = 0;   // qf_set_memory_budget: per-chunk device storage budget (traceback / Forward matrices); 0 = what the device has free
   bool ov_scores[2] = {false, false};
@@ -304,7 +306,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_lse_pack,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
@@ -712,7 +714,7 @@ static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_
   HIPCHK(S, S->d_sort_v.reserve((size_t)max_units * 4));
   for (int cls = 0; cls < kNumClasses; ++cls) {
     if (cls == kRowClass || bc.cls_count[cls] <= 64) continue;
-    if (!c->ragged_reads && cls != 0) continue;   // overlap: only the single-diagonal list, into pair order
+    (void)0;   // (overlap sorts every list: bands by the columns they cross, the single-diagonal list into pair order)
     const int rc = sort_class_list(S->d_cls_key.as<uint32_t>() + (size_t)cls * max_units, S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units,
                                    bc.cls_count[cls], S->d_sort_k.as<uint32_t>(), S->d_sort_v.as<uint32_t>(), &S->sort_tmp, &S->sort_tmp_cap,
                                    S->stream);
@@ -1135,6 +1137,18 @@ int qf_debug_set_flags(qf_ctx* c, uint32_t flags) {
   return QF_OK;
 }
 
+static int ensure_lse(qf_ctx* c);
+static std::vector<uint8_t> pack_lse_table(const std::vector<double>& tab);
+uint32_t qf_debug_pack_lse_table(uint8_t* out, uint32_t cap) {
+  const std::vector<uint8_t> pack = pack_lse_table(lse_table());
+  if (out) memcpy(out, pack.data(), std::min<size_t>(cap, pack.size()));
+  return (uint32_t)pack.size();
+}
+uint32_t qf_debug_lse_pack_bytes(qf_ctx* c) {
+  if (!c || hipSetDevice(c->device) != hipSuccess || ensure_lse(c) != QF_OK) return 0;
+  return c->lse_pack_bytes;
+}
+
 int qf_set_pipeline_chunks(qf_ctx* c, uint32_t n_chunks) {
   if (!c) return QF_ERR_ARG;
   c->pipeline_chunks = n_chunks;
@@ -1167,6 +1181,65 @@ int qf_align_batch(qf_ctx* c, const qf_dp_config* cfg, const char* seq, const ch
 // the function at the three Chebyshev nodes of the piece, in t = 128 x - n, with the linear and quadratic coefficients
 // rounded to fp32 (16 bytes per piece): within 3.3e-10 of log1p(exp(-x)) everywhere, the accuracy of the reference's own
 // 1e-4-step linear table.  The last piece is all zero: x >= 10 is the reference's cut-off (:84-90).
+// The exact table packed for LDS (qf_device.hpp).  Pieces: Chebyshev interpolants of log1p(exp(-x)) in extended precision,
+// coefficients rounded to fp64; corrections: bit pattern of the table entry minus bit pattern of the piece evaluated with the
+// device's sequence of fused multiply-adds.  Returns an empty vector if a piece would need fields wider than 16 bits (a libm
+// whose exp/log are off by more than the 1 + exp(-x) rounding this scheme is sized for).
+static std::vector<uint8_t> pack_lse_table(const std::vector<double>& tab) {
+  std::vector<uint8_t> head(kLsePackStream, 0);
+  std::vector<uint32_t> words;
+  uint64_t bit = 0;
+  constexpr int K = kLsePackDegree + 1, W = kLsePackSpan;
+  auto pattern = [](double d) { int64_t b; memcpy(&b, &d, 8); return b; };
+  for (int p = 0; p < kLsePackPieces; ++p) {
+    long double node[K], dd[K];
+    for (int k = 0; k < K; ++k) {
+      node[k] = (W / 2) * cosl(M_PIl * (2 * k + 1) / (2 * K));
+      dd[k] = log1pl(expl(-((long double)(W * p + W / 2) + node[k]) * 1e-4L));
+    }
+    for (int j = 1; j < K; ++j)
+      for (int k = K - 1; k >= j; --k) dd[k] = (dd[k] - dd[k - 1]) / (node[k] - node[k - j]);
+    std::vector<long double> poly(1, dd[K - 1]);   // Newton form -> monomials in u
+    for (int k = K - 2; k >= 0; --k) {
+      std::vector<long double> np(poly.size() + 1, 0.0L);
+      for (size_t i = 0; i < poly.size(); ++i) { np[i + 1] += poly[i]; np[i] -= node[k] * poly[i]; }
+      np[0] += dd[k];
+      poly.swap(np);
+    }
+    struct { double c[K]; uint32_t bit_base, width; } pc;
+    for (int i = 0; i < K; ++i) pc.c[i] = (double)poly[i];
+    int64_t corr[W + 1], lo = 0, hi = 0;
+    for (int t = 0; t <= W; ++t) {
+      const int n = std::min(W * p + t, kLseEntries - 1);   // the last piece ends at entry 100 000
+      const double u = (double)(t - W / 2);
+      double v = pc.c[kLsePackDegree];
+      for (int i = kLsePackDegree - 1; i >= 0; --i) v = std::fma(v, u, pc.c[i]);
+      corr[t] = W * p + t < kLseEntries ? pattern(tab[n]) - pattern(v) : 0;
+      lo = std::min(lo, corr[t]); hi = std::max(hi, corr[t]);
+    }
+    uint32_t w = 1;
+    while (lo < -(1ll << (w - 1)) || hi > (1ll << (w - 1)) - 1) ++w;
+    if (w > 16) return {};
+    pc.bit_base = (uint32_t)bit;
+    pc.width = w;
+    for (int t = 0; t <= W; ++t, bit += w) {
+      const uint64_t field = (uint64_t)corr[t] & ((1ull << w) - 1);
+      words.resize((bit + w + 63) / 32 + 1, 0u);
+      words[bit >> 5] |= (uint32_t)(field << (bit & 31));
+      if ((bit & 31) + w > 32) words[(bit >> 5) + 1] |= (uint32_t)(field >> (32 - (bit & 31)));
+    }
+    memcpy(&head[kLsePackC01 + p * 16], &pc.c[0], 16);
+    memcpy(&head[kLsePackC23 + p * 16], &pc.c[2], 16);
+    memcpy(&head[kLsePackC45 + p * 16], &pc.c[4], 16);
+    memcpy(&head[kLsePackMeta + p * 8], &pc.bit_base, 8);
+  }
+  words.resize((words.size() + 5) & ~(size_t)3, 0u);   // a look-up reads two words; whole 16-byte blocks for the copy to LDS
+  std::vector<uint8_t> out(kLsePackStream + words.size() * 4);
+  memcpy(out.data(), head.data(), kLsePackStream);
+  memcpy(out.data() + kLsePackStream, words.data(), words.size() * 4);
+  return out;
+}
+
 static int ensure_lse(qf_ctx* c) {
   if (c->lse_uploaded) return QF_OK;
   std::vector<double> t = lse_table();
@@ -1188,6 +1261,22 @@ static int ensure_lse(qf_ctx* c) {
   HIPCHK(c, c->d_lse.reserve(bytes));
   HIPCHK(c, hipMemcpy(c->d_lse.p, t.data(), kLseHermiteOffset * 8, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_lse.as<char>() + kLseHermiteOffset * 8, pieces.data(), pieces.size() * sizeof(LsePiece), hipMemcpyHostToDevice));
+  // packed form for the overlap fills: used only if this device rebuilds every entry from it bit for bit
+  {
+    const std::vector<uint8_t> pack = pack_lse_table(lse_table());
+    int lds_max = 0;
+    (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
+    if (!pack.empty() && pack.size() <= (size_t)lds_max) {
+      DevBuf bad;
+      HIPCHK(c, c->d_lse_pack.reserve(pack.size()));
+      HIPCHK(c, bad.reserve(4));
+      HIPCHK(c, hipMemcpy(c->d_lse_pack.p, pack.data(), pack.size(), hipMemcpyHostToDevice));
+      if (lse_pack_mismatches(c->d_lse_pack.as<uint8_t>(), (uint32_t)pack.size(), c->d_lse.as<double>(), bad.as<uint32_t>(), c->stream) == 0)
+        c->lse_pack_bytes = (uint32_t)pack.size();
+      bad.release();
+      (void)hipGetLastError();
+    }
+  }
   c->lse_uploaded = true;
   return QF_OK;
 }
@@ -1642,6 +1731,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
   oa.lse = c->d_lse.as<double>();
+  if (c->lse_pack_bytes && !(c->debug & QF_DEBUG_GLOBAL_LSE)) { oa.lse_pack = c->d_lse_pack.as<uint8_t>(); oa.lse_pack_bytes = c->lse_pack_bytes; }
   oa.min_score = c->min_score;
   oa.no_lds_rows = (c->debug & QF_DEBUG_GLOBAL_OVERLAP_ROWS) != 0;
   oa.Km = sc.Km;

@@ -127,6 +127,15 @@ __host__ __device__ inline uint64_t row_ov_words(int dlo, int dhi, int xLen, int
 __host__ __device__ inline uint64_t tb_word_index(int t, int l, int G) {
   return ((uint64_t)(t >> 3) * G + l) * 8 + (t & 7);
 }
+// Columns of y a band of diagonals [dlo, dhi] (d = i - j) meets inside the xLen x yLen rectangle: j0 + 1 ... band_last_col.
+// Two reads that overlap by a third of their length have bands that cross a third of the columns: the overlap fills step
+// over these columns only.
+__host__ __device__ inline int band_col0(int dhi) { return dhi < 0 ? -dhi : 0; }
+__host__ __device__ inline int band_last_col(int dlo, int xLen, int yLen) { return xLen - dlo < yLen ? xLen - dlo : yLen; }
+__host__ __device__ inline int band_cols(int dlo, int dhi, int xLen, int yLen) {
+  const int n = band_last_col(dlo, xLen, yLen) - band_col0(dhi);
+  return n > 0 ? n : 0;
+}
 __host__ __device__ inline uint64_t unit_tb_words(int cls, uint32_t yLen) {
   if (cls == 0) return (yLen + 7) / 8;
   const FillClass fc = fill_class(cls);
@@ -171,6 +180,20 @@ struct BatchCounters {
 
 constexpr int kLsePieces = 1281;   // quadratic pieces of log(1 + exp(-x)) on a 1/128 grid over [0, 10) + the all-zero piece of the cut-off
 struct LsePiece { double c0; float c1, c2; };   // c0 + t (c1 + t c2), t = 128 x - n in [0, 1): 16 bytes, one ds_read_b128 per lookup
+// The exact log-sum-exp table (src/logsumexp.cpp:20-28: 100 001 doubles, 800 KB) in a form that fits a CU's LDS: the table is
+// a smooth function plus the rounding noise of log(1 + exp(-x)) -- about 1.1e-16 absolute, i.e. 2 units in the last place at
+// x = 0 and 16 000 at x = 10 -- so entry n = one fifth-degree polynomial per 256 entries, evaluated with a fixed sequence of
+// fused multiply-adds (the same bits on the host and on the device), plus a small signed correction to the result's bit
+// pattern, stored in as many bits as the piece needs (2 ... 15).  Piece p serves entries 256 p ... 256 p + 256 (its own
+// corrections for all 257), so the two entries of an interpolation come from one piece.  128 KB instead of 800.
+// Layout (bytes): coefficient pairs (c0, c1)[391] | (c2, c3)[391] | (c4, c5)[391] of the polynomial in u = (n mod 256) - 128,
+// 16 bytes per piece each (a wavefront's 64 pieces spread over all LDS banks; 64-byte piece records would put them on four
+// bank groups) | (bit_base, width)[391]: the piece's corrections are `width`-bit two's complement fields from bit `bit_base`
+// of the stream | the correction bit stream.
+constexpr int kLseEntriesDev = 100001;
+constexpr int kLsePackPieces = 391, kLsePackSpan = 256, kLsePackDegree = 5;
+constexpr uint32_t kLsePackC01 = 0, kLsePackC23 = kLsePackPieces * 16, kLsePackC45 = 2 * kLsePackPieces * 16,
+                   kLsePackMeta = 3 * kLsePackPieces * 16, kLsePackStream = (kLsePackMeta + kLsePackPieces * 8 + 15) & ~15u;
 constexpr uint32_t kInsRows = 4 * 95;  // insert-emission table: [token * 95 + quality]
 
 struct DpParams {  // kernel argument block for the fills

@@ -17,9 +17,16 @@ enum qf_debug_flag {
   QF_DEBUG_GLOBAL_TABLES = 8u,        /* emission tables stay in global memory even when they fit LDS */
   QF_DEBUG_GLOBAL_INDEX = 16u,        /* reference k-mer index stays in global memory */
   QF_DEBUG_GLOBAL_OVERLAP_ROWS = 32u, /* overlap single-diagonal bands gather their emissions from global memory */
-  QF_DEBUG_NO_BAND_SHORTCUTS = 64u    /* E-step without the single-diagonal Forward kernel / negligible-band skip */
+  QF_DEBUG_NO_BAND_SHORTCUTS = 64u,   /* E-step without the single-diagonal Forward kernel / negligible-band skip */
+  QF_DEBUG_GLOBAL_LSE = 128u          /* overlap fills gather the exact log-sum-exp table from global memory, not its packed form in LDS */
 };
 int qf_debug_set_flags(qf_ctx *ctx, uint32_t flags);
+/* The exact log-sum-exp table packed for LDS (qf_device.hpp: kLsePack*), built on the host:
+ * copies up to `cap` bytes into `out`, returns the size (0: the host's libm does not fit the scheme).  No GPU needed. */
+uint32_t qf_debug_pack_lse_table(uint8_t *out, uint32_t cap);
+/* Bytes of the packed table this context's overlap fills keep in LDS; 0 if the device did not rebuild the table from it bit for
+ * bit (the fills then gather the table from global memory). */
+uint32_t qf_debug_lse_pack_bytes(qf_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
   __syncthreads();
   bool act = false, have = false;
   uint32_t pair = 0, lrank = 0, urank = 0;
-  int dlo = 0, dhi = 0, cls = 0, yLen = 0;
+  int dlo = 0, dhi = 0, cls = 0, yLen = 0, xLen = 0;
   unsigned long long tbw = 0, cells = 0;
   if (n_ovf) {  // overflow pass: one thread per spilled band
     if (idx < n_ovf) {
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
     if (have) {
       uint32_t r, x;
   pair_rx(a, pair, r, x);
-      const int xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]);
+      xLen = (int)(a.ref_off[x + 1] - a.ref_off[x]);
       yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
       cls = classify_width(dhi - dlo + 1);
       if (a.storage_mode == 2 && cls > 10) cls = kRowClass;    // overlap kernels take up to 8 diagonals per lane
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         urank = atomicAdd(&s_nact, 1u);
         tbw = a.storage_mode == 2 ? (cls == 0 ? (unsigned long long)(yLen + 7) / 8
                                      : cls == kRowClass ? row_ov_words(dlo, dhi, xLen, yLen)
-                                               : (unsigned long long)(yLen + fill_class(cls).G - 1) * fill_class(cls).G * 2)
+                                               : (unsigned long long)(band_cols(dlo, dhi, xLen, yLen) + fill_class(cls).G - 1) * fill_class(cls).G * 2)
               : a.storage_mode == 1 ? (cls == kRowClass ? row_fw_doubles(dlo, dhi, xLen, yLen) : unit_fw_doubles(cls, (uint32_t)yLen))
               : cls == kRowClass  ? row_unit_words(dlo, dhi, xLen, yLen)
                                   : unit_tb_words(cls, (uint32_t)yLen);
@@ -921,9 +921,11 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
     return;
   }
   a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
-  // sort key of the class lists (descending): read length; the overlap path's single-diagonal list is put back into pair
-  // order instead, so that the bands of a workgroup share their x (k_overlap_single_lds)
-  if (a.cls_key) a.cls_key[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = (a.storage_mode == 2 && cls == 0) ? ~pair : (uint32_t)yLen;
+  // sort key of the class lists (descending): read length = steps of the fill; overlap: the columns the band crosses, and its
+  // single-diagonal list is put back into pair order instead, so that the bands of a workgroup share their x (k_overlap_single_lds)
+  if (a.cls_key)
+    a.cls_key[(uint64_t)cls * a.max_units + s_base[cls] + lrank] =
+        a.storage_mode != 2 ? (uint32_t)yLen : cls == 0 ? ~pair : (uint32_t)band_cols(dlo, dhi, xLen, yLen);
   Unit u;
   u.pair = pair;
   u.dlo = dlo;

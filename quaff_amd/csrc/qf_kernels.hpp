@@ -143,6 +143,8 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   int no_lds_rows;          // A/B: single-diagonal bands gather their emissions from global memory (k_overlap_single)
   const double* gap[2];
   const double* lse;
+  const uint8_t* lse_pack;  // the same table packed for LDS (qf_device.hpp: kLsePack*) (null: not available)
+  uint32_t lse_pack_bytes;
   uint32_t Km, Kg;
   // finalize / traceback
   const uint32_t* pair_head;
@@ -236,6 +238,8 @@ int sort_kmer_index(const uint8_t* tok, const uint64_t* d_off, const int* d_off3
                     unsigned long long* keys_out, uint32_t* pos_out, void** temp, size_t* temp_cap, hipStream_t s);
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s);
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);
+// entries of the exact log-sum-exp table that its packed form (qf_device.hpp) does not reproduce on this device; ~0u on a HIP error
+uint32_t lse_pack_mismatches(const uint8_t* pack, uint32_t pack_bytes, const double* tab, uint32_t* d_bad, hipStream_t s);
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s);
 void launch_overlap_traceback(const OvArgs& a, hipStream_t s);
 void launch_select(const FinalArgs& a, hipStream_t s);

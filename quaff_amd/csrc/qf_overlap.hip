@@ -32,19 +32,66 @@ __device__ __forceinline__ double div_1e4(double x) {
 }
 struct __attribute__((packed, aligned(8))) D2 { double v[2]; };   // 16-byte load from an 8-byte aligned address
 
-// log_sum_exp(a,b), src/logsumexp.cpp:34-50,84-103, bit-for-bit (the reference's divisions, no contraction), without
-// branches: one 16-byte gather of the two table entries; x >= 10, NaN and infinities take max + 0 (:86-87).
-__device__ __forceinline__ double lse_exact(const double* __restrict__ tab, double a, double b) {
-  const double mx = a < b ? b : a;                          // (a == b: either)
-  const double diff = a == b ? 0.0 : fabs(a - b);           // -inf - -inf = NaN is the a == b case
+// Entries n and n + 1 of the exact table from its packed form in LDS (qf_device.hpp: kLsePack*): three 16-byte reads and one
+// 8-byte read of the piece, two Horner evaluations that share them, one 8-byte read of the correction stream.
+__device__ __forceinline__ void lse_pack_pair(const char* pk, int n, double& f0, double& f1) {
+  const int t = n & (kLsePackSpan - 1), p = n >> 8;
+  const double2 c01 = *(const double2*)(pk + kLsePackC01 + p * 16), c23 = *(const double2*)(pk + kLsePackC23 + p * 16),
+                c45 = *(const double2*)(pk + kLsePackC45 + p * 16);
+  const uint2 bw = *(const uint2*)(pk + kLsePackMeta + p * 8);
+  const double u0 = (double)(t - kLsePackSpan / 2), u1 = u0 + 1.0;
+  double v0 = c45.y, v1 = c45.y;
+  v0 = fma(v0, u0, c45.x); v1 = fma(v1, u1, c45.x);
+  v0 = fma(v0, u0, c23.y); v1 = fma(v1, u1, c23.y);
+  v0 = fma(v0, u0, c23.x); v1 = fma(v1, u1, c23.x);
+  v0 = fma(v0, u0, c01.y); v1 = fma(v1, u1, c01.y);
+  v0 = fma(v0, u0, c01.x); v1 = fma(v1, u1, c01.x);
+  const uint32_t o = bw.x + (uint32_t)t * bw.y;
+  const uint32_t* wp = (const uint32_t*)(pk + kLsePackStream) + (o >> 5);
+  const uint32_t bits = __builtin_amdgcn_alignbit(wp[1], wp[0], o & 31u);   // both fields: 2 * width <= 32
+  const long long k0 = (int)__builtin_amdgcn_sbfe(bits, 0u, bw.y), k1 = (int)__builtin_amdgcn_sbfe(bits, bw.y, bw.y);   // (the builtin's type is unsigned)
+  f0 = __longlong_as_double(__double_as_longlong(v0) + k0);
+  f1 = __longlong_as_double(__double_as_longlong(v1) + k1);
+}
+
+// max(log_sum_exp(a, b), c) as the fills use it (std::max(lse, c): the first unless it is smaller); log_sum_exp(a, b) is
+// src/logsumexp.cpp:34-50,84-103 bit for bit (the reference's divisions, no contraction), without branches; x >= 10, NaN and
+// infinities take max + 0 (:86-87).  The table term is at most its entry 0 = log 2 and rounding is monotonic, so
+// log_sum_exp(a, b) <= RN(max(a, b) + 0.694): a lane whose c is above that takes c without a look-up (it reads entry 0 like
+// the x >= 10 lanes).  PACKED: the two entries come from the packed table in LDS; otherwise they are one 16-byte gather of the
+// 800 KB table, which costs a 128-byte line through the L1 per lane (2 clocks of the CU's L2 port each, measured:
+// tools/dev/l2_gather_bench.hip) -- that, three times per cell with the pair emission, is what bounds the global variant.
+template <bool PACKED>
+__device__ __forceinline__ double max_lse_exact(const void* __restrict__ tab, double a, double b, double c) {
+  double mx;                                                // v_max_f64 as it is (fmax would canonicalise both operands first)
+  asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+  const double diff = fabs(a - b);                          // NaN for -inf - -inf: not "small", the result is max + 0 = -inf as in :86-87
+  const bool skip = c > mx + 0.694;
   const bool small = diff < 10.0;
-  const double x = small ? diff : 0.0;
+  const double x = small && !skip ? diff : 0.0;
   const int n = (int)div_1e4(x);
   const double dx = x - (n * .0001);
-  const D2 f = *(const D2*)(tab + n);
-  const double df = f.v[1] - f.v[0];
-  const double r = mx + (f.v[0] + df * div_1e4(dx));
-  return small ? r : mx;
+  double f0, f1;
+  if (PACKED) lse_pack_pair((const char*)tab, n, f0, f1);
+  else { const D2 f = *(const D2*)((const double*)tab + n); f0 = f.v[0]; f1 = f.v[1]; }
+  const double df = f1 - f0;
+  const double r = mx + (f0 + df * div_1e4(dx));
+  const double l = small ? r : mx;
+  return !(l > c) ? c : l;                                  // (a skipped lane has l <= RN(mx + log 2) < c)
+}
+
+// Rebuilds every table entry from the packed form, both ways it can be reached (as entry n of its own piece and as the 257th
+// entry of the piece below), and counts the ones that differ from the table: the library uses the packed form only if none does.
+__global__ __launch_bounds__(256) void k_lse_pack_check(const uint8_t* __restrict__ pack, uint32_t pack_bytes, const double* __restrict__ tab,
+                                                        uint32_t* __restrict__ bad) {
+  extern __shared__ __attribute__((aligned(16))) char s_pack[];
+  for (uint32_t k = threadIdx.x; k < pack_bytes / 16; k += blockDim.x) ((uint4*)s_pack)[k] = ((const uint4*)pack)[k];
+  __syncthreads();
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < kLseEntriesDev - 1; n += gridDim.x * blockDim.x) {
+    double f0, f1;
+    lse_pack_pair(s_pack, n, f0, f1);
+    if (__double_as_longlong(f0) != __double_as_longlong(tab[n]) || __double_as_longlong(f1) != __double_as_longlong(tab[n + 1])) atomicAdd(bad, 1u);
+  }
 }
 
 // Context words of the reverse-complement strand in this sequence's orientation (src/qoverlap.cpp:91-98: the arrays
@@ -119,9 +166,15 @@ __global__ __launch_bounds__(64) void k_overlap_sums(PrepArgs a, const uint32_t*
 // exchanges) and keeps everything that does not depend on the chain out of its way -- the pair emissions of step t+1 and the
 // context words of step t+2 are fetched at step t, and the insert state's look-ups (which read only the previous column)
 // are issued before the delete chain starts.
-template <int G, int B, bool GAPCTX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 3 : B <= 8 ? 2 : 2))) void k_overlap_fill(OvArgs a) {
+template <int G, int B, bool GAPCTX, bool PACKED>
+__global__ __launch_bounds__(PACKED ? 512 : 256) __attribute__((amdgpu_waves_per_eu(PACKED ? 2 : B <= 5 ? 3 : 2)))
+void k_overlap_fill(OvArgs a) {
   constexpr int UPW = 64 / G;
+  extern __shared__ __attribute__((aligned(16))) char s_pack[];
+  if (PACKED) {
+    for (uint32_t k = threadIdx.x; k < a.lse_pack_bytes / 16; k += blockDim.x) ((uint4*)s_pack)[k] = ((const uint4*)a.lse_pack)[k];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int grp = lane / G, l = lane % G;
@@ -139,12 +192,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 3 
     yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
     dlo = u.dlo; dhi = u.dhi; tb_off = u.tb_off;
   }
-  int T = active ? yLen + G - 1 : 0;
+  // the columns this band crosses inside the rectangle (qf_device.hpp: band_col0): step t of lane l is column j0 + t - l + 1
+  const int j0 = band_col0(dhi), jEnd = band_last_col(dlo, xLen, yLen);
+  int T = active && jEnd > j0 ? jEnd - j0 + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   const int d0 = dlo + l * B;
   const double* __restrict__ mmi = a.mmi[comp];
   const double* __restrict__ gap = a.gap[comp];
-  const double* __restrict__ tab = a.lse;
+  const void* tab = PACKED ? (const void*)s_pack : (const void*)a.lse;
   const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
   const double* gsc = gap + 3ull * Kg * Kg;
   // accessor swaps of src/qoverlap.h:46-50, literally
@@ -167,18 +222,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 3 
   auto yword = [&](int j) -> uint32_t { return yc[min(max(j - 1, -kCtxPad + 1), yLen + 4)]; };
   uint32_t xw[B + 1];
 #pragma unroll
-  for (int b = 0; b <= B; ++b) xw[b] = xword(d0 + b - l);
-  uint32_t xwN = xword(d0 + B + 1 - l), xwNN = xword(d0 + B + 2 - l);   // the words entering at steps 1 and 2
-  uint32_t gkyPrev = 0;
-  uint32_t wy = yword(1 - l), wyN = yword(2 - l), wyNN = yword(3 - l);
+  for (int b = 0; b <= B; ++b) xw[b] = xword(d0 + b + j0 - l);
+  uint32_t xwN = xword(d0 + B + 1 + j0 - l), xwNN = xword(d0 + B + 2 + j0 - l);   // the words entering at steps 1 and 2
+  uint32_t wy = yword(j0 + 1 - l), wyN = yword(j0 + 2 - l), wyNN = yword(j0 + 3 - l);
+  uint32_t gkyPrev = yword(j0 - l) >> 24;
   auto emis = [&](uint32_t wxrow, uint32_t wycol) -> double { return mmi[(size_t)(wxrow & 0x7FFFu) * KQ + (wycol & 0x7FFFu)]; };
   double e[B];
 #pragma unroll
   for (int b = 0; b < B; ++b) e[b] = emis(xw[b + 1], wy);
 
   for (int t = 0; t < T; ++t) {
-    const int j = t - l + 1;
-    const bool colvalid = active && j >= 1 && j <= yLen;
+    const int j = j0 + t - l + 1;
+    const bool colvalid = active && j > j0 && j <= jEnd;   // (the wavefront runs as long as its longest band: the others stop storing)
     const uint32_t gky = wy >> 24;
     const uint32_t gkyP = j > 1 ? gkyPrev : 0u;   // yIndelKmer[j-1], padded with a leading 0
     gkyPrev = gky;
@@ -212,14 +267,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 3 
       double sM, sI, sD;
       if (b + 1 < B) { sM = M[b + 1]; sI = I[b + 1]; sD = D[b + 1]; } else { sM = upM; sI = upI; sD = upD; }
       const double iM = sM + m2i, iI = sI + i2iS, iD = sD + d2iS;
-      const double lseI = lse_exact(tab, iI, iD);
-      double ni = lseI > iM ? lseI : iM;  // max(lse(...), mat + m2i): std::max returns the first unless it is smaller
+      double ni = max_lse_exact<PACKED>(tab, iI, iD, iM);   // max(lse(ins + i2i, del + d2i), mat + m2i)
       uint32_t si = 0;                     // traceback: M, I, D on the individual terms (:215-217)
       { double sx = iM; if (iI > sx) { sx = iI; si = 1; } if (iD > sx) { sx = iD; si = 2; } }
       // delete state: sources at (i-1, j) = diagonal d-1, this column
       const double dM = prevM + m2d, dD = prevD + d2dS, dIfill = prevI + d2iS, dItb = prevI + i2dS;
-      const double lseD = lse_exact(tab, dD, dIfill);
-      double ndl = lseD > dM ? lseD : dM;
+      double ndl = max_lse_exact<PACKED>(tab, dD, dIfill, dM);
       uint32_t sd = 0;                     // traceback: M, then ins + i2dScore(), then D (:221-223)
       { double sx = dM; if (dItb > sx) { sx = dItb; sd = 1; } if (dD > sx) { sx = dD; sd = 2; } }
       if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
@@ -227,14 +280,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? 3 
       prevM = nm; prevI = ni; prevD = ndl;
       const uint32_t byte = sm | (si << 2) | (sd << 4);
       if (b < 4) tbw0 |= byte << (8 * b); else tbw1 |= byte << (8 * (b - 4));
-      if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
-      if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
       if (b == 0) {
         upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); upD = dpp_from_above<G, false>(ndl);
       }
-      __builtin_amdgcn_sched_barrier(0);   // one slot at a time: registers (occupancy) matter more here than overlap inside a wavefront
+      if (!PACKED) __builtin_amdgcn_sched_barrier(0);   // global table: one slot at a time, registers (occupancy) matter more than overlap inside a wavefront
     }
     pubM = prevM; pubI = prevI; pubD = prevD;
+    // free ends (src/qoverlap.cpp:141,153): best match cell of the last column / last row.  Outside the slot loop, so that the
+    // loop is one basic block (the slots' look-ups overlap), and behind a branch few steps take.
+    if (colvalid && (j == yLen || (xLen - j >= d0 && xLen - j < d0 + B))) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int d = d0 + b, i = d + j;
+        const double nm = M[b];
+        const bool valid = d <= dhi && i >= 1 && i <= xLen;
+        if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
+        if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
+      }
+    }
 #pragma unroll
     for (int b = 0; b < B; ++b) xw[b] = xw[b + 1];
     xw[B] = xwN;
@@ -612,13 +675,11 @@ __global__ __launch_bounds__(64) void k_overlap_rows(OvArgs a) {
         if (tD > nm) { nm = tD; sm = 2; }
         if ((j == 1 || i == 1) && e > nm) { nm = e; sm = 3; }
         const double iM = oM + m2i, iI = oI + i2iS, iD = oD + d2iS;
-        const double lseI = lse_exact(tab, iI, iD);
-        double ni = lseI > iM ? lseI : iM;
+        double ni = max_lse_exact<false>(tab, iI, iD, iM);
         uint32_t si = 0;
         { double sv = iM; if (iI > sv) { sv = iI; si = 1; } if (iD > sv) { sv = iD; si = 2; } }
         const double dM = abM + m2d, dD = abD + d2dS, dIfill = abI + d2iS, dItb = abI + i2dS;
-        const double lseD = lse_exact(tab, dD, dIfill);
-        double ndl = lseD > dM ? lseD : dM;
+        double ndl = max_lse_exact<false>(tab, dD, dIfill, dM);
         uint32_t sd = 0;
         { double sv = dM; if (dItb > sv) { sv = dItb; sd = 1; } if (dD > sv) { sv = dD; sd = 2; } }
         if (!valid) { nm = QF_NEG_INF; ni = QF_NEG_INF; ndl = QF_NEG_INF; }
@@ -722,7 +783,7 @@ __global__ void k_overlap_traceback(OvArgs a) {
       return (words[so[s] + ((unsigned long long)(j - jlo + li) * 64 + li) * 2 + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
     }
     const int dd = (i - j) - u.dlo, l = dd / fc.B, b = dd % fc.B;
-    const uint64_t w = ((uint64_t)(j - 1 + l) * fc.G + l) * 2 + (b >> 2);
+    const uint64_t w = ((uint64_t)(j - 1 - band_col0(u.dhi) + l) * fc.G + l) * 2 + (b >> 2);
     return (tb[w] >> (8 * (b & 3))) & 0xFFu;
   };
   uint32_t* tmp = a.runs_tmp + rec.tmp_off;
@@ -759,9 +820,23 @@ __global__ void k_overlap_traceback(OvArgs a) {
 
 template <int G, int B>
 static void launch_ov_gb(const OvArgs& a, hipStream_t s) {
-  const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw, blocks = (waves + 3) / 4;
-  if (a.Kg > 1) hipLaunchKernelGGL((k_overlap_fill<G, B, true>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_overlap_fill<G, B, false>), dim3(blocks), dim3(256), 0, s, a);
+  const uint32_t upw = 64 / G, waves = (a.n_cls_units + upw - 1) / upw;
+  if (a.lse_pack) {   // the packed table takes most of a CU's LDS: one workgroup of eight wavefronts per CU
+    auto fn = a.Kg > 1 ? k_overlap_fill<G, B, true, true> : k_overlap_fill<G, B, false, true>;
+    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lse_pack_bytes);
+    hipLaunchKernelGGL(fn, dim3((waves + 7) / 8), dim3(512), a.lse_pack_bytes, s, a);
+  } else {
+    auto fn = a.Kg > 1 ? k_overlap_fill<G, B, true, false> : k_overlap_fill<G, B, false, false>;
+    hipLaunchKernelGGL(fn, dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  }
+}
+uint32_t lse_pack_mismatches(const uint8_t* pack, uint32_t pack_bytes, const double* tab, uint32_t* d_bad, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void*)k_lse_pack_check, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_bytes);
+  (void)hipMemsetAsync(d_bad, 0, 4, s);
+  hipLaunchKernelGGL(k_lse_pack_check, dim3(64), dim3(256), pack_bytes, s, pack, pack_bytes, tab, d_bad);
+  uint32_t bad = ~0u;
+  if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return ~0u;
+  return bad;
 }
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;

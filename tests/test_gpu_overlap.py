@@ -74,6 +74,26 @@ def test_overlap_small_genome(ctx):
     assert (res["n_diagonals"] > 60).sum() >= 6               # real overlaps seed multi-diagonal bands
 
 
+def test_overlap_packed_lse_table_in_lds_and_global_table_agree(ctx):
+    """The banded fills read the exact log-sum-exp table from its packed form in LDS (the device rebuilt all 100 001 entries
+    from it bit for bit when the context uploaded it); the variant that gathers the table from global memory gives the same
+    bits.  Both against the oracle, gap contexts on and off."""
+    assert ctx.lse_pack_bytes() > 100_000
+    rng = np.random.default_rng(141)
+    reads = overlapping_reads(rng, 1500, 9, 500)
+    pj = synth_params_json(rng, 1, 1)
+    for params in (DEFAULT_JSON, pj):
+        ctx.set_params_json(None if params is DEFAULT_JSON else params)
+        try:
+            a, _ = check_overlap(ctx, reads, params, dict(kmer_threshold=14))
+            ctx.set_debug_flags(128)                                  # QF_DEBUG_GLOBAL_LSE
+            b, _ = check_overlap(ctx, reads, params, dict(kmer_threshold=14))
+        finally:
+            ctx.set_debug_flags(0)
+            ctx.set_params_json(None)
+        assert np.array_equal(a["viterbi"], b["viterbi"]) and (a["n_diagonals"] > 60).sum() >= 6
+
+
 def test_overlap_bands_and_thresholds(ctx):
     rng = np.random.default_rng(42)
     reads = overlapping_reads(rng, 900, 6, 350)

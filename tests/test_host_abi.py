@@ -96,3 +96,41 @@ def test_synthetic_generator(api):
         nf, nr = len(O.envelope(xt, y, sc_cfg)), len(O.envelope(xr, y, sc_cfg))
         assert (nf > 60 and nr == 1) if n % 2 == 0 else (nr > 60 and nf == 1)
     assert api.revcomp(b"AACGT") == b"ACGTT"
+
+
+def test_packed_lse_table_rebuilds_the_table(api):
+    """The exact log-sum-exp table in the form the overlap fills keep in LDS (csrc/qf_device.hpp: one fifth-degree piece per
+    256 entries + bit-packed corrections): evaluated with exactly rounded fused multiply-adds (rational arithmetic here, the
+    device's v_fma_f64 there), every sampled entry comes back bit for bit, reached both as entry n of its piece and as the
+    piece's entry n + 1.  (On a GPU the library checks all 100 001 entries itself before it uses the packed form.)"""
+    import struct
+    from fractions import Fraction
+    L = api.load_library()
+    L.qf_debug_pack_lse_table.restype = C.c_uint32
+    size = L.qf_debug_pack_lse_table(None, 0)
+    assert 100_000 < size <= 160 * 1024 and size % 16 == 0            # fits one CU's LDS
+    raw = (C.c_uint8 * size)()
+    assert L.qf_debug_pack_lse_table(raw, size) == size
+    raw = bytes(raw)
+    tabp, cnt = C.POINTER(C.c_double)(), C.c_int()
+    L.qf_get_lse_table(None, C.byref(tabp), C.byref(cnt))
+    tab = np.ctypeslib.as_array(tabp, (cnt.value,))
+    assert np.array_equal(tab, np.ctypeslib.as_array(O.lib().qo_lse_table(), (100001,)))
+    P = 391                                                            # layout: csrc/qf_device.hpp kLsePack*
+    coef = np.concatenate([np.frombuffer(raw[k * P * 16:(k + 1) * P * 16], dtype="<f8").reshape(P, 2) for k in range(3)], axis=1)
+    meta = np.frombuffer(raw[3 * P * 16:3 * P * 16 + P * 8], dtype="<u4").reshape(P, 2)
+    words = np.frombuffer(raw[(3 * P * 16 + P * 8 + 15) & ~15:], dtype="<u4")
+    assert meta[:, 1].min() >= 1 and meta[:, 1].max() <= 16
+
+    def entry(p, t):
+        v = float(coef[p, 5])
+        for i in range(4, -1, -1):
+            v = float(Fraction(v) * (t - 128) + Fraction(float(coef[p, i])))          # one rounding: a fused multiply-add
+        w, o = int(meta[p, 1]), int(meta[p, 0]) + t * int(meta[p, 1])
+        f = ((int(words[o >> 5]) | (int(words[(o >> 5) + 1]) << 32)) >> (o & 31)) & ((1 << w) - 1)
+        if f >= 1 << (w - 1):
+            f -= 1 << w
+        return struct.unpack("<d", struct.pack("<q", struct.unpack("<q", struct.pack("<d", v))[0] + f))[0]
+
+    for n in list(range(0, 100000, 53)) + [255, 256, 511, 512, 99839, 99840, 99999]:
+        assert entry(n >> 8, n & 255) == tab[n] and entry(n >> 8, (n & 255) + 1) == tab[n + 1], n
