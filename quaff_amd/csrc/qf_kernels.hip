@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
         act = true;
         lrank = atomicAdd(&s_cnt[cls], 1u);
         urank = atomicAdd(&s_nact, 1u);
-        tbw = a.storage_mode == 2 ? (cls == 0 ? (unsigned long long)(yLen + 7) / 8
+        tbw = a.storage_mode == 2 ? (cls == 0 ? 0ull   // a single-diagonal band's traceback is one flag, kept in the unit
                                      : cls == kRowClass ? row_ov_words(dlo, dhi, xLen, yLen)
                                                : (unsigned long long)(band_cols(dlo, dhi, xLen, yLen) + fill_class(cls).G - 1) * fill_class(cls).G * 2)
               : a.storage_mode == 1 ? (cls == kRowClass ? row_fw_doubles(dlo, dhi, xLen, yLen) : unit_fw_doubles(cls, (uint32_t)yLen))

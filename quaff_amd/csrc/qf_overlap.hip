@@ -327,14 +327,17 @@ void k_overlap_fill(OvArgs a) {
 
 // Single-diagonal bands (most read pairs do not overlap: only diagonal 0 is in the envelope): with no neighbouring
 // diagonal the gap states stay -inf and the match state is a serial chain.  One lane per band, eight columns per round
-// with the context words and emissions fetched ahead of the chain; 2 traceback bits used per cell (one nibble).
+// with the context words and emissions fetched ahead of the chain.  Traceback: every cell's match state comes from the
+// match state of the cell before it, except that the diagonal's first cell (the only one with i == 1 or j == 1) may start
+// the alignment (src/qoverlap.cpp:204-209): that one flag is all a single-diagonal band keeps (in its unit's tb_off, which
+// it has no other use for), instead of a nibble per cell that would be zero everywhere else.
 __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
   struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
   const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = uidx < a.n_cls_units;
   uint32_t uid = 0, comp = 0;
   int d = 0, xLen = 0, yLen = 0;
-  uint64_t xb = 0, yb = 0, tb_off = 0;
+  uint64_t xb = 0, yb = 0;
   if (active) {
     uid = a.cls_list[uidx];
     const Unit u = a.units[uid];
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
     comp = a.pair_comp[u.pair];
     xb = a.seq_off[x]; xLen = (int)(a.seq_off[x + 1] - xb);
     yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
-    d = u.dlo; tb_off = u.tb_off;
+    d = u.dlo;
   }
   int T = active ? yLen : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
@@ -351,9 +354,8 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
   const uint32_t Kg = a.Kg, KQ = a.Km * (kNQualDev + 1);
   const uint32_t* __restrict__ xc = a.ctx + xb;
   const uint32_t* __restrict__ yc = (comp ? a.ctxc : a.ctx) + yb;
-  uint32_t* __restrict__ tb = a.tb + tb_off;
   double M = QF_NEG_INF, colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
-  uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0;
+  uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0, startFlag = 0;
   for (int j0 = 1; j0 <= T; j0 += 8) {
     const int yi = min(j0 - 1, yLen);                       // both context arrays are padded by kCtxPad words
     const int xi = min(max(d + j0 - 1, -kCtxPad + 8), xLen);
@@ -367,7 +369,6 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
       wx[c] = c < 4 ? xa.v[c] : xb4.v[c - 4];
       e[c] = mmi[(size_t)(wx[c] & 0x7FFFu) * KQ + (wy[c] & 0x7FFFu)];
     }
-    uint32_t word = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int j = j0 + c, i = d + j;
@@ -376,20 +377,18 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
       gxPrev = wx[c] >> 24; gyPrev = wy[c] >> 24;
       const double tM = (M + gap[gxP * Kg + gyP]) + e[c];
       double nm = tM;
-      uint32_t sm = 0;
-      if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; sm = 3; }
+      if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; if (valid) startFlag = 3; }
       if (!valid) nm = QF_NEG_INF;
       M = nm;
-      word |= sm << (4 * c);
       if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
       if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
     }
-    if (active && j0 <= yLen) tb[(j0 - 1) >> 3] = word;
   }
   if (active) {
     Unit* u = &a.units[uid];
     u->end_val = colBest; u->end_i = colI;
     u->end2_val = rowBest; u->end2_j = rowJ;
+    u->tb_off = startFlag;
   }
 }
 
@@ -398,8 +397,8 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
 // x's base d + j of the emission table and differ only in the column (y's base j).  Per block of kSingleSub columns the
 // workgroup copies those rows (Km * 95 doubles each, coalesced) into LDS and every lane picks its entries there; a lane
 // whose band differs from the first band's (x, diagonal, strand) gathers from global memory as before.  Each lane also
-// takes a whole 128-byte line (32 columns) of its y context words at a time, and stores its traceback nibbles 16 bytes
-// at a time.  (The per-lane gathers of the plain kernel are bound by L1 line fills: one 128-byte line per 8-byte entry.)
+// takes a whole 128-byte line (32 columns) of its y context words at a time.  (The per-lane gathers of the plain kernel are
+// bound by L1 line fills: one 128-byte line per 8-byte entry.)
 constexpr int kSingleSub = 4;    // columns per block (one barrier per block); each of the four wavefronts stages kSingleSub / 4 rows.
                                  // (8 measured the same 24 ms on config 3 at either 2 or 3 wavefronts per SIMD: the kernel streams ~30 GB of
                                  // y context words and traceback at 2.7 TB/s; barriers are not what it waits for.)
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   const bool active = uidx < a.n_cls_units;
   uint32_t uid = 0, comp = 0, x = 0;
   int d = 0, xLen = 0, yLen = 0;
-  uint64_t xb = 0, yb = 0, tb_off = 0;
+  uint64_t xb = 0, yb = 0;
   if (active) {
     uid = a.cls_list[uidx];
     const Unit u = a.units[uid];
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
     comp = a.pair_comp[u.pair];
     xb = a.seq_off[x]; xLen = (int)(a.seq_off[x + 1] - xb);
     yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
-    d = u.dlo; tb_off = u.tb_off;
+    d = u.dlo;
   }
   if (threadIdx.x == 0) { s_x0 = x; s_comp0 = comp; s_d0 = d; s_xb0 = xb; s_xLen0 = xLen; s_T = 0; }   // thread 0 is always active
   __syncthreads();
@@ -441,9 +440,8 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   const uint32_t* __restrict__ xc0 = a.ctx + s_xb0;
   const int d0 = s_d0, xLen0 = s_xLen0;
   const uint32_t* __restrict__ yc = (comp ? a.ctxc : a.ctx) + yb;
-  uint32_t* __restrict__ tb = a.tb + tb_off;
   double M = QF_NEG_INF, colBest = QF_NEG_INF, rowBest = QF_NEG_INF;
-  uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0;
+  uint32_t colI = 0, rowJ = 0, gxPrev = 0, gyPrev = 0, startFlag = 0;
   const uint32_t srow = threadIdx.x >> 6, scol = threadIdx.x & 63;   // staging: one wavefront per row of the block
   // Software pipeline, one barrier per block: block g's rows are in registers (loaded during block g-1's arithmetic), go to
   // LDS buffer g & 1, and the loads of block g+1's rows are issued before block g's arithmetic; the x context word that
@@ -497,7 +495,6 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) ywNext[q] = *(const W4*)(yc + yi + 4 * q);
     }
-    uint32_t words[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int sub = 0; sub < 32 / kSingleSub; ++sub) {
       const int js = j0 + sub * kSingleSub;                 // first column of the block
@@ -536,7 +533,6 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
             const uint32_t ey = wyc[c] & 0x7FFFu;
             e[c] = shared_row ? rows[(size_t)c * KQ + ey] : mmi[(size_t)(xav[c] & 0x7FFFu) * KQ + ey];
           }
-          uint32_t nib = 0;
 #pragma unroll
           for (int c = 0; c < kSingleSub; ++c) {
             const int j = js + c, i = d + j;
@@ -545,30 +541,21 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
             gxPrev = xav[c] >> 24; gyPrev = wyc[c] >> 24;
             const double tM = (M + (GAPCTX ? gap[gxP * Kg + gyP] : gap0)) + e[c];
             double nm = tM;
-            uint32_t sm = 0;
-            if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; sm = 3; }
+            if ((j == 1 || i == 1) && e[c] > nm) { nm = e[c]; if (valid) startFlag = 3; }   // the band's first cell only
             if (!valid) nm = QF_NEG_INF;
             M = nm;
-            nib |= sm << (4 * c);
             if (valid && j == yLen && nm >= colBest) { colBest = nm; colI = (uint32_t)i; }
             if (valid && i == xLen && (nm > rowBest || (nm == rowBest && (uint32_t)j > rowJ))) { rowBest = nm; rowJ = (uint32_t)j; }
           }
-          if (kSingleSub == 8) words[sub] = nib; else words[sub >> 1] |= nib << (16 * (sub & 1));
         }
       }
-    }
-    // traceback words of columns j0 .. j0+31 (one per 8 columns, as k_overlap_single writes them); the unit's storage is
-    // (yLen + 7) / 8 words
-    if (active) {
-      const int w0 = (j0 - 1) >> 3, nw = (yLen + 7) >> 3;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if (w0 + q < nw) tb[w0 + q] = words[q];
     }
   }
   if (active) {
     Unit* u = &a.units[uid];
     u->end_val = colBest; u->end_i = colI;
     u->end2_val = rowBest; u->end2_j = rowJ;
+    u->tb_off = startFlag;   // the band's whole traceback (see k_overlap_single)
   }
 }
 
@@ -773,7 +760,7 @@ __global__ void k_overlap_traceback(OvArgs a) {
   const int xLenR = (int)(a.seq_off[px + 1] - a.seq_off[px]), yLenR = (int)(a.seq_off[py + 1] - a.seq_off[py]);
   const RowGeom rg = u.cls == (uint32_t)kRowClass ? row_geom(u.dlo, u.dhi, xLenR, yLenR) : RowGeom{0, 0, 0};
   auto cellbyte = [&](int i, int j) -> uint32_t {
-    if (u.cls == 0) return (tb[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 0x3u;  // single diagonal: match flags only
+    if (u.cls == 0) return (i == 1 || j == 1) ? (uint32_t)u.tb_off & 0x3u : 0u;  // single diagonal: the first cell's start flag is all there is
     if (u.cls == (uint32_t)kRowClass) {
       const int rr = i - rg.ilo, s = rr / kRowStripe, li = (rr % kRowStripe) / 8, b = rr % 8;
       int jlo, jhi;

@@ -145,7 +145,7 @@ def test_overlap_internal_chunking(ctx):
     ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
     whole = ctx.overlap_resident(pairs, Q.DPConfig(kmer_threshold=14))
     try:
-        ctx.set_memory_budget(whole["traceback_bytes"] // 6)
+        ctx.set_memory_budget(whole["traceback_bytes"] // 3)      # (no less than the largest pair's own bands)
         parts = ctx.overlap_resident(pairs, Q.DPConfig(kmer_threshold=14))
     finally:
         ctx.set_memory_budget(0)
