@@ -135,12 +135,19 @@ def pmc_for(workload, kernel_prefix):
     return None
 
 
+# Bytes a kernel that does not materialise the matrix still has to stream per cell: a single-diagonal overlap band
+# keeps no per-cell traceback and shares its x context and emission rows with its workgroup; what is its own is the 4-byte
+# context word of its y base.
+STREAM_BYTES_PER_CELL = {"overlap_single": 4.0}
+
+
 def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     """The roofline object of one kernel launch: `bound` says which roof `achieved / peak / frac` are quoted against; both
     views are spelled out beside it."""
     ops = F64_OPS_PER_CELL[kind]
     t = ms * 1e-3
     alg_gbs = BYTES_PER_CELL * cells / t / 1e9
+    stream_bpc = STREAM_BYTES_PER_CELL.get(kind)
     valu = ops * cells / t / 1e12
     pmc = pmc_for(workload, kernel.replace(" ", ""))
     if pmc and abs(pmc.get("cells_per_launch", 0) - cells) > 0.01 * cells:
@@ -150,6 +157,11 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     if bound == "fp64_valu":
         out.update(achieved=round(valu, 3), peak=F64_PEAK_TOPS, unit="TFLOP/s", frac=round(valu / F64_PEAK_TOPS, 4),
                    f64_ops_per_cell=ops)
+    elif stream_bpc:
+        gbs = stream_bpc * cells / t / 1e9
+        out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), bytes_per_cell=stream_bpc,
+                   note="bytes this kernel has to stream per cell (it materialises neither the matrix nor a traceback); the 24 B/cell "
+                        "of SURVEY 8(d) is under `hbm`")
     else:
         out.update(achieved=round(alg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_gbs / HBM_PEAK_GBS, 4),
                    bytes_per_cell=BYTES_PER_CELL)
