@@ -231,6 +231,13 @@ class Context:
         self.L.qf_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         self._chk(self.L.qf_debug_set_flags(self.h, flags))
 
+    def rows_settled(self):
+        """Tests only (csrc/qf_internal.h): pairs the overlap seeding's row prefilter settled in the last overlap call
+        (counted under debug flag 512)."""
+        self.L.qf_debug_rows_settled.argtypes = [C.c_void_p]
+        self.L.qf_debug_rows_settled.restype = C.c_uint64
+        return int(self.L.qf_debug_rows_settled(self.h))
+
     def lse_pack_bytes(self):
         """Tests only (csrc/qf_internal.h): bytes of the packed log-sum-exp table the overlap fills keep in LDS (0: not used)."""
         self.L.qf_debug_lse_pack_bytes.argtypes = [C.c_void_p]

@@ -199,6 +199,19 @@ struct qf_ctx : Slot {
   // stay valid while reads, parameters, null model and k are unchanged and no other entry point re-derives them
   uint64_t prep_epoch = 1, ov_prep_epoch = 0;
   int ov_prep_k = -1;
+  // row prefilter of the overlap seeding (qf_kernels.hip: k_seed_rows): runs (x, y0), (x, y0 + 1), ... of the current pair list
+  // and the k-mer index of chunks of 2^chunk_log2 consecutive sequences
+  struct PairRow { uint32_t x, y0, n, p0; };
+  std::vector<PairRow> ov_rows;
+  bool ov_use_rows = false;
+  DevBuf d_cstart, d_ccursor, d_centries, d_row_items, d_row_skip;
+  std::vector<PairRow> row_items_rows;   // the runs / block / chunk size d_row_items was built for
+  uint32_t row_items_lo = 0, row_items_hi = 0, row_items_n = 0;
+  int row_items_cl = -1;
+  uint64_t row_items_epoch = 0;
+  uint64_t rows_settled = 0;    // QF_DEBUG_COUNT_SETTLED: pairs the prefilter settled during the last qf_overlap_resident
+  uint64_t chunk_epoch = 0;
+  int chunk_k = -1, chunk_log2 = 0;
   HostBuf<double> h_ov_result, h_ov_score;
   std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
@@ -306,7 +319,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_lse_pack,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
@@ -1144,6 +1157,7 @@ uint32_t qf_debug_pack_lse_table(uint8_t* out, uint32_t cap) {
   if (out) memcpy(out, pack.data(), std::min<size_t>(cap, pack.size()));
   return (uint32_t)pack.size();
 }
+uint64_t qf_debug_rows_settled(const qf_ctx* c) { return c ? c->rows_settled : 0; }
 uint32_t qf_debug_lse_pack_bytes(qf_ctx* c) {
   if (!c || hipSetDevice(c->device) != hipSuccess || ensure_lse(c) != QF_OK) return 0;
   return c->lse_pack_bytes;
@@ -1679,9 +1693,71 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
 
   // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
   const int max_nd = (int)(2 * c->read_maxlen - 1);
+  uint32_t n_row_items = 0;
+  if (c->ov_use_rows) {
+    // This block's runs, cut at the chunk boundaries of the y index.  Order: every x of one chunk before the next chunk, and
+    // the list dealt out so that the workgroups of one chunk land on one XCD (workgroup ids go round the eight XCDs): the
+    // chunk's index (its bucket starts and entries, ~150 KB) is then fetched into that XCD's L2 once for all the x that walk
+    // it, instead of once per x from HBM (the index of a 100 k-sequence set is 900 MB).  The list depends only on the runs
+    // and the block, so a later call with the same pair list reuses the device copy.
+    const int cl = c->chunk_log2;
+    const bool cached = c->row_items_epoch == c->prep_epoch && c->row_items_lo == lo && c->row_items_hi == hi && c->row_items_cl == cl && c->row_items_rows.size() == c->ov_rows.size() &&
+                        !memcmp(c->row_items_rows.data(), c->ov_rows.data(), c->ov_rows.size() * sizeof(qf_ctx::PairRow));
+    if (!cached) {
+      const uint32_t n_chunks = (c->n_reads + (1u << cl) - 1) >> cl;
+      std::vector<uint32_t> first(n_chunks + 1, 0);
+      auto clip = [&](const qf_ctx::PairRow& r, uint32_t& y, uint32_t& yend, uint32_t& p) {
+        const uint64_t a0 = std::max<uint64_t>(r.p0, lo), a1 = std::min<uint64_t>((uint64_t)r.p0 + r.n, hi);
+        if (a0 >= a1) return false;
+        y = r.y0 + (uint32_t)(a0 - r.p0); yend = r.y0 + (uint32_t)(a1 - r.p0); p = (uint32_t)(a0 - lo);
+        return true;
+      };
+      uint32_t y, yend, p;
+      for (const auto& r : c->ov_rows)
+        if (clip(r, y, yend, p)) for (uint32_t ch = y >> cl; ch <= (yend - 1) >> cl; ++ch) ++first[ch + 1];
+      for (uint32_t ch = 0; ch < n_chunks; ++ch) first[ch + 1] += first[ch];
+      std::vector<RowItem> sorted(first[n_chunks]);
+      for (const auto& r : c->ov_rows)
+        if (clip(r, y, yend, p))
+          for (uint32_t yy = y; yy < yend;) {
+            const uint32_t ch = yy >> cl, stop = std::min<uint32_t>(yend, (ch + 1) << cl);
+            sorted[first[ch]++] = {r.x, ch, yy, stop, p + (yy - y)};
+            yy = stop;
+          }
+      // deal: segments of kSeg consecutive items go to XCD 0, 1, ... 7, 0, ...; workgroup b sits on XCD b % 8
+      constexpr uint32_t kSeg = 32, kXcd = 8;
+      const uint32_t n_items = (uint32_t)sorted.size(), n_seg = (n_items + kSeg - 1) / kSeg, seg_rounds = (n_seg + kXcd - 1) / kXcd;
+      std::vector<RowItem> items((size_t)seg_rounds * kXcd * kSeg, RowItem{~0u, 0, 0, 0, 0});
+      for (uint32_t k = 0; k < n_items; ++k) {
+        const uint32_t seg = k / kSeg, pos = k % kSeg;
+        items[((size_t)(seg / kXcd) * kSeg + pos) * kXcd + seg % kXcd] = sorted[k];
+      }
+      c->row_items_n = (uint32_t)items.size();
+      if (!items.empty()) {
+        HIPCHK(c, c->d_row_items.reserve(items.size() * sizeof(RowItem)));
+        HIPCHK(c, hipMemcpyAsync(c->d_row_items.p, items.data(), items.size() * sizeof(RowItem), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // `items` is a stack-lifetime host buffer
+      }
+      c->row_items_rows = c->ov_rows;
+      c->row_items_lo = lo; c->row_items_hi = hi; c->row_items_cl = cl; c->row_items_epoch = c->prep_epoch;
+    }
+    n_row_items = c->row_items_n;
+    if (n_row_items) {
+      HIPCHK(c, c->d_row_skip.reserve(n_pairs));
+      HIPCHK(c, hipMemsetAsync(c->d_row_skip.p, 0, n_pairs, c->stream));
+    }
+  }
   SeedArgs sa;
   BatchCounters bc;
   if (int rc = seed_pairs(c, c, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
+        if (n_row_items) {
+          s.row_items = c->d_row_items.as<RowItem>();
+          s.n_row_items = n_row_items;
+          s.chunk_start = c->d_cstart.as<uint32_t>();
+          s.chunk_entries = c->d_centries.as<uint32_t>();
+          s.chunk_log2 = c->chunk_log2;
+          s.row_skip = c->d_row_skip.as<uint8_t>();
+        }
         s.pair_x = c->d_px.as<uint32_t>() + lo;
         s.pair_y = c->d_py.as<uint32_t>() + lo;
         s.ref_off = c->d_roff.as<uint64_t>();
@@ -1694,6 +1770,11 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       }, max_units, sa, bc))
     return rc;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if ((c->debug & QF_DEBUG_COUNT_SETTLED) && n_row_items) {   // tests: how many pairs the row prefilter settled
+    std::vector<uint8_t> sk(n_pairs);
+    HIPCHK(c, hipMemcpy(sk.data(), c->d_row_skip.p, n_pairs, hipMemcpyDeviceToHost));
+    for (uint8_t v : sk) c->rows_settled += v;
+  }
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
   if (bc.error & 2u)
     return fail(c, QF_ERR_UNSUPPORTED, "unsupported overlap band of " + std::to_string(bc.error_detail) + " diagonals");
@@ -1872,9 +1953,13 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   if (n_pairs > kMaxPairsPerCall) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^28 pairs in one call");
   const uint32_t n_seqs = c->n_reads;
   bool need[2] = {false, false};
+  c->ov_rows.clear();
+  c->rows_settled = 0;
   for (uint32_t p = 0; p < n_pairs; ++p) {
     if (pair_x[p] >= n_seqs || pair_y[p] >= n_seqs) return fail(c, QF_ERR_ARG, "pair index out of range");
     need[y_comp[p] ? 1 : 0] = true;
+    if (!c->ov_rows.empty() && c->ov_rows.back().x == pair_x[p] && c->ov_rows.back().y0 + c->ov_rows.back().n == pair_y[p]) ++c->ov_rows.back().n;
+    else c->ov_rows.push_back({pair_x[p], pair_y[p], 1u, p});
   }
   const bool sparse = cfg->sparse != 0;
   if (int rc = ensure_lse(c)) return rc;
@@ -1925,6 +2010,36 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   }
   c->ov_prep_epoch = c->prep_epoch;   // (only once the symbols have been checked)
   c->ov_prep_k = prep_k;
+  // Row prefilter: worth it when the list is the scheduler's (x-major, runs of consecutive y: src/qoverlap.cpp:528-547)
+  c->ov_use_rows = false;
+  if (sparse && cfg->kmer_threshold >= 0 && cfg->kmer_len <= kMaxRefK && !(c->debug & QF_DEBUG_NO_ROW_PREFILTER) &&
+      (uint64_t)c->ov_rows.size() * 32 <= n_pairs) {
+    SeedArgs t;
+    fill_seed_args(c, *c, cfg, t, 0, (int)(2 * c->read_maxlen - 1));
+    t.max_ref_len = t.max_read_len;
+    t.ref_skeys = nullptr;
+    const size_t stride = seed_row_stride_bytes(t);
+    int cl = 6;
+    while (stride && cl > 3 && (stride << cl) > 64 * 1024) --cl;
+    if (stride && (stride << cl) <= 64 * 1024) {
+      if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl) {
+        const uint32_t nb = 1u << (2 * cfg->kmer_len), n_chunks = (n_seqs + (1u << cl) - 1) >> cl;
+        const size_t bytes = (size_t)n_chunks * (nb + 1) * 4;
+        HIPCHK(c, c->d_cstart.reserve(bytes));
+        HIPCHK(c, c->d_ccursor.reserve(bytes));
+        HIPCHK(c, c->d_centries.reserve((c->read_total + 16) * 4));
+        HIPCHK(c, hipMemsetAsync(c->d_cstart.p, 0, bytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ccursor.p, 0, bytes, c->stream));
+        launch_chunk_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len, nb, cl,
+                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), c->stream);
+        HIPCHK(c, hipGetLastError());
+        c->chunk_epoch = c->prep_epoch;
+        c->chunk_k = cfg->kmer_len;
+        c->chunk_log2 = cl;
+      }
+      c->ov_use_rows = true;
+    }
+  }
   (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
   out->ms_total = out->ms_prep;
   c->h_ov_result.resize(n_pairs);

@@ -18,7 +18,9 @@ enum qf_debug_flag {
   QF_DEBUG_GLOBAL_INDEX = 16u,        /* reference k-mer index stays in global memory */
   QF_DEBUG_GLOBAL_OVERLAP_ROWS = 32u, /* overlap single-diagonal bands gather their emissions from global memory */
   QF_DEBUG_NO_BAND_SHORTCUTS = 64u,   /* E-step without the single-diagonal Forward kernel / negligible-band skip */
-  QF_DEBUG_GLOBAL_LSE = 128u          /* overlap fills gather the exact log-sum-exp table from global memory, not its packed form in LDS */
+  QF_DEBUG_GLOBAL_LSE = 128u,         /* overlap fills gather the exact log-sum-exp table from global memory, not its packed form in LDS */
+  QF_DEBUG_NO_ROW_PREFILTER = 256u,   /* overlap seeding: every pair through the per-pair kernel (no chunk-of-y prefilter) */
+  QF_DEBUG_COUNT_SETTLED = 512u       /* overlap: count the pairs the prefilter settles (qf_debug_rows_settled; costs a read-back) */
 };
 int qf_debug_set_flags(qf_ctx *ctx, uint32_t flags);
 /* The exact log-sum-exp table packed for LDS (qf_device.hpp: kLsePack*), built on the host:
@@ -27,6 +29,9 @@ uint32_t qf_debug_pack_lse_table(uint8_t *out, uint32_t cap);
 /* Bytes of the packed table this context's overlap fills keep in LDS; 0 if the device did not rebuild the table from it bit for
  * bit (the fills then gather the table from global memory). */
 uint32_t qf_debug_lse_pack_bytes(qf_ctx *ctx);
+/* Pairs of the last qf_overlap_resident call that the seeding's row prefilter settled (given their single forced diagonal without
+ * the per-pair kernel); counted only under QF_DEBUG_COUNT_SETTLED. */
+uint64_t qf_debug_rows_settled(const qf_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -839,6 +839,116 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_
   }
 }
 
+// Row prefilter for explicit pair lists (read-vs-read overlap).  The scheduler's list is x-major (src/qoverlap.cpp:528-547):
+// long runs (x, y0), (x, y0 + 1), ...  Nearly all of those pairs are unrelated reads whose only envelope diagonal is the
+// forced one (diagenv.cpp:52-54), and finding that out one pair per wavefront is what the seeding spends its time on: a
+// read position meets 0.5 k-mer matches in the other read, so most lanes of every counting instruction are idle.  Here one
+// workgroup takes x against a whole chunk of 2^cl consecutive y at once: the chunk has its own k-mer index (built once per
+// upload: launch_chunk_index), an x position meets ~30 matches in it, and the lanes walk those lists into per-y coarse
+// counters in LDS (the coarse pass of seed_wave_pair for 2^cl pairs).  A pair none of whose coarse bins reaches the threshold
+// has no diagonal that does: it gets its one band (diagonal 0) here and is marked in row_skip; the others go through the
+// per-pair kernels as before, which skip the marked ones.
+// Sixteen wavefronts per workgroup: a position's three dependent loads (its k-mer, the bucket, the bucket's entries four at a
+// time) are all the latency there is to hide, and the counters take 64 KB of LDS whatever the workgroup's size.
+constexpr int kSeedRowThreads = 1024;
+template <int CB>
+__global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint32_t stride) {
+  extern __shared__ uint32_t cnt[];   // [2^cl][stride]: two 16-bit coarse counters per word
+  const RowItem it = a.row_items[blockIdx.x];
+  if (it.x == ~0u) return;   // padding of the dealt-out list
+  const int cl = a.chunk_log2, k = a.kmer_len;
+  const uint32_t tid = threadIdx.x, csize = 1u << cl;
+  for (uint32_t w = tid; w < csize * stride; w += kSeedRowThreads) cnt[w] = 0;
+  __syncthreads();
+  const uint64_t xb = a.ref_off[it.x];
+  const int xLen = (int)(a.ref_off[it.x + 1] - xb), nkx = xLen - k + 1;
+  const uint32_t* __restrict__ cs = a.chunk_start + (uint64_t)it.chunk * (a.nbuckets + 1);
+  const uint32_t* __restrict__ ce = a.chunk_entries + a.read_off[(uint64_t)it.chunk << cl];
+  const uint32_t* __restrict__ xk = a.skmer + xb;
+  const uint32_t y0 = it.chunk << cl, yylo = it.ylo - y0, yyhi = it.yhi - y0;
+  auto count = [&](uint32_t i, uint32_t ent) {
+    const uint32_t yy = ent >> 26;
+    if (yy < yylo || yy >= yyhi) return;
+    const uint32_t cbin = (i + (ent & 0x3FFFFFFu)) >> CB;   // bin = i - j + yLen - 1 (diagenv.cpp:33-40)
+    atomicAdd(&cnt[yy * stride + (cbin >> 1)], 1u << (16 * (cbin & 1)));
+  };
+  // two positions per thread and round, their buckets' first kRowBatch x 4 entries fetched as one batch of independent loads
+  constexpr int kRowPos = 2, kRowBatch = 5;
+  for (int i0 = (int)tid; i0 < nkx; i0 += kRowPos * kSeedRowThreads) {
+    uint32_t km[kRowPos], sq[kRowPos], eq[kRowPos];
+#pragma unroll
+    for (int c = 0; c < kRowPos; ++c) km[c] = i0 + c * kSeedRowThreads < nkx ? xk[i0 + c * kSeedRowThreads] : 0u;
+#pragma unroll
+    for (int c = 0; c < kRowPos; ++c) {
+      sq[c] = cs[km[c]];
+      eq[c] = i0 + c * kSeedRowThreads < nkx ? cs[km[c] + 1] : sq[c];
+    }
+    W4a v[kRowPos][kRowBatch];
+#pragma unroll
+    for (int c = 0; c < kRowPos; ++c)
+#pragma unroll
+      for (int b = 0; b < kRowBatch; ++b)
+        if (sq[c] + 4 * b < eq[c]) v[c][b] = *(const W4a*)(ce + sq[c] + 4 * b);   // (the entry array has 16 words of slack)
+#pragma unroll
+    for (int c = 0; c < kRowPos; ++c) {
+      const uint32_t i = (uint32_t)(i0 + c * kSeedRowThreads);
+#pragma unroll
+      for (int b = 0; b < kRowBatch; ++b)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if (sq[c] + 4 * b + w < eq[c]) count(i, v[c][b].v[w]);
+      for (uint32_t q = sq[c] + 4 * kRowBatch; q < eq[c]; ++q) count(i, ce[q]);   // longer buckets: rare
+    }
+  }
+  __syncthreads();
+  const uint32_t thr = a.threshold > 1 ? (uint32_t)a.threshold : 1u, minLen = 2u * (uint32_t)(k + a.threshold);
+  const uint32_t lane = tid & 63;
+  for (uint32_t yy = yylo + (tid >> 6); yy < yyhi; yy += kSeedRowThreads / 64) {   // one wavefront per y
+    const uint32_t y = y0 + yy;
+    const int yLen = (int)(a.read_off[y + 1] - a.read_off[y]);
+    const uint32_t nwords = (uint32_t)((((xLen + yLen - 1 + (1 << CB) - 1) >> CB) + 1) / 2);
+    bool hit = false;
+    for (uint32_t w = lane; w < nwords; w += 64) {
+      const uint32_t v = cnt[yy * stride + w];
+      hit |= (v & 0xFFFFu) >= thr || (v >> 16) >= thr;
+    }
+    // (sequences shorter than 2 (k + threshold) take the full envelope, diagenv.cpp:23-29: left to the per-pair kernel)
+    const bool cand = __any(hit) || (uint32_t)xLen < minLen || (uint32_t)yLen < minLen;
+    if (lane == 0) {
+      const uint32_t p = it.pbase + (y - it.ylo);
+      if (!cand) {
+        record_band(a, a.pair_base + p, 0, 0);
+        a.pair_ndiag[a.pair_base + p] = 1;
+      }
+      a.row_skip[p] = cand ? 0 : 1;
+    }
+  }
+}
+
+__global__ void k_chunk_kmer_count(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k, uint32_t nbuckets,
+                                   int cl, uint32_t* __restrict__ counts) {
+  const uint32_t x = blockIdx.y;
+  const uint64_t b = off[x], len = off[x + 1] - b;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (len < k || i > len - k) return;
+  uint32_t km = 0;
+  for (uint32_t c = 0; c < k; ++c) km = km * 4 + tok[b + i + c];
+  atomicAdd(&counts[(uint64_t)(x >> cl) * (nbuckets + 1) + km], 1u);
+}
+__global__ void k_chunk_kmer_scatter(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k, uint32_t nbuckets,
+                                     int cl, const uint32_t* __restrict__ starts, uint32_t* __restrict__ cursor,
+                                     uint32_t* __restrict__ entries) {
+  const uint32_t x = blockIdx.y;
+  const uint64_t b = off[x], len = off[x + 1] - b;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (len < k || i > len - k) return;
+  uint32_t km = 0;
+  for (uint32_t c = 0; c < k; ++c) km = km * 4 + tok[b + i + c];
+  const uint64_t bi = (uint64_t)(x >> cl) * (nbuckets + 1) + km;
+  const uint32_t slot = starts[bi] + atomicAdd(&cursor[bi], 1u);
+  entries[off[(uint64_t)(x >> cl) << cl] + slot] = ((x & ((1u << cl) - 1)) << 26) | (uint32_t)(len - 1 - i);
+}
+
 // Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
 // (pair, band slot); one global atomic per workgroup and counter.
 __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs, uint32_t n_ovf) {
@@ -1848,6 +1958,14 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
   hipLaunchKernelGGL(k_bucket_scan, dim3(n_refs), dim3(1024), 0, s, starts, nbuckets);
   hipLaunchKernelGGL(k_ref_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, starts, cursor, pos);
 }
+void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, hipStream_t s) {
+  const dim3 grid((uint32_t)((max_len + 255) / 256), n_seqs);
+  const uint32_t n_chunks = (n_seqs + (1u << chunk_log2) - 1) >> chunk_log2;
+  hipLaunchKernelGGL(k_chunk_kmer_count, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(n_chunks), dim3(1024), 0, s, starts, nbuckets);
+  hipLaunchKernelGGL(k_chunk_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts, cursor, entries);
+}
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;
   if (a.skmer64) hipLaunchKernelGGL(k_prep_reads2<true>, dim3(n_reads), dim3(64), 0, s, a);
@@ -1882,6 +2000,15 @@ static uint32_t seed_wave_words(const SeedArgs& a, int cb, bool& wide) {
   wide = ((uint64_t)a.max_read_len << cb) >= 65280u;
   return (wide ? nc + 2 : (nc + 1) / 2 + 1) + (nb + 1) + 32 * 16 + 40;
 }
+// The prefilter's coarse bins are half as wide as the per-pair kernel's: k-mer matches come in runs (a chance 8-mer is three
+// of them on one diagonal), and with bins of 8 diagonals 17 % of unrelated 2 kb read pairs still had a bin at the threshold.
+static int seed_row_bits(const SeedArgs& a) { return seed_coarse_bits(a) - 1; }
+size_t seed_row_stride_bytes(const SeedArgs& a) {
+  if (!a.sparse || a.threshold < 0 || !a.nbuckets || a.ref_skeys || a.dump_cover || a.force_block_kernel || seed_needs_deep_counters(a)) return 0;
+  const int cb = seed_row_bits(a);
+  if (((uint64_t)a.max_read_len << cb) >= 65280u || a.max_read_len >= (1u << 26)) return 0;   // 16-bit coarse counters, 26-bit positions
+  return (size_t)((((a.max_nd + (1 << cb) - 1) >> cb) + 1) / 2 + 1) * 4;
+}
 bool seed_needs_workspace(const SeedArgs& a, bool mem) {
   if (!a.sparse) return false;
   if (seed_needs_deep_counters(a)) return true;
@@ -1903,8 +2030,20 @@ void with_seed_variant(bool wide, int cb, F&& f) {   // f(std::bool_constant<WID
   if (wide) pick(std::true_type()); else pick(std::false_type());
 }
 }  // namespace
-int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s) {
+int launch_seed(const SeedArgs& a_in, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
+  SeedArgs a = a_in;
+  if (a.row_items && a.n_row_items && !mem) {   // settle the pairs with nothing but the forced diagonal a chunk of y at a time
+    const size_t stride = seed_row_stride_bytes(a);
+    const size_t lds = stride << a.chunk_log2;
+    if (stride && lds <= 64 * 1024) {
+      const int cb = seed_row_bits(a);
+      auto fn = cb == 4 ? k_seed_rows<4> : cb == 3 ? k_seed_rows<3> : k_seed_rows<2>;
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(fn, dim3(a.n_row_items), dim3(kSeedRowThreads), lds, s, a, (uint32_t)(stride / 4));
+      a.pair_skip = a.row_skip;
+    }
+  }
   if (seed_needs_deep_counters(a)) {  // 65 536+ matches on one diagonal are possible: 32-bit counters, global workspaces
     if (!a.ws || !a.ws_slots || a.ws_words * 4 < seed_lds_bytes(a.max_nd, mem, true)) return -1;
     const uint32_t grid = n_pairs < a.ws_slots ? n_pairs : a.ws_slots;

@@ -34,6 +34,8 @@ struct PrepArgs {
   BatchCounters* bc;
 };
 
+struct RowItem { uint32_t x, chunk, ylo, yhi, pbase; };   // pairs (x, y) for y in [ylo, yhi), all inside one chunk; pair index of ylo
+
 struct SeedArgs {
   uint32_t pair_base, n_refs;
   const uint32_t* pair_x;      // optional explicit pair list (overlap): x / y sequence of each pair
@@ -69,6 +71,13 @@ struct SeedArgs {
   int few_hits;                // a read k-mer is expected less than once in an x-sequence (longest x / 4^k < 1): seeding prefetches two bucket entries, not four
   int no_lds_index;            // 1: never copy the reference index to LDS (debug / A-B)
   const uint8_t* pair_skip;    // optional [n_pairs]: 1 = do not seed this pair (train: pruned references)
+  // row prefilter (explicit pair lists made of long runs x, y0, y0 + 1, ...: qf_kernels.hip, k_seed_rows)
+  const RowItem* row_items;    // optional
+  uint32_t n_row_items;
+  const uint32_t* chunk_start; // [n_chunks][nbuckets + 1] bucket starts of each chunk of 2^chunk_log2 consecutive sequences
+  const uint32_t* chunk_entries; // per chunk, from position read_off[first sequence of the chunk]: (sequence in chunk) << 26 | (len - 1 - j)
+  int chunk_log2;
+  uint8_t* row_skip;           // [n_pairs], zero-initialised: set for the pairs the prefilter settled
   int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
   int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
   BatchCounters* bc;
@@ -237,6 +246,11 @@ int sort_kmer_index(const uint8_t* tok, const uint64_t* d_off, const int* d_off3
                     uint64_t max_len, uint32_t k, unsigned long long* keys_tmp, uint32_t* vals_tmp,
                     unsigned long long* keys_out, uint32_t* pos_out, void** temp, size_t* temp_cap, hipStream_t s);
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s);
+// k-mer index of chunks of 2^chunk_log2 consecutive sequences (row prefilter of the overlap seeding)
+void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, hipStream_t s);
+// LDS bytes per sequence of a chunk in the row prefilter (coarse counters of one pair), or 0 if the prefilter does not apply
+size_t seed_row_stride_bytes(const SeedArgs& a);
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);
 // entries of the exact log-sum-exp table that its packed form (qf_device.hpp) does not reproduce on this device; ~0u on a HIP error
 uint32_t lse_pack_mismatches(const uint8_t* pack, uint32_t pack_bytes, const double* tab, uint32_t* d_bad, hipStream_t s);

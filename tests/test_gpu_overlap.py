@@ -94,6 +94,29 @@ def test_overlap_packed_lse_table_in_lds_and_global_table_agree(ctx):
         assert np.array_equal(a["viterbi"], b["viterbi"]) and (a["n_diagonals"] > 60).sum() >= 6
 
 
+def test_overlap_row_prefilter_settles_unrelated_pairs(ctx):
+    """The scheduler's pair list is long runs (x, y0), (x, y0 + 1), ...: the seeding takes x against 8 - 64 consecutive y at a
+    time (coarse k-mer-match counters per y in LDS) and gives every pair without a candidate bin its one forced diagonal
+    there; only the rest go through the per-pair kernel.  Same results as the oracle and as the per-pair kernel alone, and
+    most pairs of a set with few true overlaps are settled by the prefilter."""
+    rng = np.random.default_rng(142)
+    reads = overlapping_reads(rng, 9000, 36, 300)            # 72 sequences, rows of ~70 pairs; few of the pairs overlap
+    try:
+        ctx.set_debug_flags(512)                                 # QF_DEBUG_COUNT_SETTLED
+        a, nfinite = check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
+        settled = ctx.rows_settled()
+        ctx.set_debug_flags(256 | 512)                           # QF_DEBUG_NO_ROW_PREFILTER
+        b, _ = check_overlap(ctx, reads, DEFAULT_JSON, dict(kmer_threshold=14))
+        assert ctx.rows_settled() == 0
+    finally:
+        ctx.set_debug_flags(0)
+    n_pairs = len(O.overlap_task_pairs(36, 72))
+    assert nfinite == n_pairs and settled > 0.7 * n_pairs and (a["n_diagonals"] == 1).sum() >= settled
+    for key in ("viterbi", "cells", "n_diagonals"):
+        assert np.array_equal(a[key], b[key]), key
+    assert (a["n_diagonals"] > 60).sum() >= 4                  # and the true overlaps kept their bands
+
+
 def test_overlap_bands_and_thresholds(ctx):
     rng = np.random.default_rng(42)
     reads = overlapping_reads(rng, 900, 6, 350)
