@@ -180,6 +180,16 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     return out
 
 
+def run_in_flight(job, k):
+    """k steps of `job` over its contexts, one host thread per context: the thread of context i runs its share of the steps one
+    after another (a context is not re-entrant), the contexts' calls overlap on the device."""
+    n = len(job.ctxs)
+    share = [k // n + (1 if (i - job.turn) % n < k % n else 0) for i in range(n)]
+    job.turn += k
+    futs = [job.pool.submit(lambda c=job.ctxs[i], m=share[i]: sum(job.step(c) for _ in range(m))) for i in range(n) if share[i]]
+    return sum(f.result() for f in futs)
+
+
 class Job:
     """One workload on one rank.  setup() leaves everything resident; step() runs the hot path once and returns the cells
     it processed; finish() (rank 0, after the timed region) builds the roofline and the CPU-baseline / parity leg."""
@@ -242,9 +252,7 @@ class AlignJob(Job):
         its results on the host; the calls of different contexts overlap on the device)."""
         if len(self.ctxs) == 1:
             return sum(self.step() for _ in range(k))
-        futs = [self.pool.submit(self.step, self.ctxs[(self.turn + s) % len(self.ctxs)]) for s in range(k)]
-        self.turn += k
-        return sum(f.result() for f in futs)
+        return run_in_flight(self, k)
 
     def step(self, ctx=None):
         res = (ctx or self.ctx).align_resident(self.cfg, self.a.align_flags, raw=True)   # synchronous: returns with the results on the host
@@ -579,9 +587,7 @@ class OverlapJob(Job):
         """k steps, len(self.ctxs) of them in flight (step s on context s mod n; see AlignJob.run_steps)."""
         if len(self.ctxs) == 1:
             return sum(self.step() for _ in range(k))
-        futs = [self.pool.submit(self.step, self.ctxs[(self.turn + s) % len(self.ctxs)]) for s in range(k)]
-        self.turn += k
-        return sum(f.result() for f in futs)
+        return run_in_flight(self, k)
 
     def step(self, ctx=None):
         res = (ctx or self.ctx).overlap_resident(self.pairs, self.cfg, raw=True)

@@ -24,7 +24,7 @@ from collections import defaultdict
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)   # (gpurun merges: older runs' files stay)
     return hits[-1] if hits else None
 
 
