@@ -204,7 +204,7 @@ struct qf_ctx : Slot {
   struct PairRow { uint32_t x, y0, n, p0; };
   std::vector<PairRow> ov_rows;
   bool ov_use_rows = false;
-  DevBuf d_cstart, d_ccursor, d_centries, d_row_items, d_row_skip;
+  DevBuf d_cstart, d_ccursor, d_centries, d_row_items, d_row_skip, d_slot_list;
   std::vector<PairRow> row_items_rows;   // the runs / block / chunk size d_row_items was built for
   uint32_t row_items_lo = 0, row_items_hi = 0, row_items_n = 0;
   int row_items_cl = -1;
@@ -319,7 +319,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
@@ -721,12 +721,13 @@ static int reserve_seed_workspace(Slot* c, SeedArgs& sa, bool mem, uint64_t n_pa
 
 // Ragged read lengths: a wavefront's bands run in lockstep for as long as the longest of them, so each class list is sorted
 // by read length (longest first) before the fills.
-static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_t max_units, bool pair_order_cls0 = false) {
+static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_t max_units, bool pair_order_cls0 = false,
+                            bool slotted_cls0 = false) {
   if (!c->ragged_reads && !pair_order_cls0) return QF_OK;
   HIPCHK(S, S->d_sort_k.reserve((size_t)max_units * 4));
   HIPCHK(S, S->d_sort_v.reserve((size_t)max_units * 4));
   for (int cls = 0; cls < kNumClasses; ++cls) {
-    if (cls == kRowClass || bc.cls_count[cls] <= 64) continue;
+    if (cls == kRowClass || bc.cls_count[cls] <= 64 || (cls == 0 && slotted_cls0)) continue;
     (void)0;   // (overlap sorts every list: bands by the columns they cross, the single-diagonal list into pair order)
     const int rc = sort_class_list(S->d_cls_key.as<uint32_t>() + (size_t)cls * max_units, S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units,
                                    bc.cls_count[cls], S->d_sort_k.as<uint32_t>(), S->d_sort_v.as<uint32_t>(), &S->sort_tmp, &S->sort_tmp_cap,
@@ -1747,9 +1748,35 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       HIPCHK(c, hipMemsetAsync(c->d_row_skip.p, 0, n_pairs, c->stream));
     }
   }
+  // Slotted single-diagonal list: x rows x0, x0 + 1, ... (the scheduler's order), at most one single-diagonal band per pair
+  // (bands are at least 2 wide otherwise) and the staging kernel applies.
+  uint32_t slot_rows = 0, slot_x0 = 0, slot_ychunks = 0;
+  if (c->ov_use_rows && cfg->band_size >= 2 && overlap_single_stages_rows(sc.Km) && !(c->debug & (QF_DEBUG_GLOBAL_OVERLAP_ROWS | QF_DEBUG_PAIR_ORDER_SINGLES))) {
+    bool ok = true;
+    uint32_t xa = 0, xb = 0, first = 1;
+    for (const auto& r : c->ov_rows) {
+      if ((uint64_t)r.p0 + r.n <= lo || r.p0 >= hi) continue;
+      if (first) { xa = xb = r.x; first = 0; }
+      else if (r.x == xb + 1) xb = r.x;
+      else { ok = false; break; }
+    }
+    slot_ychunks = (c->n_reads + 255) / 256;
+    if (ok && !first && (uint64_t)(xb - xa + 1) * slot_ychunks * 256 <= (1ull << 28)) {
+      slot_rows = xb - xa + 1;
+      slot_x0 = xa;
+      const size_t bytes = (size_t)slot_rows * slot_ychunks * 256 * 4;
+      HIPCHK(c, c->d_slot_list.reserve(bytes));
+      HIPCHK(c, hipMemsetAsync(c->d_slot_list.p, 0xFF, bytes, c->stream));
+    }
+  }
   SeedArgs sa;
   BatchCounters bc;
   if (int rc = seed_pairs(c, c, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
+        if (slot_rows) {
+          s.slot_list = c->d_slot_list.as<uint32_t>();
+          s.slot_x0 = slot_x0;
+          s.slot_rows = slot_rows;
+        }
         if (n_row_items) {
           s.row_items = c->d_row_items.as<RowItem>();
           s.n_row_items = n_row_items;
@@ -1791,7 +1818,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     *too_big = true;
     return QF_OK;
   }
-  if (int rc = sort_class_lists(c, c, bc, max_units, true)) return rc;
+  if (int rc = sort_class_lists(c, c, bc, max_units, true, slot_rows != 0)) return rc;
   HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
   HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));
@@ -1811,6 +1838,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.gap[1] = c->d_gap1.as<double>();
   if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
+  if (slot_rows) { oa.slot_list = c->d_slot_list.as<uint32_t>(); oa.slot_rows = slot_rows; oa.slot_ychunks = slot_ychunks; }
   oa.lse = c->d_lse.as<double>();
   if (c->lse_pack_bytes && !(c->debug & QF_DEBUG_GLOBAL_LSE)) { oa.lse_pack = c->d_lse_pack.as<uint8_t>(); oa.lse_pack_bytes = c->lse_pack_bytes; }
   oa.min_score = c->min_score;

@@ -1030,7 +1030,11 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
     atomicOr(&a.bc->error, 1u);
     return;
   }
-  a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
+  if (a.slot_list && cls == 0) {   // overlap: single-diagonal bands by (y chunk, x row, y), so that a workgroup is one x against 256 consecutive y
+    const uint32_t x = a.pair_x[pair], y = a.pair_y[pair];
+    a.slot_list[((uint64_t)(y >> 8) * a.slot_rows + (x - a.slot_x0)) * 256 + (y & 255u)] = uid;
+  } else
+    a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
   // sort key of the class lists (descending): read length = steps of the fill; overlap: the columns the band crosses, and its
   // single-diagonal list is put back into pair order instead, so that the bands of a workgroup share their x (k_overlap_single_lds)
   if (a.cls_key)

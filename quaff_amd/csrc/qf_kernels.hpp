@@ -78,6 +78,10 @@ struct SeedArgs {
   const uint32_t* chunk_entries; // per chunk, from position read_off[first sequence of the chunk]: (sequence in chunk) << 26 | (len - 1 - j)
   int chunk_log2;
   uint8_t* row_skip;           // [n_pairs], zero-initialised: set for the pairs the prefilter settled
+  // slotted single-diagonal list (overlap, x-major lists with consecutive x): unit of pair (x, y) at
+  // slot_list[((y >> 8) * slot_rows + (x - slot_x0)) * 256 + (y & 255)], holes = ~0u (kNoUnit)
+  uint32_t* slot_list;         // optional, ~0u-initialised
+  uint32_t slot_x0, slot_rows;
   int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
   int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
   BatchCounters* bc;
@@ -151,6 +155,8 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   double min_score;         // alignments scoring below it are neither traced back nor returned (-inf: keep all)
   int no_lds_rows;          // A/B: single-diagonal bands gather their emissions from global memory (k_overlap_single)
   const double* gap[2];
+  const uint32_t* slot_list;  // single-diagonal bands by (y chunk, x row, y) instead of cls_list (SeedArgs::slot_list)
+  uint32_t slot_rows, slot_ychunks;
   const double* lse;
   const uint8_t* lse_pack;  // the same table packed for LDS (qf_device.hpp: kLsePack*) (null: not available)
   uint32_t lse_pack_bytes;
@@ -252,6 +258,7 @@ void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs
 // LDS bytes per sequence of a chunk in the row prefilter (coarse counters of one pair), or 0 if the prefilter does not apply
 size_t seed_row_stride_bytes(const SeedArgs& a);
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);
+bool overlap_single_stages_rows(uint32_t Km);   // the single-diagonal kernel that stages emission rows through LDS applies
 // entries of the exact log-sum-exp table that its packed form (qf_device.hpp) does not reproduce on this device; ~0u on a HIP error
 uint32_t lse_pack_mismatches(const uint8_t* pack, uint32_t pack_bytes, const double* tab, uint32_t* d_bad, hipStream_t s);
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s);

@@ -409,14 +409,29 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
   extern __shared__ double s_rows[];   // [2][kSingleSub][KQ]
   __shared__ unsigned long long s_xb0;
   __shared__ int s_d0, s_xLen0, s_T;
-  __shared__ uint32_t s_x0, s_comp0;
-  const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = uidx < a.n_cls_units;
-  uint32_t uid = 0, comp = 0, x = 0;
+  __shared__ uint32_t s_x0, s_comp0, s_first;
+  // Which band is this lane's?  Plain list: 256 consecutive entries.  Slotted list (SeedArgs::slot_list): workgroup b takes y
+  // chunk (b / 8 / rows) * 8 + b % 8 and x row (b / 8) % rows -- the workgroups of one y chunk, one per x row, follow each
+  // other on one XCD (workgroup ids go round the eight XCDs), so the chunk's context words (2 MB for 256 sequences of 2 kb)
+  // come from that XCD's L2 for every x but the first instead of from HBM once per x.
+  uint32_t uid = ~0u;
+  if (a.slot_list) {
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, chunk = (slot / a.slot_rows) * 8 + xcd, row = slot % a.slot_rows;
+    if (chunk < a.slot_ychunks) uid = a.slot_list[((uint64_t)chunk * a.slot_rows + row) * 256 + threadIdx.x];
+  } else {
+    const uint32_t uidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (uidx < a.n_cls_units) uid = a.cls_list[uidx];
+  }
+  const bool active = uid != ~0u;
+  if (threadIdx.x == 0) { s_first = 256; s_T = 0; }
+  __syncthreads();
+  if (active) atomicMin(&s_first, threadIdx.x);
+  __syncthreads();
+  if (s_first == 256) return;                              // an empty slot group (below the diagonal of the pair triangle)
+  uint32_t comp = 0, x = 0;
   int d = 0, xLen = 0, yLen = 0;
   uint64_t xb = 0, yb = 0;
   if (active) {
-    uid = a.cls_list[uidx];
     const Unit u = a.units[uid];
     x = a.pair_x[u.pair];
     const uint32_t y = a.pair_y[u.pair];
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
     yb = a.seq_off[y]; yLen = (int)(a.seq_off[y + 1] - yb);
     d = u.dlo;
   }
-  if (threadIdx.x == 0) { s_x0 = x; s_comp0 = comp; s_d0 = d; s_xb0 = xb; s_xLen0 = xLen; s_T = 0; }   // thread 0 is always active
+  if (threadIdx.x == s_first) { s_x0 = x; s_comp0 = comp; s_d0 = d; s_xb0 = xb; s_xLen0 = xLen; }   // the group's first band sets the shared rows
   __syncthreads();
   atomicMax(&s_T, active ? yLen : 0);
   __syncthreads();
@@ -833,7 +848,8 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
       if (row_lds <= 64 * 1024 && !a.no_lds_rows) {
         auto fn = a.Kg > 1 ? k_overlap_single_lds<true> : k_overlap_single_lds<false>;
         if (row_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
-        hipLaunchKernelGGL(fn, dim3((a.n_cls_units + 255) / 256), dim3(256), row_lds, s, a);
+        const uint32_t blocks = a.slot_list ? ((a.slot_ychunks + 7) / 8) * 8 * a.slot_rows : (a.n_cls_units + 255) / 256;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), row_lds, s, a);
       } else
         hipLaunchKernelGGL(k_overlap_single, dim3((a.n_cls_units + 255) / 256), dim3(256), 0, s, a);
       break;
@@ -851,6 +867,7 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
     case 13: hipLaunchKernelGGL(k_overlap_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); break;
   }
 }
+bool overlap_single_stages_rows(uint32_t Km) { return 2ull * kSingleSub * Km * (kNQualDev + 1) * 8 <= 64 * 1024; }
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_prep_overlap, dim3(n), dim3(64), 0, s, a);
