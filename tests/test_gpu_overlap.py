@@ -117,6 +117,49 @@ def test_overlap_row_prefilter_settles_unrelated_pairs(ctx):
     assert (a["n_diagonals"] > 60).sum() >= 4                  # and the true overlaps kept their bands
 
 
+def test_overlap_row_structures_survive_block_splits_and_other_orders(ctx):
+    """The row prefilter's work list and the slotted single-diagonal list are built per internal block of the pair list: a
+    memory budget that forces the call to run in pieces (blocks that start and end in the middle of an x row), a pair list in
+    another order (no runs: everything through the per-pair kernel and the plain list) and a narrow band (several
+    single-diagonal bands per pair: plain list) all give the whole call's results."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(143)
+    reads = overlapping_reads(rng, 4000, 40, 260)
+    seqs = reads + [r.revcomp() for r in reads]
+    pairs = O.overlap_task_pairs(40, 80)
+    ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    cfg = Q.DPConfig(kmer_threshold=14)
+    try:
+        ctx.set_debug_flags(512)
+        whole = ctx.overlap_resident(pairs, cfg)
+        assert ctx.rows_settled() > len(pairs) // 2
+        ctx.set_memory_budget(whole["traceback_bytes"] // 5)
+        parts = ctx.overlap_resident(pairs, cfg)
+        assert ctx.rows_settled() > len(pairs) // 2
+    finally:
+        ctx.set_memory_budget(0)
+        ctx.set_debug_flags(0)
+    order = rng.permutation(len(pairs))
+    shuffled = ctx.overlap_resident([pairs[k] for k in order], cfg)
+
+    def same(a, b, index=None):
+        index = np.arange(len(pairs)) if index is None else index
+        for key in ("viterbi", "cells", "n_diagonals"):
+            assert np.array_equal(a[key][index], b[key]), key
+        inv = {int(index[k]): k for k in range(len(index))}
+        assert sorted(a["alignments"]) == sorted(int(index[k]) for k in b["alignments"])
+        for k, al in a["alignments"].items():
+            bl = b["alignments"][inv[k]]
+            assert (al["result"], al["score"], al["xStart"], al["xEnd"], al["yStart"], al["yEnd"], al["ops"]) == \
+                   (bl["result"], bl["score"], bl["xStart"], bl["xEnd"], bl["yStart"], bl["yEnd"], bl["ops"]), k
+
+    same(whole, parts)
+    same(whole, shuffled, order)
+    assert len(whole["alignments"]) >= 20
+    # narrow band: a seeded diagonal on its own is a second single-diagonal band of its pair
+    check_overlap(ctx, reads[:36], DEFAULT_JSON, dict(kmer_threshold=14, band_size=0))
+
+
 def test_overlap_bands_and_thresholds(ctx):
     rng = np.random.default_rng(42)
     reads = overlapping_reads(rng, 900, 6, 350)
