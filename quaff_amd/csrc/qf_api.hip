@@ -1983,11 +1983,16 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   bool need[2] = {false, false};
   c->ov_rows.clear();
   c->rows_settled = 0;
+  bool runs = true;   // still looks like the scheduler's order: runs (x, y0), (x, y0 + 1), ... of 32+ pairs on average
   for (uint32_t p = 0; p < n_pairs; ++p) {
     if (pair_x[p] >= n_seqs || pair_y[p] >= n_seqs) return fail(c, QF_ERR_ARG, "pair index out of range");
     need[y_comp[p] ? 1 : 0] = true;
+    if (!runs) continue;
     if (!c->ov_rows.empty() && c->ov_rows.back().x == pair_x[p] && c->ov_rows.back().y0 + c->ov_rows.back().n == pair_y[p]) ++c->ov_rows.back().n;
-    else c->ov_rows.push_back({pair_x[p], pair_y[p], 1u, p});
+    else {
+      c->ov_rows.push_back({pair_x[p], pair_y[p], 1u, p});
+      if (c->ov_rows.size() > 4096 && (uint64_t)c->ov_rows.size() * 32 > p) { runs = false; c->ov_rows.clear(); }   // (an arbitrary list: do not keep a row per pair)
+    }
   }
   const bool sparse = cfg->sparse != 0;
   if (int rc = ensure_lse(c)) return rc;
@@ -2041,7 +2046,7 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   // Row prefilter: worth it when the list is the scheduler's (x-major, runs of consecutive y: src/qoverlap.cpp:528-547)
   c->ov_use_rows = false;
   if (sparse && cfg->kmer_threshold >= 0 && cfg->kmer_len <= kMaxRefK && !(c->debug & QF_DEBUG_NO_ROW_PREFILTER) &&
-      (uint64_t)c->ov_rows.size() * 32 <= n_pairs) {
+      !c->ov_rows.empty() && (uint64_t)c->ov_rows.size() * 32 <= n_pairs) {
     SeedArgs t;
     fill_seed_args(c, *c, cfg, t, 0, (int)(2 * c->read_maxlen - 1));
     t.max_ref_len = t.max_read_len;
