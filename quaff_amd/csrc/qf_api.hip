@@ -2053,8 +2053,8 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
     t.ref_skeys = nullptr;
     const size_t stride = seed_row_stride_bytes(t);
     int cl = 6;
-    while (stride && cl > 3 && (stride << cl) > 64 * 1024) --cl;
-    if (stride && (stride << cl) <= 64 * 1024) {
+    while (stride && cl > 3 && (stride << cl) > kSeedRowLdsMax) --cl;   // two workgroups' counters per CU
+    if (stride && (stride << cl) <= kSeedRowLdsMax) {
       if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl) {
         const uint32_t nb = 1u << (2 * cfg->kmer_len), n_chunks = (n_seqs + (1u << cl) - 1) >> cl;
         const size_t bytes = (size_t)n_chunks * (nb + 1) * 4;

@@ -866,9 +866,10 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
   const uint32_t* __restrict__ ce = a.chunk_entries + a.read_off[(uint64_t)it.chunk << cl];
   const uint32_t* __restrict__ xk = a.skmer + xb;
   const uint32_t y0 = it.chunk << cl, yylo = it.ylo - y0, yyhi = it.yhi - y0;
+  const bool whole = yylo == 0 && yyhi == csize;            // the item takes every sequence of the chunk (all but a row's two end chunks)
   auto count = [&](uint32_t i, uint32_t ent) {
     const uint32_t yy = ent >> 26;
-    if (yy < yylo || yy >= yyhi) return;
+    if (!whole && (yy < yylo || yy >= yyhi)) return;
     const uint32_t cbin = (i + (ent & 0x3FFFFFFu)) >> CB;   // bin = i - j + yLen - 1 (diagenv.cpp:33-40)
     atomicAdd(&cnt[yy * stride + (cbin >> 1)], 1u << (16 * (cbin & 1)));
   };
@@ -2040,7 +2041,7 @@ int launch_seed(const SeedArgs& a_in, uint32_t n_pairs, bool mem, hipStream_t s)
   if (a.row_items && a.n_row_items && !mem) {   // settle the pairs with nothing but the forced diagonal a chunk of y at a time
     const size_t stride = seed_row_stride_bytes(a);
     const size_t lds = stride << a.chunk_log2;
-    if (stride && lds <= 64 * 1024) {
+    if (stride && lds <= kSeedRowLdsMax) {
       const int cb = seed_row_bits(a);
       auto fn = cb == 4 ? k_seed_rows<4> : cb == 3 ? k_seed_rows<3> : k_seed_rows<2>;
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -34,6 +34,7 @@ struct PrepArgs {
   BatchCounters* bc;
 };
 
+constexpr size_t kSeedRowLdsMax = 76 * 1024;   // LDS of one row-prefilter workgroup (per-y coarse counters of a chunk): two fit a CU
 struct RowItem { uint32_t x, chunk, ylo, yhi, pbase; };   // pairs (x, y) for y in [ylo, yhi), all inside one chunk; pair index of ylo
 
 struct SeedArgs {
