@@ -312,3 +312,38 @@ def test_overlap_read_preparation_is_cached_and_invalidated(ctx):
         assert not np.array_equal(changed["viterbi"], first["viterbi"])
     finally:
         ctx.set_params_json(None)
+
+
+def test_overlap_blocks_in_flight_on_two_contexts():
+    """Two contexts with the same sequences, one host thread each, overlap calls running side by side on the device (how a
+    caller keeps the GPU busy across the blocks of a pair list): every call returns what a lone call returns."""
+    import quaff_amd as Q
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(144)
+    reads = overlapping_reads(rng, 5000, 40, 300)
+    seqs = reads + [r.revcomp() for r in reads]
+    pairs = O.overlap_task_pairs(40, 80)
+    ctxs = []
+    for _ in range(2):
+        c = Q.Context(0)
+        c.set_params_json(None)
+        c.set_null_json(NULL_JSON)
+        c.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+        ctxs.append(c)
+    try:
+        cfg = Q.DPConfig(kmer_threshold=14)
+        lone = ctxs[0].overlap_resident(pairs, cfg)
+        with ThreadPoolExecutor(2) as pool:
+            def run(c):
+                return [c.overlap_resident(pairs, cfg) for _ in range(4)]
+            results = [f.result() for f in [pool.submit(run, c) for c in ctxs]]
+        for per_ctx in results:
+            for r in per_ctx:
+                for key in ("viterbi", "score", "cells", "n_diagonals"):
+                    assert np.array_equal(r[key], lone[key]), key
+                assert {k: (a["score"], a["ops"]) for k, a in r["alignments"].items()} == \
+                       {k: (a["score"], a["ops"]) for k, a in lone["alignments"].items()}
+        assert len(lone["alignments"]) >= 10
+    finally:
+        for c in ctxs:
+            c.close()
