@@ -1525,10 +1525,24 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
     double M[B], I[B], D[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) M[b] = I[b] = D[b] = QF_NEG_INF;
-    double p1M = QF_NEG_INF, p1D = QF_NEG_INF;                     // last row, column of the previous step
-    double p2M = QF_NEG_INF, p2I = QF_NEG_INF, p2D = QF_NEG_INF;   // last row, column of two steps ago
-    double p1I = QF_NEG_INF;
+    double p1M = QF_NEG_INF, p1I = QF_NEG_INF, p1D = QF_NEG_INF;   // this lane's last row, column of the previous step
+    // the row above slot 0 at the previous step = this step's diagonal neighbour (it is lane L-1's last row two steps ago)
+    double dgMnext = QF_NEG_INF, dgInext = QF_NEG_INF, dgDnext = QF_NEG_INF;
+    if (L == 0) {   // the stripe's first lane starts on column jlo: its first diagonal neighbour is the previous stripe's last row at jlo - 1
+      const int jp = min(max(jlo - 1, 0), yLen + 1);
+      dgMnext = bprev[jp]; dgInext = bprev[(yLen + 2) + jp]; dgDnext = bprev[2 * (yLen + 2) + jp];
+    }
     const int steps = jhi - jlo + 1 + kVitSkewMax;
+    // FAST steps (below) of this stripe, for the whole workgroup's lane pattern: a lane is on an inner column with all eight
+    // cells inside the band and the matrix for a contiguous range of steps; the wavefront's range is the intersection
+    int fastLo, fastHi;
+    {
+      const bool rowsIn = i0 >= 1 && i0 + B - 1 <= xLen;
+      const int jA = max(max(jlo, 2), i0 + B - 1 - dhi), jB = min(min(jhi, yLen - 1), i0 - dlo);   // laneFast <=> jA <= j <= jB
+      int lo = rowsIn ? jA - jlo + skew : 1, hi = rowsIn ? jB - jlo + skew : 0;                      // in steps t (j = jlo + t - skew)
+      for (int o = 32; o; o >>= 1) { lo = max(lo, __shfl_xor(lo, o)); hi = min(hi, __shfl_xor(hi, o)); }
+      fastLo = lo; fastHi = hi;
+    }
     // the column's context word is fetched a step ahead (two wavefronts per SIMD do not hide a load per step), and the
     // previous column's word is simply the previous step's
     uint32_t wPrev = ctxword(jlo - skew - 1), wCur = ctxword(jlo - skew);
@@ -1544,28 +1558,25 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       const double insE = eins[insrow];
       // row above slot 0: lane L-1's last row (column j one step ago, column j-1 two steps ago): by shuffle inside the
       // wavefront, from the previous wavefront's ring, or (lane 0 of the stripe) from the boundary buffer
-      double upM = dpp_from_below<64, false>(p1M), upD = dpp_from_below<64, false>(p1D);   // DPP wave shift, not ds_bpermute
-      double dgM = dpp_from_below<64, false>(p2M), dgI = dpp_from_below<64, false>(p2I), dgD = dpp_from_below<64, false>(p2D);
+      double upM = dpp_from_below<64, false>(p1M), upI = dpp_from_below<64, false>(p1I), upD = dpp_from_below<64, false>(p1D);   // DPP wave shift, not ds_bpermute
       if (l == 0) {
         if (wv == 0) {
-          const int jc = min(max(j, 0), yLen + 1), jp = min(max(j - 1, 0), yLen + 1);
-          upM = bprev[jc]; upD = bprev[2 * (yLen + 2) + jc];
-          dgM = bprev[jp]; dgI = bprev[(yLen + 2) + jp]; dgD = bprev[2 * (yLen + 2) + jp];
+          const int jc = min(max(j, 0), yLen + 1);
+          upM = bprev[jc]; upI = bprev[(yLen + 2) + jc]; upD = bprev[2 * (yLen + 2) + jc];
         } else {
-          // the previous wavefront's last lane was on column j at step t-K-1 and on column j-1 at step t-K-2
+          // the previous wavefront's last lane was on column j at step t-K-1
           const double* x1 = s_x[wv - 1][(t + 2 * R - K - 1) % R];
-          const double* x2 = s_x[wv - 1][(t + 2 * R - K - 2) % R];
-          upM = x1[0]; upD = x1[2];
-          dgM = x2[0]; dgI = x2[1]; dgD = x2[2];
+          upM = x1[0]; upI = x1[1]; upD = x1[2];
         }
       }
+      double dgM = dgMnext, dgI = dgInext, dgD = dgDnext;
+      dgMnext = upM; dgInext = upI; dgDnext = upD;
       uint32_t tbword = 0;
       double aboveM = upM, aboveD = upD;
       // FAST step (wave-uniform): every lane is on an inner column (not the first or last read column) and all eight of
       // its cells are inside the band and the matrix: no start candidate, no end tracking, no masking; values by
       // v_max_f64, flags as raw compare bits (see k_viterbi_fill)
-      const bool laneFast = colvalid && j > 1 && j < yLen && i0 >= 1 && i0 + B - 1 <= xLen && i0 - j >= dlo && i0 + B - 1 - j <= dhi;
-      if (__builtin_amdgcn_ballot_w64(!laneFast) == 0) {
+      if (t >= fastLo && t <= fastHi) {
         uint32_t acc = 0;
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -1618,7 +1629,6 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
         }
       }
       }
-      p2M = p1M; p2I = p1I; p2D = p1D;
       p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
       if (l == 63) { double* xo = s_x[wv][t % R]; xo[0] = p1M; xo[1] = p1I; xo[2] = p1D; }
       if (colvalid) {
