@@ -1478,6 +1478,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   unsigned long long* stripe_off = (unsigned long long*)base;                 // [nStripes+1]
   double* bnd = (double*)(base + 2ull * (g.nStripes + 1));                   // [2][3][yLen+2]
   uint32_t* tbw = base + row_header_words(g, yLen);
+  asm volatile("" : "+v"(tbw));
   const size_t bndStride = 3ull * (yLen + 2);
   // stripe offsets (thread 0) and the row-0 boundary (-inf)
   if (L == 0) {
@@ -1495,7 +1496,10 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
   __syncthreads();
   const int skew = vit_skew(L);
 
-  const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  // (kept in vector registers: the kernel has fifty of those to spare at two wavefronts per SIMD and no scalar ones -- the
+  // compiler was parking scalars in the lanes of a vector register and reading them back ~25 times per step)
+  double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
+  asm volatile("" : "+v"(i2m), "+v"(d2m), "+v"(i2i), "+v"(d2d));
   const double* __restrict__ ematch = EMLDS ? lds_tab : a.dp.ematch;
   const double* __restrict__ eins = EMLDS ? lds_tab + n_em : a.dp.eins;
   const double* __restrict__ trans = EMLDS ? lds_tab + n_em + kInsRows : a.dp.trans;   // (a step's first cell waits on these)
@@ -1514,6 +1518,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
     const int i0 = g.ilo + s * S + L * B;           // this lane's first row
     const double* __restrict__ bprev = bnd + (size_t)(s & 1) * bndStride;      // last row of the previous stripe
     double* __restrict__ bnext = bnd + (size_t)((s + 1) & 1) * bndStride;
+    asm volatile("" : "+v"(bprev), "+v"(bnext));                              // (vector registers: see above)
     for (size_t c = L; c < bndStride; c += G) bnext[c] = QF_NEG_INF;
     if (L < NW * R * 3) (&s_x[0][0][0])[L] = QF_NEG_INF;
     __threadfence();
