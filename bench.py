@@ -40,8 +40,8 @@ F64_OPS_PER_CELL = {"viterbi": 20.0, "forward": 65.0, "backward": 101.0, "overla
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default 10 (align, train), 1 (overlap: a step is the whole pair triangle), 2 (fulldp)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (align, train), 1 (overlap, fulldp)")
     ap.add_argument("--workload", default="align", choices=["align", "train", "overlap", "fulldp"],
                     help="align = BASELINE config 2 (the headline metric, default); train / overlap / fulldp = configs 4 / 3 / 5")
     ap.add_argument("--reads", type=int, default=0,
@@ -54,8 +54,9 @@ def parse(argv=None):
                     help="units in the CPU-baseline / parity sample (reads; pairs for overlap); 0 = skip; default per workload")
     ap.add_argument("--overlap-rows", type=int, default=-1,
                     help="overlap: the job is rows [0, R) of the all-vs-all pair triangle (row nx = pairs (nx, ny > nx), both "
-                         "strands), cut into per-rank blocks of equal pair count; default 34 rows (3.4 M pairs) for the 50 k-read "
-                         "config, the whole triangle for small --reads")
+                         "strands), cut into per-rank blocks of equal pair count; default: the whole triangle (all n - 1 rows)")
+    ap.add_argument("--overlap-block-pairs", type=int, default=1 << 26,
+                    help="overlap: pairs per qf_overlap_rows call (the unit the contexts of a rank pull off their shared list)")
     ap.add_argument("--overlap-threshold", type=float, default=0.0,
                     help="overlap: alignments scoring below it are not traced back (`quaff overlap` prints only score >= 0 by "
                          "default, -threshold; pass -inf for -nothreshold)")
@@ -70,7 +71,11 @@ def parse(argv=None):
                     help="testing only: every rank uses GPU 0 and the process group is gloo (RCCL wants one GPU per rank)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = this process's CPU share (at most 16)")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    d_steps, d_warm = {"align": (10, 3), "train": (10, 3), "overlap": (1, 1), "fulldp": (2, 1)}[a.workload]
+    a.steps = d_steps if a.steps is None else a.steps
+    a.warmup = d_warm if a.warmup is None else a.warmup
+    return a
 
 
 def spawn_ranks(a):
@@ -110,6 +115,11 @@ def order2_params_json():
     match = ",\n".join('   "%s": {%s }' % (c, block.rstrip().rstrip("}").rstrip() + " }") for c in ctxs)
     return ('{\n  "matchOrder": 3,\n  "gapOrder": 2,\n' + head[head.index('"refBase"') - 2:] + '"beginInsert": {%s },\n  "beginDelete": {%s },\n  '
             % gaps + mid + '"match": {\n' + match + " } }\n")
+
+
+def api_revcomp(seq):
+    from quaff_amd import api
+    return api.revcomp(seq)
 
 
 def cpu_threads(a):
@@ -361,7 +371,7 @@ class FullDPJob(AlignJob):
 
     def setup(self, Q, api, dist):
         a = self.a
-        total = a.reads or 256
+        total = a.reads or 10000                 # BASELINE config 5: all 10 000 reads (1e13 cells), cut into pieces by the memory budget
         self.read_len = a.read_len or 5000
         self.ref_len = a.ref_len or 100000
         self.ctx = ctx = Q.Context(self.local_rank)
@@ -386,9 +396,10 @@ class FullDPJob(AlignJob):
         self.lock = threading.Lock()
 
     def describe(self):
-        return ("BASELINE config 5%s: -kmatchoff full DP, %d bp ref (+revcomp) x %d x %d bp reads sharded over %d GPU(s) by cell count"
+        return ("BASELINE config 5%s: -kmatchoff full DP, %d bp ref (+revcomp) x %d x %d bp reads sharded over %d GPU(s) by cell count "
+                "(%d reads on rank 0; a rank's batch is processed in pieces that fit the device's memory)"
                 % ("" if (self.total_reads, self.ref_len, self.read_len) == (10000, 100000, 5000) else " shape (10 000 reads in the stated config)",
-                   self.ref_len, self.total_reads, self.read_len, self.world))
+                   self.ref_len, self.total_reads, self.read_len, self.world, self.n))
 
     def finish(self, steps):
         a, ctx = self.a, self.ctx
@@ -400,7 +411,16 @@ class FullDPJob(AlignJob):
         cpu = None
         n_s = min(1 if a.cpu_sample < 0 else a.cpu_sample, self.n)
         if n_s > 0:
-            full = ctx.align_resident(self.cfg, 0, reads_below=n_s)
+            # the sample alone on a second context (the job's context holds the whole batch; running it again for one read's
+            # alignment would cost another full step)
+            small = self.Q.Context(self.local_rank)
+            small.set_params_json(None)
+            small.set_null_json(golden("testquaffnullparams.json"))
+            small.set_refs([self.ref, api_revcomp(self.ref)])
+            b1 = int(self.off[n_s])
+            small.upload_reads_packed(self.seq[:b1], self.qual[:b1], self.off[:n_s + 1].copy())
+            full = small.align_resident(self.cfg, 0)
+            small.close()
             cpu = self.cpu_baseline(n_s, min(cpu_threads(a), 2 * n_s), full, cfg_kw=dict(sparse=False))
             cpu["sample"] = cpu["sample"].replace("one read per task", "one read per task (a read's two strands run one after the other)")
         return roof, cpu
@@ -530,6 +550,9 @@ class TrainJob(Job):
 
 # ------------------------------------------------------------------------------------------------ config 3: overlap
 class OverlapJob(Job):
+    """quaff overlap over rows of QuaffOverlapScheduler's pair enumeration (src/qoverlap.cpp:475-480,528-547), through
+    qf_overlap_rows: the pairs are enumerated, thresholded and reduced on the device; what comes back is the alignments scoring
+    at least the threshold plus totals.  The default job is the WHOLE triangle of BASELINE config 3 (3.75e9 pairs)."""
     metric = "DP cells/sec (overlap Viterbi)"
     scaling = "strong"
 
@@ -538,8 +561,8 @@ class OverlapJob(Job):
         a = self.a
         self.n = n = a.reads or 50000            # BASELINE config 3: 50 k reads x 2 kb, 100x coverage of a 1 Mb genome
         self.read_len = a.read_len or 2000
-        rows = a.overlap_rows if a.overlap_rows >= 0 else (34 if n >= 10000 else 0)
-        self.rows = rows = min(rows, n - 1) if rows else n - 1
+        rows = a.overlap_rows if a.overlap_rows > 0 else n - 1     # the scheduler's rows: nx = 0 ... n - 2
+        self.rows = rows = min(rows, n - 1)
         self.genome = api.synth_ref(3, max(a.ref_len, 20 * n))
         seq, qual, off = api.synth_reads(4, self.genome, n, self.read_len)
         # SeqList::loadSequences: originals followed by their reverse complements
@@ -547,10 +570,24 @@ class OverlapJob(Job):
         self.quals = [qual[int(off[k]):int(off[k + 1])] for k in range(n)]
         self.seqs += [api.revcomp(s) for s in self.seqs]
         self.quals += [q[::-1] for q in self.quals[:n]]
-        # as for align: a caller keeps a few blocks of the pair list in flight, one context and host thread each (calls are
-        # synchronous); a block's latency-bound tails (wide bands, selection, copies) then run beside the next block's seeding
+        # Row nx holds 2n - 1 - nx pairs; ranks take contiguous row blocks of equal pair count, and inside a rank a few contexts
+        # (one host thread each; calls are synchronous) pull sub-blocks of rows off a shared list, as the reference's worker
+        # threads pull tasks off the scheduler: a block's tails (wide bands, selection, traceback, copies) run beside the next
+        # block's seeding.
+        row_len = (2 * n - 1 - np.arange(rows)).astype(np.float64)
+        cuts = dist.balanced_blocks(row_len, self.world)
+        r0, r1 = int(cuts[self.rank]), int(cuts[self.rank + 1])
+        self.row_block = (r0, r1)
+        self.n_pairs = int(row_len[r0:r1].sum())
+        target = max(1, a.overlap_block_pairs)
+        self.blocks, b0, acc = [], r0, 0
+        for r in range(r0, r1):
+            acc += int(row_len[r])
+            if acc >= target or r == r1 - 1:
+                self.blocks.append((b0, r + 1))
+                b0, acc = r + 1, 0
         self.ctxs = []
-        for _ in range(max(1, 1 if a.serial_classes else a.inflight)):
+        for _ in range(max(1, 1 if a.serial_classes else min(a.inflight, len(self.blocks)))):
             ctx = Q.Context(self.local_rank)
             ctx.set_params_json(None)
             ctx.set_null_json(golden("testquaffnullparams.json"))
@@ -559,51 +596,59 @@ class OverlapJob(Job):
             ctx.set_debug_flags((4 if a.serial_classes else 0) | a.debug_flags)
             self.ctxs.append(ctx)
         self.ctx = self.ctxs[0]
-        # QuaffOverlapScheduler order (src/qoverlap.cpp:475-480): nx < ny, nx an original, ny over originals then complements.
-        # Row nx holds 2n - 1 - nx pairs; ranks take contiguous row blocks of equal pair count.
-        row_len = (2 * n - 1 - np.arange(rows)).astype(np.float64)
-        cuts = dist.balanced_blocks(row_len, self.world)
-        r0, r1 = int(cuts[self.rank]), int(cuts[self.rank + 1])
-        self.row_block = (r0, r1)
-        xs = np.concatenate([np.full(2 * n - 1 - r, r, np.uint32) for r in range(r0, r1)]) if r1 > r0 else np.zeros(0, np.uint32)
-        ys = np.concatenate([np.arange(r + 1, 2 * n, dtype=np.uint32) for r in range(r0, r1)]) if r1 > r0 else np.zeros(0, np.uint32)
-        self.pairs = (xs, ys, (ys >= n).astype(np.uint8))
         self.cfg = Q.DPConfig(kmer_threshold=14, band_size=a.band)
         self.cls = {}
+        self.tot = {}
         self.Q = Q
-        self.turn = 0
         import threading
+        from concurrent.futures import ThreadPoolExecutor
         self.lock = threading.Lock()
-        if len(self.ctxs) > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            self.pool = ThreadPoolExecutor(len(self.ctxs))
-            for c in self.ctxs[1:]:                   # every context prepares its reads and buffers before the warm-up steps
-                c.overlap_resident(self.pairs, self.cfg, raw=True)
+        self.pool = ThreadPoolExecutor(len(self.ctxs))
+        if self.blocks:
+            for c in self.ctxs:                       # every context prepares its reads and buffers before the warm-up steps
+                c.overlap_rows(n, self.blocks[0][0], min(self.blocks[0][0] + 2, self.blocks[0][1]), self.cfg, raw=True)
 
     def reset(self):
-        self.phase, self.cls = {}, {}
+        self.phase, self.cls, self.tot = {}, {}, {}
 
     def run_steps(self, k):
-        """k steps, len(self.ctxs) of them in flight (step s on context s mod n; see AlignJob.run_steps)."""
-        if len(self.ctxs) == 1:
-            return sum(self.step() for _ in range(k))
-        return run_in_flight(self, k)
+        return sum(self.step() for _ in range(k))
 
-    def step(self, ctx=None):
-        res = (ctx or self.ctx).overlap_resident(self.pairs, self.cfg, raw=True)
-        with self.lock:
-            self.add_phases(res, ("prep", "seed", "fill", "traceback", "total"))
-            for k in range(res.n_fill_classes):
-                if res.units_class[k]:
-                    e = self.cls.setdefault(k, {"ms": 0.0, "cells": int(res.cells_class[k]), "units": int(res.units_class[k])})
-                    e["ms"] += res.ms_fill_class[k]
-            self.n_align = int(res.n_alignments)
-        return int(res.total_cells)
+    def step(self):
+        """The rank's whole row range once: its sub-blocks dealt to the contexts from a shared list."""
+        todo = list(reversed(self.blocks))
+        cells = [0]
+
+        def work(ctx):
+            while True:
+                with self.lock:
+                    if not todo:
+                        return
+                    b0, b1 = todo.pop()
+                res = ctx.overlap_rows(self.n, b0, b1, self.cfg, raw=True)
+                with self.lock:
+                    self.add_phases(res, ("prep", "seed", "fill", "traceback", "total"))
+                    for key in ("n_pairs", "n_finite", "n_hits", "total_cells", "total_diagonals", "n_blocks", "traceback_bytes"):
+                        self.tot[key] = self.tot.get(key, 0) + int(getattr(res, key))
+                    self.tot["checksum"] = (self.tot.get("checksum", 0) + int(res.result_checksum)) & ((1 << 64) - 1)
+                    for k in range(res.n_fill_classes):
+                        if res.units_class[k]:
+                            e = self.cls.setdefault(k, {"ms": 0.0, "cells": 0, "units": 0})
+                            e["ms"] += res.ms_fill_class[k]
+                            e["cells"] += int(res.cells_class[k])
+                            e["units"] += int(res.units_class[k])
+                    cells[0] += int(res.total_cells)
+        for f in [self.pool.submit(work, c) for c in self.ctxs]:
+            f.result()
+        return cells[0]
 
     def describe(self):
-        return ("BASELINE config 3%s: quaff overlap, %d x %d bp reads from a %d bp genome, both strands, rows [0, %d) of the all-vs-all pair "
-                "triangle sharded over %d GPU(s) by pair count (%d pairs on rank 0)"
-                % ("" if self.n == 50000 else " shape", self.n, self.read_len, len(self.genome), self.rows, self.world, len(self.pairs[0])))
+        whole = self.n == 50000 and self.rows == self.n - 1
+        return ("BASELINE config 3%s: quaff overlap, %d x %d bp reads from a %d bp genome, both strands, %s all-vs-all pair triangle "
+                "(%d pairs in all) through qf_overlap_rows, rows sharded over %d GPU(s) by pair count (rows [%d, %d) = %d pairs on rank 0)"
+                % ("" if whole else " shape", self.n, self.read_len, len(self.genome),
+                   "the whole" if self.rows == self.n - 1 else "rows [0, %d) of the" % self.rows,
+                   sum(2 * self.n - 1 - r for r in range(self.rows)), self.world, self.row_block[0], self.row_block[1], self.n_pairs))
 
     def kernel_symbol(self, cls):
         name = self.ctx.L.qf_fill_class_name(cls).decode()
@@ -616,38 +661,60 @@ class OverlapJob(Job):
     def finish(self, steps):
         a = self.a
         # the kernel that fills most of the cells (the classes run side by side: a small class's event-bracketed duration is
-        # the length of the whole phase, not its own work)
+        # the length of the whole phase, not its own work); per launch = per internal row block
         dom = max(self.cls, key=lambda k: self.cls[k]["cells"])
         e = self.cls[dom]
+        launches = max(1, self.tot["n_blocks"])
         sym = self.kernel_symbol(dom)
         kind = "overlap_single" if dom == 0 else "overlap"
-        roof = roofline_entry(a.workload, sym, kind, e["cells"], e["ms"] / steps, "fp64_valu" if dom else "hbm")
-        t0 = time.perf_counter()
-        for _ in range(3):
-            self.ctx.overlap_resident(self.pairs, self.cfg, raw=True)
-        seq_ms = (time.perf_counter() - t0) / 3 * 1e3
-        if len(self.ctxs) > 1 and not a.serial_classes:
-            # the dominant kernel alone: in the timed region it shares the GPU with the other fill classes and with the other
-            # blocks in flight
+        roof = roofline_entry(a.workload, sym, kind, e["cells"] / launches, e["ms"] / launches, "fp64_valu" if dom else "hbm")
+        roof["launches_per_step"] = launches // steps
+        if not a.serial_classes and self.blocks:
+            # the dominant kernel alone, on one internal block: in the timed region it shares the GPU with the other fill classes
+            # and with the other contexts' blocks
+            b0 = self.blocks[0][0]
+            b1 = b0
+            while b1 < self.row_block[1] and sum(2 * self.n - 1 - r for r in range(b0, b1 + 1)) <= (1 << 24):
+                b1 += 1
+            b1 = max(b1, b0 + 1)
             self.ctx.set_debug_flags(4 | a.debug_flags)
-            sres = self.ctx.overlap_resident(self.pairs, self.cfg, raw=True)
+            sres = self.ctx.overlap_rows(self.n, b0, b1, self.cfg, raw=True)
             self.ctx.set_debug_flags(a.debug_flags)
-            iso = roofline_entry(a.workload, sym, kind, e["cells"], float(sres.ms_fill_class[dom]), "fp64_valu" if dom else "hbm")
-            roof["isolated"] = {"ms_per_launch": iso["ms_per_launch"], "achieved": iso["achieved"], "frac": iso["frac"]}
-        self.extra = {"pairs_this_rank": len(self.pairs[0]), "rows_this_rank": list(self.row_block), "score_threshold": a.overlap_threshold,
-                      "alignments": self.n_align, "blocks_in_flight": len(self.ctxs), "ms_per_step_one_at_a_time": round(seq_ms, 3),
-                      "fill_kernels": {self.kernel_symbol(k): {"ms": round(v["ms"] / steps, 4), "cells": v["cells"], "bands": v["units"]}
+            if sres.units_class[dom]:
+                iso = roofline_entry(a.workload, sym, kind, int(sres.cells_class[dom]), float(sres.ms_fill_class[dom]), "fp64_valu" if dom else "hbm")
+                roof["isolated"] = {"rows": [b0, b1], "cells_per_launch": iso["cells_per_launch"], "ms_per_launch": iso["ms_per_launch"],
+                                    "achieved": iso["achieved"], "frac": iso["frac"]}
+        t = {k: v // steps if k != "checksum" else v for k, v in self.tot.items()}
+        self.extra = {"pairs_this_rank": self.n_pairs, "rows_this_rank": list(self.row_block), "row_blocks": len(self.blocks),
+                      "score_threshold": a.overlap_threshold, "contexts_in_flight": len(self.ctxs),
+                      "per_step": {"pairs": t["n_pairs"], "pairs_with_a_finite_result": t["n_finite"], "alignments_returned": t["n_hits"],
+                                   "envelope_diagonals": t["total_diagonals"], "internal_blocks": t["n_blocks"], "traceback_bytes": t["traceback_bytes"]},
+                      "fill_kernels": {self.kernel_symbol(k): {"ms": round(v["ms"] / steps, 3), "cells": v["cells"] // steps, "bands": v["units"] // steps}
                                        for k, v in sorted(self.cls.items())}}
+        assert t["n_pairs"] == self.n_pairs, (t["n_pairs"], self.n_pairs)
         cpu = None
-        n_s = min(10000 if a.cpu_sample < 0 else a.cpu_sample, len(self.pairs[0]))
-        if n_s > 0:
+        n_s = 10000 if a.cpu_sample < 0 else a.cpu_sample
+        if n_s > 0 and self.n_pairs:
             cpu = self.cpu_baseline(n_s, cpu_threads(a))
         return roof, cpu
 
-    def cpu_baseline(self, n_sample, threads):
-        """Oracle overlap (QuaffOverlapTask::run, one pair per task) on every pair of this rank's block the GPU returned an
-        alignment for (score >= threshold) plus a random n_sample of the rest: result, score, coordinates and state path compared
-        with ==; pairs below the threshold must have no alignment."""
+    def sample_rows(self, rng, n_rows=24, edge=34):
+        """Rows whose hits the parity leg checks in full: the first and the last `edge` rows of this rank's range (long rows; the
+        short rows at the end of the triangle) and a random n_rows in between."""
+        r0, r1 = self.row_block
+        rows = set(range(r0, min(r1, r0 + edge))) | set(range(max(r0, r1 - edge), r1))
+        mid = [r for r in range(r0, r1) if r not in rows]
+        if mid:
+            rows |= set(int(r) for r in rng.choice(mid, size=min(n_rows, len(mid)), replace=False))
+        return sorted(rows)
+
+    def cpu_baseline(self, n_sample, threads, max_hits=3000):
+        """Oracle overlap (QuaffOverlapTask::run, one pair per task), timed, on (a) the alignments qf_overlap_rows returned for a
+        sample of rows -- the first 34 and the last 34 rows of the rank's range and 24 random rows between (at most max_hits of
+        them, chosen at random) -- compared record for record with ==, and (b) n_sample random pairs of the rank's range pushed through
+        the explicit-pair-list entry point (qf_overlap_resident), whose per-pair result, score and cell count are compared with ==
+        (most of these score below the threshold: they must have no alignment).  Also checks the two entry points against each
+        other on the sampled rows: every pair of a row the oracle scores >= threshold is among the returned hits."""
         from concurrent.futures import ThreadPoolExecutor
         import numpy as np
         from oracle import oracle as O
@@ -656,47 +723,72 @@ class OverlapJob(Job):
         null = O.NullParams.from_json(golden("testquaffnullparams.json"))
         osc = [O.OverlapScores(params, sc, False), O.OverlapScores(params, sc, True)]
         cfg = O.DPConfig(kmer_threshold=14, band=self.a.band)
-        res = self.ctx.overlap_resident(self.pairs, self.cfg)
-        xs, ys, cs = self.pairs
         rng = np.random.default_rng(5)
-        with_al = sorted(res["alignments"].keys())
-        if len(with_al) > 2000:          # dense read sets: a random 2 000 of the pairs that align (each is a banded 2 kb x 2 kb fill on the CPU)
-            with_al = [with_al[k] for k in sorted(rng.choice(len(with_al), size=2000, replace=False))]
-        pick = sorted(set(with_al) | set(int(p) for p in rng.choice(len(xs), size=n_sample, replace=False)))
+        n, total = self.n, 2 * self.n
+        thr = self.a.overlap_threshold
+        ctx = self.ctx
+        # (a) hits of the sampled rows
+        hit_recs = []
+        for r in self.sample_rows(rng):
+            res = ctx.overlap_rows(n, r, r + 1, self.cfg)
+            for h in res["hits"]:
+                hit_recs.append((h, ctx.hit_ops(h, res["runs"])))
+        n_hits_all = len(hit_recs)
+        if len(hit_recs) > max_hits:
+            hit_recs = [hit_recs[k] for k in sorted(rng.choice(len(hit_recs), size=max_hits, replace=False))]
+        # (b) random pairs of the rank's rows, row chosen by its length
+        r0, r1 = self.row_block
+        row_len = (total - 1 - np.arange(r0, r1)).astype(np.float64)
+        rr = r0 + rng.choice(r1 - r0, size=n_sample, p=row_len / row_len.sum())
+        yy = rr + 1 + (rng.random(n_sample) * (total - 1 - rr)).astype(np.int64)
+        rnd = sorted(set(zip(rr.tolist(), yy.tolist())))
+        xs = np.array([p[0] for p in rnd], np.uint32)
+        ys = np.array([p[1] for p in rnd], np.uint32)
+        lst = ctx.overlap_resident((xs, ys, (ys >= n).astype(np.uint8)), self.cfg)
         fs = {}
 
         def seq_of(k):
             if k not in fs:
                 fs[k] = O.FastSeq("s%d" % k, self.seqs[k].decode(), self.quals[k].decode())
             return fs[k]
-        for p in pick:
-            seq_of(int(xs[p])), seq_of(int(ys[p]))
+        for h, _ in hit_recs:
+            seq_of(int(h["x"])), seq_of(int(h["y"]))
+        for x, y in rnd:
+            seq_of(x), seq_of(y)
+        tasks = [(int(h["x"]), int(h["y"])) for h, _ in hit_recs] + rnd
         O.lib()
         t0 = time.time()
         with ThreadPoolExecutor(threads) as ex:
-            out = list(ex.map(lambda p: O.overlap_pair(fs[int(xs[p])], fs[int(ys[p])], bool(cs[p]), osc[int(cs[p])], sc, null, cfg), pick))
+            out = list(ex.map(lambda p: O.overlap_pair(fs[p[0]], fs[p[1]], p[1] >= n, osc[int(p[1] >= n)], sc, null, cfg), tasks))
         dt = time.time() - t0
-        thr = self.a.overlap_threshold
         mism, cells = 0, 0
-        for p, want in zip(pick, out):
-            cells += int(res["cells"][p])
-            g = res["alignments"].get(p)
-            if want is None:
-                mism += g is not None or np.isfinite(res["viterbi"][p])
-                continue
-            if res["viterbi"][p] != want["result"] or res["score"][p] != want["score"]:
+        for (h, ops), want in zip(hit_recs, out[:len(hit_recs)]):
+            if want is None or want["score"] < thr:
                 mism += 1
                 continue
-            if want["score"] >= thr:
+            cells += want["cells"]
+            if (h["viterbi"], h["score"], int(h["x_start"]), int(h["x_end"]), int(h["y_start"]), int(h["y_end"]), ops) != \
+                    (want["result"], want["score"], want["xStart"], want["xEnd"], want["yStart"], want["yEnd"], want["ops"]):
+                mism += 1
+        for p, want in enumerate(out[len(hit_recs):]):
+            cells += int(lst["cells"][p])
+            g = lst["alignments"].get(p)
+            if want is None:
+                mism += g is not None or np.isfinite(lst["viterbi"][p])
+                continue
+            if lst["viterbi"][p] != want["result"] or lst["score"][p] != want["score"] or int(lst["cells"][p]) != want["cells"]:
+                mism += 1
+            elif want["score"] >= thr:
                 if g is None or (g["xStart"], g["xEnd"], g["yStart"], g["yEnd"], g["ops"]) != \
                         (want["xStart"], want["xEnd"], want["yStart"], want["yEnd"], want["ops"]):
                     mism += 1
             elif g is not None:
                 mism += 1
         return {"value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
-                "sample": "%d pairs of the rank-0 block: %d of the %d with a returned alignment + a random %d (%d cells), oracle/quaff_oracle.c, %d "
-                          "threads, one pair per task; result, score, coordinates and state path compared with =="
-                          % (len(pick), len(with_al), len(res["alignments"]), n_sample, cells, threads),
+                "sample": "%d of the %d alignments qf_overlap_rows returned for %d sampled rows of the rank-0 range (first / last 34 rows + 24 random) and "
+                          "%d random pairs of the range through qf_overlap_resident (%d cells in all), oracle/quaff_oracle.c, %d threads, one pair per "
+                          "task; result, score, coordinates and state path compared with =="
+                          % (len(hit_recs), n_hits_all, len(self.sample_rows(np.random.default_rng(5))), len(rnd), cells, threads),
                 "seconds": round(dt, 3), "gpu_parity_mismatches": int(mism)}
 
 

@@ -31,6 +31,7 @@
  *   QuaffOverlapViterbiMatrix ctor   src/qoverlap.cpp:77-160  qf_overlap_resident (overlap fill kernel)
  *   QuaffOverlapViterbiMatrix::alignment :162-290, scoreAdjustedAlignment :292-302   qf_overlap_resident
  *   QuaffOverlapTask::run            src/qoverlap.cpp:457-464 qf_overlap_resident (one task per pair)
+ *   QuaffOverlapScheduler::advance / nextOverlapTask src/qoverlap.cpp:475-480,528-547 qf_overlap_rows (pairs enumerated on the device)
  *   QuaffAlignmentPrinter threshold  src/qmodel.cpp:2566-2569 qf_set_score_threshold (applied before the traceback)
  *   runQuaff*Tasks worker threads    src/qmodel.cpp:2870-2882 qf_device_count + one qf_ctx per device
  *
@@ -269,6 +270,52 @@ typedef struct qf_overlap_result {
  * (as for reads x references in qf_align_* / qf_count_resident); callers feed longer lists in blocks. */
 int qf_overlap_resident(qf_ctx *ctx, const qf_dp_config *cfg, const uint32_t *pair_x, const uint32_t *pair_y,
                         const uint8_t *y_complemented, uint32_t n_pairs, qf_overlap_result *out);
+
+/* ---- quaff overlap, the scheduler's own enumeration (rows of the pair triangle) ------------------------------------
+ * QuaffOverlapScheduler (src/qoverlap.cpp:457-480,528-547) walks nx = 0 ... nOriginals - 2 and, for each nx,
+ * ny = nx + 1 ... y.size() - 1 over the originals followed by their reverse complements (yComplemented = ny >= nOriginals),
+ * one QuaffOverlapTask per (nx, ny); the printer keeps what scores at least -threshold (src/qmodel.cpp:2566-2569).
+ * qf_overlap_rows does rows [x0, x1) of that enumeration on the device: the (nx, ny, yComplemented) triples are generated
+ * there, the score threshold (qf_set_score_threshold) is applied there, and only the alignments that pass come back, in the
+ * scheduler's order, with totals over all the row block's pairs.  Nothing per pair crosses PCIe in either direction: an
+ * all-vs-all run of N reads has ~N^2 pairs, of which a fraction ~coverage/N overlap.  Row blocks are independent, so
+ * several GPUs take disjoint [x0, x1) (rows are not equally long: row nx has n_seqs - 1 - nx pairs). */
+typedef struct qf_overlap_hit {
+  uint32_t x, y;             /* nx, ny: indices into the resident set (y >= n_originals: a reverse complement) */
+  double viterbi;            /* QuaffOverlapViterbiMatrix::result */
+  double score;              /* result - null(x) - null(y) */
+  uint32_t x_start, x_end, y_start, y_end;  /* 1-based closed intervals */
+  uint32_t n_columns, n_runs;
+  uint64_t run_offset;       /* first run in qf_overlap_rows_result.state_runs */
+} qf_overlap_hit;
+
+typedef struct qf_overlap_rows_result {
+  uint32_t x0, x1;
+  uint64_t n_pairs;            /* pairs enumerated: sum over nx in [x0, x1) of n_seqs - 1 - nx */
+  uint64_t n_finite;           /* pairs with a finite Viterbi result (every one of them is a candidate for the printer) */
+  uint64_t total_cells;        /* DP cells visited (SURVEY 8d definition) */
+  uint64_t total_diagonals;    /* envelope diagonals, summed over the pairs */
+  uint64_t result_checksum;    /* sum over the finite pairs of the bit pattern of `viterbi`, mod 2^64: independent of order
+                                  and blocking, equal between this entry point and qf_overlap_resident on the same pairs */
+  uint32_t n_hits;             /* alignments scoring >= the threshold, ordered by (x, y) */
+  const qf_overlap_hit *hits;
+  const uint32_t *state_runs;  /* as qf_overlap_result.state_runs */
+  uint32_t n_blocks;           /* row blocks the call was cut into (device memory, 2^28-pair tables) */
+  float ms_prep, ms_seed, ms_fill, ms_traceback, ms_total;   /* device-side, summed over the blocks */
+  uint64_t traceback_bytes;
+  float ms_fill_class[QF_MAX_FILL_CLASSES];
+  uint64_t cells_class[QF_MAX_FILL_CLASSES];
+  uint32_t units_class[QF_MAX_FILL_CLASSES];
+  uint32_t n_fill_classes;
+} qf_overlap_rows_result;
+
+/* The resident set (qf_upload_reads) is n_originals reads, optionally followed by their reverse complements (n_seqs =
+ * n_originals or 2 n_originals, as SeqList::loadSequences builds it).  Rows: 0 <= x0 <= x1 <= n_originals - 1 (the scheduler
+ * stops when nx + 1 == nOriginals, src/qoverlap.cpp:520-522).  Results stay valid until the next overlap call on ctx. */
+int qf_overlap_rows(qf_ctx *ctx, const qf_dp_config *cfg, uint32_t n_originals, uint32_t x0, uint32_t x1,
+                    qf_overlap_rows_result *out);
+/* Pairs in rows [x0, x1) of that enumeration over n_seqs resident sequences (host arithmetic; for splitting the triangle). */
+uint64_t qf_overlap_rows_pairs(uint32_t n_seqs, uint32_t x0, uint32_t x1);
 
 /* Envelope only (DiagonalEnvelope::diagonals for pair (read, ref)); returns the number of
  * diagonals, writes at most cap of them.  For tests and debugging. */

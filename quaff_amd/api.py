@@ -83,12 +83,34 @@ class _OverlapResult(C.Structure):
                 ("n_fill_classes", C.c_uint32)]
 
 
+class _OverlapHit(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("viterbi", C.c_double), ("score", C.c_double), ("x_start", C.c_uint32),
+                ("x_end", C.c_uint32), ("y_start", C.c_uint32), ("y_end", C.c_uint32), ("n_columns", C.c_uint32),
+                ("n_runs", C.c_uint32), ("run_offset", C.c_uint64)]
+
+
+class _OverlapRowsResult(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("x1", C.c_uint32), ("n_pairs", C.c_uint64), ("n_finite", C.c_uint64),
+                ("total_cells", C.c_uint64), ("total_diagonals", C.c_uint64), ("result_checksum", C.c_uint64),
+                ("n_hits", C.c_uint32), ("hits", C.POINTER(_OverlapHit)), ("state_runs", C.POINTER(C.c_uint32)),
+                ("n_blocks", C.c_uint32), ("ms_prep", C.c_float), ("ms_seed", C.c_float), ("ms_fill", C.c_float),
+                ("ms_traceback", C.c_float), ("ms_total", C.c_float), ("traceback_bytes", C.c_uint64),
+                ("ms_fill_class", C.c_float * 16), ("cells_class", C.c_uint64 * 16), ("units_class", C.c_uint32 * 16),
+                ("n_fill_classes", C.c_uint32)]
+
+
+# numpy view of the hit records (same layout as _OverlapHit): a whole triangle returns ~10^6 of them
+HIT_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("viterbi", "<f8"), ("score", "<f8"), ("x_start", "<u4"), ("x_end", "<u4"),
+                      ("y_start", "<u4"), ("y_end", "<u4"), ("n_columns", "<u4"), ("n_runs", "<u4"), ("run_offset", "<u8")])
+assert HIT_DTYPE.itemsize == C.sizeof(_OverlapHit)
+
+
 EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name", "qf_set_params_json", "qf_get_scores",
            "qf_set_null_json", "qf_get_lse_table", "qf_set_refs", "qf_upload_reads", "qf_align_resident",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
            "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks",
            "qf_device_count", "qf_set_score_threshold", "qf_comm_unique_id", "qf_comm_init_rank", "qf_comm_init_all",
-           "qf_comm_size", "qf_comm_destroy", "qf_allreduce_counts"]
+           "qf_comm_size", "qf_comm_destroy", "qf_allreduce_counts", "qf_overlap_rows", "qf_overlap_rows_pairs"]
 
 
 def load_library():
@@ -130,6 +152,10 @@ def load_library():
                                         C.POINTER(_CountResult)]
         L.qf_overlap_resident.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                           C.POINTER(_OverlapResult)]
+        L.qf_overlap_rows.argtypes = [C.c_void_p, C.POINTER(DPConfig), C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.POINTER(_OverlapRowsResult)]
+        L.qf_overlap_rows_pairs.restype = C.c_uint64
+        L.qf_overlap_rows_pairs.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.qf_counts_size.restype = C.c_uint32
         L.qf_counts_size.argtypes = [C.c_void_p]
         L.qf_fill_class_name.restype = C.c_char_p
@@ -417,6 +443,38 @@ class Context:
                                           "xEnd": al.x_end, "yStart": al.y_start, "yEnd": al.y_end,
                                           "ops": "".join("MID"[int(r) & 3] * (int(r) >> 2) for r in runs)}
         return out
+
+    def set_overlap_block_pairs(self, pairs):
+        """Tests only (csrc/qf_internal.h): pairs per internal row block of overlap_rows (0 = default)."""
+        self.L.qf_debug_set_overlap_block_pairs.argtypes = [C.c_void_p, C.c_uint64]
+        self._chk(self.L.qf_debug_set_overlap_block_pairs(self.h, pairs))
+
+    def overlap_rows(self, n_originals, x0, x1, cfg=None, raw=False):
+        """Rows [x0, x1) of QuaffOverlapScheduler's enumeration (src/qoverlap.cpp:475-480,528-547) over the resident set
+        (n_originals reads, optionally followed by their reverse complements): pairs enumerated, thresholded
+        (set_score_threshold) and reduced on the device.  Returns totals + the hits as a numpy record array (HIT_DTYPE, ordered
+        by (x, y)) + the concatenated state runs; raw=True returns the ctypes struct."""
+        cfg = cfg or DPConfig(kmer_threshold=14)
+        res = _OverlapRowsResult()
+        self._chk(self.L.qf_overlap_rows(self.h, C.byref(cfg), n_originals, x0, x1, C.byref(res)))
+        if raw:
+            return res
+        n = res.n_hits
+        hits = (np.frombuffer(C.string_at(res.hits, n * HIT_DTYPE.itemsize), dtype=HIT_DTYPE).copy() if n else np.zeros(0, HIT_DTYPE))
+        n_runs = int(hits["run_offset"][-1] + hits["n_runs"][-1]) if n else 0
+        runs = np.ctypeslib.as_array(res.state_runs, (n_runs,)).copy() if n_runs else np.zeros(0, np.uint32)
+        return {"n_pairs": int(res.n_pairs), "n_finite": int(res.n_finite), "total_cells": int(res.total_cells),
+                "total_diagonals": int(res.total_diagonals), "result_checksum": int(res.result_checksum), "hits": hits, "runs": runs,
+                "n_blocks": int(res.n_blocks), "traceback_bytes": int(res.traceback_bytes),
+                "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "fill", "traceback", "total")},
+                "classes": {k: {"ms": res.ms_fill_class[k], "cells": int(res.cells_class[k]), "units": int(res.units_class[k])}
+                            for k in range(res.n_fill_classes) if res.units_class[k]}}
+
+    @staticmethod
+    def hit_ops(hit, runs):
+        """State path of one hit ("M" / "I" / "D" per column) from the concatenated runs."""
+        r = runs[int(hit["run_offset"]):int(hit["run_offset"]) + int(hit["n_runs"])]
+        return "".join("MID"[int(v) & 3] * (int(v) >> 2) for v in r)
 
     def envelope(self, read, ref, cfg=None):
         cfg = cfg or DPConfig()

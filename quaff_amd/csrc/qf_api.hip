@@ -215,6 +215,13 @@ struct qf_ctx : Slot {
   HostBuf<double> h_ov_result, h_ov_score;
   std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
+  // qf_overlap_rows: no per-pair arrays come back; totals from the device's counters, hits accumulated over the row blocks
+  bool ov_per_pair = true;
+  bool ov_slot_collision = false;   // set by a chunk whose slotted single-diagonal list had a collision: plain lists for the rest of the call
+  struct OvTotals { uint64_t n_finite = 0, sum_ndiag = 0, result_sum = 0; } ov_tot;
+  uint64_t ov_block_pairs = 0;   // qf_debug_set_overlap_block_pairs: pairs per internal row block (0 = default)
+  std::vector<qf_overlap_hit> h_hits;
+  std::vector<uint32_t> h_hit_runs;
   // E-step reduction over RCCL (qf_comm_*): communicator, this context's rank, a device staging buffer
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_size = 1;
@@ -658,6 +665,7 @@ static int prep_reads(qf_ctx* c, int seed_k, hipStream_t side = nullptr) {
 static int check_cfg(qf_ctx* c, const qf_dp_config* cfg) {
   if (!c) return QF_ERR_ARG;
   if (!cfg) return fail(c, QF_ERR_ARG, "null config");
+  if (cfg->reserved) return fail(c, QF_ERR_ARG, "qf_dp_config.reserved must be 0 (kernel-variant switches: qf_debug_set_flags)");
   if (!c->have_params) return fail(c, QF_ERR_STATE, "no parameters set (qf_set_params_json)");
   if (!c->n_refs) return fail(c, QF_ERR_STATE, "no references set (qf_set_refs)");
   if (cfg->band_size < 0) return fail(c, QF_ERR_ARG, "negative band size");
@@ -727,8 +735,8 @@ static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_
   HIPCHK(S, S->d_sort_k.reserve((size_t)max_units * 4));
   HIPCHK(S, S->d_sort_v.reserve((size_t)max_units * 4));
   for (int cls = 0; cls < kNumClasses; ++cls) {
+    // (overlap sorts every list: bands by the columns they cross, the single-diagonal list into pair order)
     if (cls == kRowClass || bc.cls_count[cls] <= 64 || (cls == 0 && slotted_cls0)) continue;
-    (void)0;   // (overlap sorts every list: bands by the columns they cross, the single-diagonal list into pair order)
     const int rc = sort_class_list(S->d_cls_key.as<uint32_t>() + (size_t)cls * max_units, S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units,
                                    bc.cls_count[cls], S->d_sort_k.as<uint32_t>(), S->d_sort_v.as<uint32_t>(), &S->sort_tmp, &S->sort_tmp_cap,
                                    S->stream);
@@ -1689,7 +1697,9 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   const bool sparse = cfg->sparse != 0;
   const bool mem = sparse && cfg->kmer_threshold < 0;
   const Scores& sc = c->scores;
-  uint32_t max_units = n_pairs * 4 + 1024;
+  // Unit table: four bands per pair is the provision for arbitrary lists; a row block of the all-vs-all enumeration has barely
+  // more bands than pairs (nearly all of them the forced single diagonal), and seed_pairs grows the table if a block needs more.
+  uint32_t max_units = c->ov_per_pair ? n_pairs * 4 + 1024 : n_pairs + n_pairs / 4 + 65536;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
   // ---- seeding: x = pair_x's k-mer index, y = pair_y's k-mers (as stored)
@@ -1743,15 +1753,13 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       c->row_items_lo = lo; c->row_items_hi = hi; c->row_items_cl = cl; c->row_items_epoch = c->prep_epoch;
     }
     n_row_items = c->row_items_n;
-    if (n_row_items) {
-      HIPCHK(c, c->d_row_skip.reserve(n_pairs));
-      HIPCHK(c, hipMemsetAsync(c->d_row_skip.p, 0, n_pairs, c->stream));
-    }
+    if (n_row_items) HIPCHK(c, c->d_row_skip.reserve(n_pairs));
   }
   // Slotted single-diagonal list: x rows x0, x0 + 1, ... (the scheduler's order), at most one single-diagonal band per pair
   // (bands are at least 2 wide otherwise) and the staging kernel applies.
   uint32_t slot_rows = 0, slot_x0 = 0, slot_ychunks = 0;
-  if (c->ov_use_rows && cfg->band_size >= 2 && overlap_single_stages_rows(sc.Km) && !(c->debug & (QF_DEBUG_GLOBAL_OVERLAP_ROWS | QF_DEBUG_PAIR_ORDER_SINGLES))) {
+  if (c->ov_use_rows && cfg->band_size >= 2 && overlap_single_stages_rows(sc.Km) && !c->ov_slot_collision &&
+      !(c->debug & (QF_DEBUG_GLOBAL_OVERLAP_ROWS | QF_DEBUG_PAIR_ORDER_SINGLES))) {
     bool ok = true;
     uint32_t xa = 0, xb = 0, first = 1;
     for (const auto& r : c->ov_rows) {
@@ -1764,20 +1772,21 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     if (ok && !first && (uint64_t)(xb - xa + 1) * slot_ychunks * 256 <= (1ull << 28)) {
       slot_rows = xb - xa + 1;
       slot_x0 = xa;
-      const size_t bytes = (size_t)slot_rows * slot_ychunks * 256 * 4;
-      HIPCHK(c, c->d_slot_list.reserve(bytes));
-      HIPCHK(c, hipMemsetAsync(c->d_slot_list.p, 0xFF, bytes, c->stream));
+      HIPCHK(c, c->d_slot_list.reserve((size_t)slot_rows * slot_ychunks * 256 * 4));
     }
   }
   SeedArgs sa;
   BatchCounters bc;
   if (int rc = seed_pairs(c, c, cfg, n_pairs, mem, sparse ? max_nd : 2, [&](SeedArgs& s) {
+        // (cleared here, not once before: a batch that outgrows its unit table is seeded again from scratch)
         if (slot_rows) {
+          (void)hipMemsetAsync(c->d_slot_list.p, 0xFF, (size_t)slot_rows * slot_ychunks * 256 * 4, c->stream);
           s.slot_list = c->d_slot_list.as<uint32_t>();
           s.slot_x0 = slot_x0;
           s.slot_rows = slot_rows;
         }
         if (n_row_items) {
+          (void)hipMemsetAsync(c->d_row_skip.p, 0, n_pairs, c->stream);
           s.row_items = c->d_row_items.as<RowItem>();
           s.n_row_items = n_row_items;
           s.chunk_start = c->d_cstart.as<uint32_t>();
@@ -1803,6 +1812,10 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     for (uint8_t v : sk) c->rows_settled += v;
   }
   if (bc.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(bc.error_detail));
+  if ((bc.error & 16u) && slot_rows) {   // two bands claimed one slot (k_bin_units): this chunk again, single-diagonal bands as a plain list
+    c->ov_slot_collision = true;
+    return overlap_chunk(c, cfg, need, lo, hi, out, too_big);
+  }
   if (bc.error & 2u)
     return fail(c, QF_ERR_UNSUPPORTED, "unsupported overlap band of " + std::to_string(bc.error_detail) + " diagonals");
 
@@ -1846,6 +1859,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.Km = sc.Km;
   oa.Kg = sc.Kg;
   oa.pair_head = c->d_pair_head.as<uint32_t>();
+  oa.pair_ndiag = c->d_pair_ndiag.as<uint32_t>();
   oa.ins_sum = c->d_ins_sum.as<double>();
   oa.ins_sum_c = c->d_ins_sum_c.as<double>();
   oa.nll = c->d_nll.as<double>();
@@ -1880,15 +1894,20 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   HIPCHK(c, hipGetLastError());
   if (int rc = read_counters(c, bc)) return rc;
   const uint64_t total_runs = bc.total_runs_out;
+  c->ov_tot.n_finite += bc.n_finite;
+  c->ov_tot.sum_ndiag += bc.sum_ndiag;
+  c->ov_tot.result_sum += bc.result_sum;
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
 
   const size_t recs0 = c->h_recs.size(), runs0 = c->h_runs.size();
   c->h_recs.resize(recs0 + n_recs);
   c->h_runs.resize(runs0 + total_runs);
-  HIPCHK(c, hipMemcpyAsync(c->h_ov_result.data() + lo, c->d_pair_result.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_ov_score.data() + lo, c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + lo, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data() + lo, c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->ov_per_pair) {
+    HIPCHK(c, hipMemcpyAsync(c->h_ov_result.data() + lo, c->d_pair_result.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_ov_score.data() + lo, c->d_pair_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_cells.data() + lo, c->d_pair_cells.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_ndiag.data() + lo, c->d_pair_ndiag.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  }
   if (n_recs) HIPCHK(c, hipMemcpyAsync(c->h_recs.data() + recs0, c->d_recs.p, (size_t)n_recs * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
   if (total_runs) HIPCHK(c, hipMemcpyAsync(c->h_runs.data() + runs0, c->d_runs_out.p, (size_t)total_runs * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -1966,34 +1985,13 @@ static int prep_overlap_reads(qf_ctx* c, const qf_dp_config* cfg, int prep_k) {
   return QF_OK;
 }
 
-int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair_x, const uint32_t* pair_y,
-                        const uint8_t* y_comp, uint32_t n_pairs, qf_overlap_result* out) {
-  if (!c) return QF_ERR_ARG;
-  if (!cfg || !out) return fail(c, QF_ERR_ARG, "null argument");
-  if (!c->have_params) return fail(c, QF_ERR_STATE, "no parameters set (qf_set_params_json)");
-  if (cfg->band_size < 0) return fail(c, QF_ERR_ARG, "negative band size");
-  if (cfg->sparse && (cfg->kmer_len < 1 || cfg->kmer_len > 32)) return fail(c, QF_ERR_ARG, "kmer_len out of range");
-  HIPCHK(c, hipSetDevice(c->device));
-  memset(out, 0, sizeof *out);
-  out->n_pairs = n_pairs;
-  if (!n_pairs) return QF_OK;
-  if (!pair_x || !pair_y || !y_comp) return fail(c, QF_ERR_ARG, "null pair list");
-  if (n_pairs > kMaxPairsPerCall) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^28 pairs in one call");
+// Everything from the pair list to the host-side records.  `put_pairs` queues what leaves the list on the device (d_px / d_py /
+// d_pc: copies of the caller's arrays, or the enumeration kernel); c->ov_rows describes its runs (x, y0, y0 + 1, ...), or is
+// empty for an arbitrary list; c->ov_per_pair says whether the per-pair result arrays go back to the host.  Leaves the
+// alignment records in c->h_recs (AlignRec::read = index into the list) and their runs in c->h_runs.
+static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t n_pairs, qf_overlap_result* out,
+                       const std::function<int()>& put_pairs) {
   const uint32_t n_seqs = c->n_reads;
-  bool need[2] = {false, false};
-  c->ov_rows.clear();
-  c->rows_settled = 0;
-  bool runs = true;   // still looks like the scheduler's order: runs (x, y0), (x, y0 + 1), ... of 32+ pairs on average
-  for (uint32_t p = 0; p < n_pairs; ++p) {
-    if (pair_x[p] >= n_seqs || pair_y[p] >= n_seqs) return fail(c, QF_ERR_ARG, "pair index out of range");
-    need[y_comp[p] ? 1 : 0] = true;
-    if (!runs) continue;
-    if (!c->ov_rows.empty() && c->ov_rows.back().x == pair_x[p] && c->ov_rows.back().y0 + c->ov_rows.back().n == pair_y[p]) ++c->ov_rows.back().n;
-    else {
-      c->ov_rows.push_back({pair_x[p], pair_y[p], 1u, p});
-      if (c->ov_rows.size() > 4096 && (uint64_t)c->ov_rows.size() * 32 > p) { runs = false; c->ov_rows.clear(); }   // (an arbitrary list: do not keep a row per pair)
-    }
-  }
   const bool sparse = cfg->sparse != 0;
   if (int rc = ensure_lse(c)) return rc;
   const Scores& sc = c->scores;
@@ -2031,12 +2029,10 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   HIPCHK(c, c->d_px.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_py.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_pc.reserve((size_t)n_pairs));
-  HIPCHK(c, hipMemcpyAsync(c->d_px.p, pair_x, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_py.p, pair_y, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pc.p, y_comp, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+  if (int rc = put_pairs()) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
-  {
+  if (!prepped) {
     BatchCounters pb;
     if (int rc = read_counters(c, pb)) return rc;
     if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
@@ -2073,14 +2069,20 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
       c->ov_use_rows = true;
     }
   }
-  (void)hipEventElapsedTime(&out->ms_prep, c->ev[0], c->ev[1]);
-  out->ms_total = out->ms_prep;
-  c->h_ov_result.resize(n_pairs);
-  c->h_ov_score.resize(n_pairs);
-  c->h_cells.resize(n_pairs);
-  c->h_ndiag.resize(n_pairs);
+  float ms_prep = 0;
+  HIPCHK(c, hipEventSynchronize(c->ev[1]));
+  (void)hipEventElapsedTime(&ms_prep, c->ev[0], c->ev[1]);
+  out->ms_prep += ms_prep;
+  out->ms_total += ms_prep;
+  if (c->ov_per_pair) {
+    c->h_ov_result.resize(n_pairs);
+    c->h_ov_score.resize(n_pairs);
+    c->h_cells.resize(n_pairs);
+    c->h_ndiag.resize(n_pairs);
+  }
   c->h_recs.clear();
   c->h_runs.clear();
+  c->ov_slot_collision = false;
   std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n_pairs}};
   while (!todo.empty()) {
     const auto [lo, hi] = todo.back();
@@ -2093,6 +2095,55 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
       todo.push_back({lo, mid});
     }
   }
+  for (size_t a = 0; a < c->h_recs.size(); ++a)
+    if (!c->h_recs[a].ok)
+      return fail(c, QF_ERR_DEVICE, "overlap traceback did not reach the start state (pair " + std::to_string(c->h_recs[a].read) + ")");
+  return QF_OK;
+}
+
+static int check_overlap_call(qf_ctx* c, const qf_dp_config* cfg, const void* out) {
+  if (!c) return QF_ERR_ARG;
+  if (!cfg || !out) return fail(c, QF_ERR_ARG, "null argument");
+  if (cfg->reserved) return fail(c, QF_ERR_ARG, "qf_dp_config.reserved must be 0");
+  if (!c->have_params) return fail(c, QF_ERR_STATE, "no parameters set (qf_set_params_json)");
+  if (cfg->band_size < 0) return fail(c, QF_ERR_ARG, "negative band size");
+  if (cfg->sparse && (cfg->kmer_len < 1 || cfg->kmer_len > 32)) return fail(c, QF_ERR_ARG, "kmer_len out of range");
+  return QF_OK;
+}
+
+int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair_x, const uint32_t* pair_y,
+                        const uint8_t* y_comp, uint32_t n_pairs, qf_overlap_result* out) {
+  if (int rc = check_overlap_call(c, cfg, out)) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  out->n_pairs = n_pairs;
+  if (!n_pairs) return QF_OK;
+  if (!pair_x || !pair_y || !y_comp) return fail(c, QF_ERR_ARG, "null pair list");
+  if (n_pairs > kMaxPairsPerCall) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^28 pairs in one call");
+  const uint32_t n_seqs = c->n_reads;
+  bool need[2] = {false, false};
+  c->ov_rows.clear();
+  c->rows_settled = 0;
+  c->ov_per_pair = true;
+  c->ov_tot = qf_ctx::OvTotals();
+  bool runs = true;   // still looks like the scheduler's order: runs (x, y0), (x, y0 + 1), ... of 32+ pairs on average
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    if (pair_x[p] >= n_seqs || pair_y[p] >= n_seqs) return fail(c, QF_ERR_ARG, "pair index out of range");
+    need[y_comp[p] ? 1 : 0] = true;
+    if (!runs) continue;
+    if (!c->ov_rows.empty() && c->ov_rows.back().x == pair_x[p] && c->ov_rows.back().y0 + c->ov_rows.back().n == pair_y[p]) ++c->ov_rows.back().n;
+    else {
+      c->ov_rows.push_back({pair_x[p], pair_y[p], 1u, p});
+      if (c->ov_rows.size() > 4096 && (uint64_t)c->ov_rows.size() * 32 > p) { runs = false; c->ov_rows.clear(); }   // (an arbitrary list: do not keep a row per pair)
+    }
+  }
+  if (int rc = overlap_run(c, cfg, need, n_pairs, out, [&]() -> int {
+        HIPCHK(c, hipMemcpyAsync(c->d_px.p, pair_x, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_py.p, pair_y, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_pc.p, y_comp, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+        return QF_OK;
+      }))
+    return rc;
   const uint32_t n_recs = (uint32_t)c->h_recs.size();
   // records arrive in the device's completion order; a pair has at most one, so pair order is one scatter + one sweep
   c->h_ov_slot.assign(n_pairs, ~0u);
@@ -2102,7 +2153,6 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   for (uint32_t p = 0; p < n_pairs; ++p) {
     if (c->h_ov_slot[p] == ~0u) continue;
     const AlignRec& r = c->h_recs[c->h_ov_slot[p]];
-    if (!r.ok) return fail(c, QF_ERR_DEVICE, "overlap traceback did not reach the start state (pair " + std::to_string(r.read) + ")");
     qf_overlap_alignment& o = c->h_ov_align[n_out++];
     o.pair = r.read;
     o.viterbi = r.viterbi;
@@ -2120,6 +2170,116 @@ int qf_overlap_resident(qf_ctx* c, const qf_dp_config* cfg, const uint32_t* pair
   out->n_alignments = n_recs;
   out->alignments = c->h_ov_align.data();
   out->state_runs = c->h_runs.data();
+  return QF_OK;
+}
+
+uint64_t qf_overlap_rows_pairs(uint32_t n_seqs, uint32_t x0, uint32_t x1) {
+  if (x1 <= x0 || !n_seqs) return 0;
+  if (x1 > n_seqs - 1) x1 = n_seqs - 1;
+  if (x1 <= x0) return 0;
+  const uint64_t r = x1 - x0;
+  return r * (uint64_t)(n_seqs - 1 - x0) - r * (r - 1) / 2;
+}
+
+int qf_debug_set_overlap_block_pairs(qf_ctx* c, uint64_t pairs) {
+  if (!c) return QF_ERR_ARG;
+  c->ov_block_pairs = pairs;
+  return QF_OK;
+}
+
+// Rows [x0, x1) of QuaffOverlapScheduler's enumeration (src/qoverlap.cpp:475-480,528-547), in row blocks of about 2^24 pairs
+// (a block's per-pair tables and unit lists take ~400 bytes a pair; with a few million bands per class the latency-bound
+// classes of a block -- a hundred wide bands per 34 rows -- run beside enough single-diagonal work to vanish).
+int qf_overlap_rows(qf_ctx* c, const qf_dp_config* cfg, uint32_t n_originals, uint32_t x0, uint32_t x1,
+                    qf_overlap_rows_result* out) {
+  if (int rc = check_overlap_call(c, cfg, out)) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  out->x0 = x0;
+  out->x1 = x1;
+  const uint32_t n_seqs = c->n_reads;
+  if (!n_originals || (n_seqs != n_originals && n_seqs != 2 * (uint64_t)n_originals))
+    return fail(c, QF_ERR_ARG, "the resident set must be n_originals reads, optionally followed by their reverse complements");
+  if (x0 > x1 || x1 > n_originals - 1) return fail(c, QF_ERR_ARG, "rows out of range: 0 <= x0 <= x1 <= n_originals - 1");
+  c->rows_settled = 0;
+  c->ov_per_pair = false;
+  c->ov_tot = qf_ctx::OvTotals();
+  c->h_hits.clear();
+  c->h_hit_runs.clear();
+  const uint64_t want = c->ov_block_pairs ? c->ov_block_pairs : (1ull << 24);
+  std::vector<uint64_t> row_start;
+  for (uint32_t b0 = x0; b0 < x1;) {
+    // rows of this block: as many as stay under the pair target (at least one; a row has fewer than 2^28 pairs by the
+    // library's own limit on resident sequences), at most what one launch of the enumeration kernel takes
+    uint32_t b1 = b0;
+    uint64_t np = 0;
+    row_start.clear();
+    while (b1 < x1 && b1 - b0 < 32768u) {
+      const uint64_t len = n_seqs - 1 - b1;
+      if (b1 > b0 && np + len > want) break;
+      if (np + len > kMaxPairsPerCall) break;
+      row_start.push_back(np);
+      np += len;
+      ++b1;
+    }
+    if (b1 == b0) return fail(c, QF_ERR_UNSUPPORTED, "a row of more than 2^28 pairs");
+    const uint32_t n_pairs = (uint32_t)np;
+    bool need[2] = {b0 + 1 < n_originals, n_seqs > n_originals};   // (a row's ny run from nx + 1 to n_seqs - 1)
+    c->ov_rows.clear();
+    for (uint32_t x = b0; x < b1; ++x)
+      if (n_seqs - 1 - x) c->ov_rows.push_back({x, x + 1, n_seqs - 1 - x, (uint32_t)row_start[x - b0]});
+    qf_overlap_result blk;
+    memset(&blk, 0, sizeof blk);
+    if (n_pairs) {
+      if (int rc = overlap_run(c, cfg, need, n_pairs, &blk, [&]() -> int {
+            launch_overlap_row_pairs(b0, b1 - b0, n_seqs, n_originals, c->d_px.as<uint32_t>(), c->d_py.as<uint32_t>(), c->d_pc.as<uint8_t>(),
+                                     c->stream);
+            HIPCHK(c, hipGetLastError());
+            return QF_OK;
+          }))
+        return rc;
+    }
+    // this block's records -> hits in (x, y) order
+    const size_t n_recs = c->h_recs.size();
+    std::vector<uint32_t> idx(n_recs);
+    for (size_t a = 0; a < n_recs; ++a) idx[a] = (uint32_t)a;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t p, uint32_t q) { return c->h_recs[p].read < c->h_recs[q].read; });
+    for (size_t k = 0; k < n_recs; ++k) {
+      const AlignRec& r = c->h_recs[idx[k]];
+      const size_t row = std::upper_bound(row_start.begin(), row_start.end(), (uint64_t)r.read) - row_start.begin() - 1;
+      qf_overlap_hit h;
+      h.x = b0 + (uint32_t)row;
+      h.y = h.x + 1 + (uint32_t)(r.read - row_start[row]);
+      h.viterbi = r.viterbi;
+      h.score = r.score;
+      h.x_start = r.x_start; h.x_end = r.x_end; h.y_start = r.y_start; h.y_end = r.y_end;
+      h.n_columns = r.n_columns;
+      h.n_runs = r.n_runs;
+      h.run_offset = c->h_hit_runs.size();
+      c->h_hit_runs.insert(c->h_hit_runs.end(), c->h_runs.data() + r.run_off, c->h_runs.data() + r.run_off + r.n_runs);
+      c->h_hits.push_back(h);
+    }
+    out->n_pairs += n_pairs;
+    out->total_cells += blk.total_cells;
+    out->traceback_bytes += blk.traceback_bytes;
+    out->ms_prep += blk.ms_prep; out->ms_seed += blk.ms_seed; out->ms_fill += blk.ms_fill;
+    out->ms_traceback += blk.ms_traceback; out->ms_total += blk.ms_total;
+    for (int k = 0; k < kNumClasses; ++k) {
+      out->ms_fill_class[k] += blk.ms_fill_class[k];
+      out->cells_class[k] += blk.cells_class[k];
+      out->units_class[k] += blk.units_class[k];
+    }
+    ++out->n_blocks;
+    b0 = b1;
+  }
+  if (c->h_hits.size() > 0xFFFFFFFFull) return fail(c, QF_ERR_UNSUPPORTED, "more than 2^32 alignments in one call");
+  out->n_fill_classes = kNumClasses;
+  out->n_finite = c->ov_tot.n_finite;
+  out->total_diagonals = c->ov_tot.sum_ndiag;
+  out->result_checksum = c->ov_tot.result_sum;
+  out->n_hits = (uint32_t)c->h_hits.size();
+  out->hits = c->h_hits.data();
+  out->state_runs = c->h_hit_runs.data();
   return QF_OK;
 }
 

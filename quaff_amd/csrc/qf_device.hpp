@@ -168,7 +168,7 @@ struct BatchCounters {
   uint32_t n_units;
   uint32_t n_ovf;           // bands spilled past kMaxBandsPerPair
   uint32_t cls_count[kNumClasses];
-  uint32_t error;          // bit 0: unit overflow, 1: band too wide, 2: bad symbol, 3: > kMaxBandsPerPair bands
+  uint32_t error;          // bit 0: unit overflow, 1: band too wide, 2: bad symbol, 3: > kMaxBandsPerPair bands, 4: two bands claimed one slot of the slotted list
   uint32_t error_detail;
   unsigned long long tb_words;
   unsigned long long total_cells;
@@ -176,6 +176,10 @@ struct BatchCounters {
   uint32_t n_align;
   unsigned long long n_runs;          // scratch run capacity reserved by the select kernel
   unsigned long long total_runs_out;  // compacted CIGAR runs written by the traceback kernel
+  // overlap totals (k_overlap_finalize): what qf_overlap_rows reports instead of per-pair arrays
+  unsigned long long n_finite;        // pairs with a finite result
+  unsigned long long sum_ndiag;       // envelope diagonals over all pairs
+  unsigned long long result_sum;      // sum of the finite results' bit patterns, mod 2^64
 };
 
 constexpr int kLsePieces = 1281;   // quadratic pieces of log(1 + exp(-x)) on a 1/128 grid over [0, 10) + the all-zero piece of the cut-off

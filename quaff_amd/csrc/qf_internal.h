@@ -34,6 +34,10 @@ uint32_t qf_debug_lse_pack_bytes(qf_ctx *ctx);
  * the per-pair kernel); counted only under QF_DEBUG_COUNT_SETTLED. */
 uint64_t qf_debug_rows_settled(const qf_ctx *ctx);
 
+/* qf_overlap_rows cuts its rows into blocks of about this many pairs (0 = the default, 2^24); tests use small values to push a
+ * small read set through many blocks. */
+int qf_debug_set_overlap_block_pairs(qf_ctx *ctx, uint64_t pairs);
+
 #ifdef __cplusplus
 }
 #endif

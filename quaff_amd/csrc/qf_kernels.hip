@@ -1033,7 +1033,10 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
   }
   if (a.slot_list && cls == 0) {   // overlap: single-diagonal bands by (y chunk, x row, y), so that a workgroup is one x against 256 consecutive y
     const uint32_t x = a.pair_x[pair], y = a.pair_y[pair];
-    a.slot_list[((uint64_t)(y >> 8) * a.slot_rows + (x - a.slot_x0)) * 256 + (y & 255u)] = uid;
+    // The host admits the slotted list only for lists in which (x, y) is unique and a pair has one single-diagonal band; should
+    // that ever not hold, the second claimant of a slot raises error bit 4 and the host redoes the chunk with the plain list.
+    if (atomicCAS(&a.slot_list[((uint64_t)(y >> 8) * a.slot_rows + (x - a.slot_x0)) * 256 + (y & 255u)], kNoUnit, uid) != kNoUnit)
+      atomicOr(&a.bc->error, 16u);
   } else
     a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;
   // sort key of the class lists (descending): read length = steps of the fill; overlap: the columns the band crosses, and its

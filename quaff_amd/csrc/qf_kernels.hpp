@@ -164,6 +164,7 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   uint32_t Km, Kg;
   // finalize / traceback
   const uint32_t* pair_head;
+  const uint32_t* pair_ndiag;   // envelope diagonals of each pair (summed into BatchCounters::sum_ndiag)
   const double* ins_sum;
   const double* ins_sum_c;
   const double* nll;
@@ -263,6 +264,9 @@ bool overlap_single_stages_rows(uint32_t Km);   // the single-diagonal kernel th
 // entries of the exact log-sum-exp table that its packed form (qf_device.hpp) does not reproduce on this device; ~0u on a HIP error
 uint32_t lse_pack_mismatches(const uint8_t* pack, uint32_t pack_bytes, const double* tab, uint32_t* d_bad, hipStream_t s);
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s);
+// (x, y, yComplemented) of rows [x0, x0 + rows) of QuaffOverlapScheduler's enumeration over n_seqs resident sequences, row-major
+void launch_overlap_row_pairs(uint32_t x0, uint32_t rows, uint32_t n_seqs, uint32_t n_orig, uint32_t* px, uint32_t* py, uint8_t* pc,
+                              hipStream_t s);
 void launch_overlap_traceback(const OvArgs& a, hipStream_t s);
 void launch_select(const FinalArgs& a, hipStream_t s);
 void launch_traceback(const FinalArgs& a, hipStream_t s);

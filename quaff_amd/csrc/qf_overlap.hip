@@ -7,6 +7,8 @@
 // literally.  Bit-exact: the log-sum-exp uses the host-built table with IEEE division, as src/logsumexp.cpp does.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "qf_dpp.hpp"
 #include "qf_kernels.hpp"
 
@@ -722,42 +724,82 @@ __global__ __launch_bounds__(64) void k_overlap_rows(OvArgs a) {
 // End cell (src/qoverlap.cpp:164-182): start from mat(xLen,yLen), scan the last read column downwards, then the last
 // reference row, replacing only on strict '>'.  result = end + xInsertScore + yInsertScore (:157); adjusted score
 // subtracts both reads' null log-likelihoods (:292-302).
+// 64-bit sum over the wavefront's lanes; the result is valid in every lane
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += (unsigned long long)__shfl_xor((long long)v, m, 64);
+  return v;
+}
+
 __global__ void k_overlap_finalize(OvArgs a) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.n_pairs) return;
-  const uint32_t x = a.pair_x[p], y = a.pair_y[p], comp = a.pair_comp[p];
-  const uint32_t xLen = (uint32_t)(a.seq_off[x + 1] - a.seq_off[x]), yLen = (uint32_t)(a.seq_off[y + 1] - a.seq_off[y]);
-  double cb = QF_NEG_INF, rb = QF_NEG_INF;
-  uint32_t ci = 0, cu = kNoUnit, rj = 0, ru = kNoUnit;
-  for (uint32_t uid = a.pair_head[p]; uid != kNoUnit; uid = a.units[uid].next) {
-    const Unit& u = a.units[uid];
-    if (u.end_val > cb || (u.end_val == cb && u.end_val > QF_NEG_INF && u.end_i > ci)) { cb = u.end_val; ci = u.end_i; cu = uid; }
-    if (u.end2_val > rb || (u.end2_val == rb && u.end2_val > QF_NEG_INF && u.end2_j > rj)) { rb = u.end2_val; rj = u.end2_j; ru = uid; }
+  const bool live = p < a.n_pairs;
+  unsigned long long t_finite = 0, t_ndiag = 0, t_bits = 0;
+  if (live) {
+    const uint32_t x = a.pair_x[p], y = a.pair_y[p], comp = a.pair_comp[p];
+    const uint32_t xLen = (uint32_t)(a.seq_off[x + 1] - a.seq_off[x]), yLen = (uint32_t)(a.seq_off[y + 1] - a.seq_off[y]);
+    double cb = QF_NEG_INF, rb = QF_NEG_INF;
+    uint32_t ci = 0, cu = kNoUnit, rj = 0, ru = kNoUnit;
+    for (uint32_t uid = a.pair_head[p]; uid != kNoUnit; uid = a.units[uid].next) {
+      const Unit& u = a.units[uid];
+      if (u.end_val > cb || (u.end_val == cb && u.end_val > QF_NEG_INF && u.end_i > ci)) { cb = u.end_val; ci = u.end_i; cu = uid; }
+      if (u.end2_val > rb || (u.end2_val == rb && u.end2_val > QF_NEG_INF && u.end2_j > rj)) { rb = u.end2_val; rj = u.end2_j; ru = uid; }
+    }
+    double end = cb;
+    uint32_t ei = ci, ej = yLen, eu = cu;
+    if (rb > cb) { end = rb; ei = xLen; ej = rj; eu = ru; }
+    const double yins = comp ? a.ins_sum_c[y] : a.ins_sum[y];
+    const double result = end + a.ins_sum[x] + yins;
+    a.pair_result[p] = result;
+    double score = result - a.nll[x];
+    score -= comp ? a.nll_c[y] : a.nll[y];
+    a.pair_score[p] = score;
+    a.pair_end_unit[p] = end > QF_NEG_INF ? eu : kNoUnit;
+    a.pair_end_ij[2 * p] = ei;
+    a.pair_end_ij[2 * p + 1] = ej;
+    t_ndiag = a.pair_ndiag[p];
+    if (end > QF_NEG_INF) {
+      t_finite = 1;
+      t_bits = (unsigned long long)__double_as_longlong(result);
+    }
+    if (end > QF_NEG_INF && score >= a.min_score) {
+      const Unit& u = a.units[eu];
+      const uint32_t cap = xLen + yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
+      const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
+      AlignRec rec{};
+      rec.read = p;  // pair index
+      rec.ref = x;
+      rec.unit = eu;
+      rec.viterbi = result;
+      rec.score = score;
+      rec.tmp_off = atomicAdd(&a.bc->n_runs, (unsigned long long)cap);
+      a.recs[idx] = rec;
+    }
   }
-  double end = cb;
-  uint32_t ei = ci, ej = yLen, eu = cu;
-  if (rb > cb) { end = rb; ei = xLen; ej = rj; eu = ru; }
-  const double yins = comp ? a.ins_sum_c[y] : a.ins_sum[y];
-  const double result = end + a.ins_sum[x] + yins;
-  a.pair_result[p] = result;
-  double score = result - a.nll[x];
-  score -= comp ? a.nll_c[y] : a.nll[y];
-  a.pair_score[p] = score;
-  a.pair_end_unit[p] = end > QF_NEG_INF ? eu : kNoUnit;
-  a.pair_end_ij[2 * p] = ei;
-  a.pair_end_ij[2 * p + 1] = ej;
-  if (end > QF_NEG_INF && score >= a.min_score) {
-    const Unit& u = a.units[eu];
-    const uint32_t cap = xLen + yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
-    const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
-    AlignRec rec{};
-    rec.read = p;  // pair index
-    rec.ref = x;
-    rec.unit = eu;
-    rec.viterbi = result;
-    rec.score = score;
-    rec.tmp_off = atomicAdd(&a.bc->n_runs, (unsigned long long)cap);
-    a.recs[idx] = rec;
+  // totals over the pairs (what the row-block entry point reports instead of per-pair arrays): one atomic per wavefront each
+  t_finite = wave_sum_u64(t_finite);
+  t_ndiag = wave_sum_u64(t_ndiag);
+  t_bits = wave_sum_u64(t_bits);
+  if ((threadIdx.x & 63) == 0) {
+    if (t_finite) atomicAdd(&a.bc->n_finite, t_finite);
+    if (t_ndiag) atomicAdd(&a.bc->sum_ndiag, t_ndiag);
+    if (t_bits) atomicAdd(&a.bc->result_sum, t_bits);
+  }
+}
+
+// The scheduler's pair enumeration for rows [x0, x0 + rows) (QuaffOverlapScheduler::advance, src/qoverlap.cpp:475-480): row nx
+// holds ny = nx + 1 ... n_seqs - 1, yComplemented = ny >= nOriginals (:540).  blockIdx.y = row; pair index = pairs of the
+// earlier rows + (ny - nx - 1).
+__global__ void k_overlap_row_pairs(uint32_t x0, uint32_t n_seqs, uint32_t n_orig, uint32_t* __restrict__ px,
+                                    uint32_t* __restrict__ py, uint8_t* __restrict__ pc) {
+  const uint32_t r = blockIdx.y, x = x0 + r;
+  const uint32_t len = n_seqs - 1 - x;
+  const unsigned long long base = (unsigned long long)r * (n_seqs - 1 - x0) - (unsigned long long)r * (r - 1) / 2;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < len; q += gridDim.x * blockDim.x) {
+    const uint32_t y = x + 1 + q;
+    px[base + q] = x;
+    py[base + q] = y;
+    pc[base + q] = y >= n_orig;
   }
 }
 
@@ -875,6 +917,13 @@ void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s) {
 }
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s) {
   if (a.n_pairs) hipLaunchKernelGGL(k_overlap_finalize, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_overlap_row_pairs(uint32_t x0, uint32_t rows, uint32_t n_seqs, uint32_t n_orig, uint32_t* px, uint32_t* py, uint8_t* pc,
+                              hipStream_t s) {
+  if (!rows) return;
+  const uint32_t longest = n_seqs - 1 - x0;
+  const uint32_t bx = std::max(1u, std::min(64u, (longest + 255) / 256));
+  hipLaunchKernelGGL(k_overlap_row_pairs, dim3(bx, rows), dim3(256), 0, s, x0, n_seqs, n_orig, px, py, pc);
 }
 void launch_overlap_traceback(const OvArgs& a, hipStream_t s) {
   if (a.n_recs) hipLaunchKernelGGL(k_overlap_traceback, dim3((a.n_recs + 63) / 64), dim3(64), 0, s, a);

@@ -85,26 +85,72 @@ def _job(workload, *extra):
     return job
 
 
-def test_config5_full_dp_100kb_by_5kb():
-    """-kmatchoff, 100 kb reference (+ reverse complement) x 5 kb reads: 49 stripes of the row-space Viterbi kernel per pair.
-    Two reads x both strands against the oracle with == (score, strand choice, coordinates, CIGAR: 4 x 5e8 cells on the CPU);
-    every alignment of a 64-read batch re-scored along its path with the oracle's O(path) recurrence."""
-    job = _job("fulldp", "--reads", "64")
-    cells = job.step()
-    assert cells == 2 * 100000 * int(np.diff(job.off).sum())
-    cpu = job.cpu_baseline(2, 4, job.ctx.align_resident(job.cfg, 0, reads_below=2), cfg_kw=dict(sparse=False))
-    assert cpu["gpu_parity_mismatches"] == 0, cpu
-    res = job.ctx.align_resident(job.cfg, 0)
-    assert len(res["alignments"]) == 64
+def test_config5_full_dp_all_10000_reads():
+    """BASELINE config 5 at its stated extent: -kmatchoff, 100 kb reference (+ reverse complement) x 10 000 x 5 kb reads = 1e13 cells,
+    49 stripes of the row-space Viterbi kernel per pair, the batch cut into pieces by the device's memory (its 5 TB of packed
+    traceback does not fit at once: the budget-halving path under a full batch).  On every read: one alignment, on its true
+    strand, better than the other strand, CIGAR accounting; the cell total equals the closed form.  The first 64 alignments equal
+    those of the same reads run alone (other pieces, same bits) and are re-scored along their paths with the oracle's O(path)
+    recurrence; two reads x both strands against the full oracle with == (4 x 5e8 cells on the CPU)."""
+    import time
+    import quaff_amd as Q
+    from quaff_amd import api
+    job = _job("fulldp")
+    assert job.n == 10000
+    t0 = time.time()
+    raw = job.ctx.align_resident(job.cfg, 0, raw=True)
+    print("config 5: 10 000 reads, %.3e cells in %.1f s (%.3e cells/s)" % (raw.total_cells, time.time() - t0, raw.total_cells / (time.time() - t0)))
+    n = job.n
+    lens = np.diff(job.off).astype(np.int64)
+    assert int(raw.total_cells) == 2 * 100000 * int(lens.sum()) and raw.total_cells > 9.5e12
+    assert raw.n_alignments == n
+    vit = np.ctypeslib.as_array(raw.viterbi, (2 * n,)).reshape(n, 2).copy()
+    cells = np.ctypeslib.as_array(raw.cells, (2 * n,)).reshape(n, 2)
+    assert np.array_equal(cells, np.repeat((100000 * lens)[:, None], 2, axis=1).astype(np.uint64))
+    from quaff_amd.api import _Alignment
+    AL = np.dtype([("read", "<u4"), ("ref", "<u4"), ("viterbi", "<f8"), ("score", "<f8"), ("x_start", "<u4"), ("x_end", "<u4"),
+                   ("n_columns", "<u4"), ("n_runs", "<u4"), ("run_offset", "<u8")])
+    import ctypes as C
+    assert AL.itemsize == C.sizeof(_Alignment)
+    al = np.frombuffer(C.string_at(raw.alignments, n * AL.itemsize), dtype=AL).copy()
+    assert np.array_equal(al["read"], np.arange(n)) and np.array_equal(al["ref"], np.arange(n) & 1)   # the generator reverse-complements odd reads
+    assert np.array_equal(al["viterbi"], vit[np.arange(n), al["ref"]]) and np.all(al["viterbi"] > vit[np.arange(n), 1 - al["ref"]])
+    assert np.all((1 <= al["x_start"]) & (al["x_start"] <= al["x_end"]) & (al["x_end"] <= 100000))
+    n_runs = int(al["run_offset"].max() + al["n_runs"][np.argmax(al["run_offset"])])
+    runs = np.ctypeslib.as_array(raw.cigar_runs, (n_runs,)).copy()
+    order = np.argsort(al["run_offset"], kind="stable")
+    starts = al["run_offset"][order].astype(np.int64)
+    assert np.array_equal(starts[1:], starts[:-1] + al["n_runs"][order][:-1]) and starts[0] == 0      # the runs tile the array
+    ops, ln = runs & 3, (runs >> 2).astype(np.int64)
+    seg = lambda v: np.add.reduceat(v, starts)
+    y_used, x_used, cols = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
+    y_used[order], x_used[order], cols[order] = seg(ln * (ops != 2)), seg(ln * (ops != 1)), seg(ln)
+    assert np.array_equal(y_used, lens) and np.array_equal(x_used, al["x_end"].astype(np.int64) - al["x_start"] + 1)
+    assert np.array_equal(cols, al["n_columns"])
+    first = {r: (int(al["ref"][r]), al["viterbi"][r], al["score"][r], int(al["x_start"][r]), int(al["x_end"][r]),
+                 "".join("MID"[int(o)] * int(l) for o, l in zip(ops[int(al["run_offset"][r]):int(al["run_offset"][r] + al["n_runs"][r])],
+                                                                ln[int(al["run_offset"][r]):int(al["run_offset"][r] + al["n_runs"][r])])))
+             for r in range(64)}
+    # the same 64 reads alone (one piece instead of a slice of a 300-read piece): bit-identical records
+    small = Q.Context(0)
+    small.set_params_json(None)
+    small.set_null_json(open(os.path.join(GOLDEN, "testquaffnullparams.json")).read())
+    small.set_refs([job.ref, api.revcomp(job.ref)])
+    b1 = int(job.off[64])
+    small.upload_reads_packed(job.seq[:b1], job.qual[:b1], job.off[:65].copy())
+    res = small.align_resident(job.cfg, 0)
+    small.close()
     sc = O.Scores(O.Params.from_json(open(os.path.join(GOLDEN, "defaultparams.json")).read()))
     xf = O.FastSeq("ref", job.ref.decode())
     xtoks = [O.tokens(xf.seq), O.tokens(xf.revcomp().seq)]
-    for al in res["alignments"]:
-        r = al["read"]
-        assert al["ref"] == (r & 1)                                      # the generator reverse-complements odd reads
+    assert len(res["alignments"]) == 64
+    for a in res["alignments"]:
+        r = a["read"]
+        assert (a["ref"], a["viterbi"], a["score"], a["xStart"], a["xEnd"], a["ops"]) == first[r], r
         rd = O.FastSeq("r", job.seq[int(job.off[r]):int(job.off[r + 1])].decode(), job.qual[int(job.off[r]):int(job.off[r + 1])].decode())
-        assert O.rescore_path(xtoks[al["ref"]], O.ReadCtx(rd, sc), sc, al["xStart"], al["ops"]) == al["viterbi"], r
-        assert al["viterbi"] == res["viterbi"][r, al["ref"]] and al["viterbi"] > res["viterbi"][r, 1 - al["ref"]]
+        assert O.rescore_path(xtoks[a["ref"]], O.ReadCtx(rd, sc), sc, a["xStart"], a["ops"]) == a["viterbi"], r
+    cpu = job.cpu_baseline(2, 4, res, cfg_kw=dict(sparse=False))
+    assert cpu["gpu_parity_mismatches"] == 0, cpu
     job.ctx.close()
 
 
@@ -168,21 +214,69 @@ def test_config4_train_estep_20k_reads_order2():
     job.ctx.close()
 
 
-def test_config3_overlap_block_of_50k_reads():
-    """quaff overlap, 50 000 x 2 kb reads of a 1 Mb genome, both strands: rows 0..33 of the all-vs-all pair triangle (3.4 M pairs).
-    Every pair that yields an alignment with score >= 0 and a random 2 000 of the others against the oracle with ==."""
-    job = _job("overlap")
+def test_config3_whole_pair_triangle_of_50k_reads():
+    """BASELINE config 3 at its stated extent: quaff overlap, 50 000 x 2 kb reads of a 1 Mb genome, both strands, ALL 49 999 rows of
+    the scheduler's pair triangle (3 749 925 000 pairs) through qf_overlap_rows, the pairs enumerated and thresholded on the
+    device.  On everything: pair count = closed form; every pair has a finite result (the forced diagonal); every returned
+    alignment scores >= 0, lies inside its reads, accounts for its CIGAR, and the list is in the scheduler's order.  The
+    sampled rows (first 34, last 34 -- the short rows of the triangle -- and 24 between) give the same records alone as inside
+    their block, and every one of their alignments, plus 10 000 random pairs through the pair-list entry point, == the oracle
+    (bench.py's parity leg)."""
+    import time
+    job = _job("overlap", "--inflight", "2")
+    n, total = job.n, 2 * job.n
+    assert (n, job.rows) == (50000, 49999) and job.n_pairs == 3749925000
+    ctx = job.ctxs[0]
+    t0 = time.time()
+    tot = {k: 0 for k in ("n_pairs", "n_finite", "total_cells", "total_diagonals", "n_blocks")}
+    checksum = 0
+    hits, runs, run_base = [], [], 0
+    for b0, b1 in job.blocks:
+        res = ctx.overlap_rows(n, b0, b1, job.cfg)
+        for k in tot:
+            tot[k] += res[k]
+        checksum = (checksum + res["result_checksum"]) & ((1 << 64) - 1)
+        h = res["hits"]
+        h["run_offset"] += run_base
+        run_base += len(res["runs"])
+        hits.append(h)
+        runs.append(res["runs"])
+    hits, runs = np.concatenate(hits), np.concatenate(runs)
+    dt = time.time() - t0
+    print("config 3: whole triangle, %d pairs, %.3e cells, %d alignments in %.1f s on one context (%.3e cells/s, %.3e pairs/s)"
+          % (tot["n_pairs"], tot["total_cells"], len(hits), dt, tot["total_cells"] / dt, tot["n_pairs"] / dt))
+    assert tot["n_pairs"] == 3749925000 == ctx.L.qf_overlap_rows_pairs(total, 0, n - 1)
+    assert tot["n_finite"] == tot["n_pairs"]                       # diagonal 0 is always in the envelope
+    assert tot["total_diagonals"] >= tot["n_pairs"] and tot["total_cells"] > 1900 * tot["n_pairs"]
+    assert len(hits) > 1_000_000                                   # ~100x coverage: ~40 true overlaps per row and strand
+    lens = np.array([len(s) for s in job.seqs], np.int64)
+    x, y = hits["x"].astype(np.int64), hits["y"].astype(np.int64)
+    assert np.all((x < y) & (x < n - 1) & (y < total)) and np.all(np.diff(x * total + y) > 0)   # the scheduler's order, no pair twice
+    assert np.all(hits["score"] >= 0) and np.all(np.isfinite(hits["viterbi"]))
+    assert np.all((1 <= hits["x_start"]) & (hits["x_start"] <= hits["x_end"] + 1) & (hits["x_end"] <= lens[x]))
+    assert np.all((1 <= hits["y_start"]) & (hits["y_start"] <= hits["y_end"] + 1) & (hits["y_end"] <= lens[y]))
+    starts = hits["run_offset"].astype(np.int64)
+    assert starts[0] == 0 and np.array_equal(starts[1:], starts[:-1] + hits["n_runs"][:-1]) and starts[-1] + hits["n_runs"][-1] == len(runs)
+    ops, ln = runs & 3, (runs >> 2).astype(np.int64)
+    seg = lambda v: np.add.reduceat(v, starts)
+    assert np.array_equal(seg(ln * (ops != 1)), hits["x_end"].astype(np.int64) - hits["x_start"] + 1)    # M + D = x span
+    assert np.array_equal(seg(ln * (ops != 2)), hits["y_end"].astype(np.int64) - hits["y_start"] + 1)    # M + I = y span
+    assert np.array_equal(seg(ln), hits["n_columns"])
+    # an overlap ends at an end of one of the reads on each side (both ends are free, src/qoverlap.cpp:141,153)
+    assert np.all((hits["x_end"] == lens[x]) | (hits["y_end"] == lens[y]))
+    # sampled rows alone == the same rows inside their blocks (other blocking, other y chunks in flight)
+    rng = np.random.default_rng(5)
+    fields = ["x", "y", "viterbi", "score", "x_start", "x_end", "y_start", "y_end", "n_columns", "n_runs"]
+    for r in job.sample_rows(rng):
+        alone = ctx.overlap_rows(n, r, r + 1, job.cfg)
+        sel = hits[hits["x"] == r]
+        assert np.array_equal(alone["hits"][fields], sel[fields]), r
+        if len(sel):
+            assert np.array_equal(alone["runs"], runs[int(sel["run_offset"][0]):int(sel["run_offset"][-1] + sel["n_runs"][-1])]), r
+    # the timed step of the bench (raw results, two contexts pulling blocks off one list) sees the same totals
     cells = job.step()
-    xs, ys, cs = job.pairs
-    assert len(xs) == sum(2 * 50000 - 1 - r for r in range(34)) and cells > 6e9
-    cpu = job.cpu_baseline(2000, 8)
+    assert cells == tot["total_cells"] and job.tot["n_hits"] == len(hits) and job.tot["checksum"] == checksum
+    cpu = job.cpu_baseline(10000, 8)
     assert cpu["gpu_parity_mismatches"] == 0, cpu
-    res = job.ctx.overlap_resident(job.pairs, job.cfg)
-    assert len(res["alignments"]) > 1000                               # ~100x coverage: ~40 true overlaps per row and strand
-    assert int(res["cells"].sum()) == res["total_cells"] == cells
-    for p, al in res["alignments"].items():
-        assert al["score"] >= 0 and al["score"] == res["score"][p]
-        ops = al["ops"]
-        assert ops.count("M") + ops.count("D") == al["xEnd"] - al["xStart"] + 1
-        assert ops.count("M") + ops.count("I") == al["yEnd"] - al["yStart"] + 1
-    job.ctx.close()
+    for c in job.ctxs:
+        c.close()
