@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_PEAK_TOPS = 39.3         # 256 CUs x 4 SIMDs x 16 fp64 lanes x 2.4 GHz (= the 78.6 TFLOP/s FMA peak / 2)
+MEASURED_F64_TOPS = None     # set by main(): the fp64 add rate this device sustains (T lane-operations/s), measured live
 BYTES_PER_CELL = 24.0        # 3 fp64 states per DP cell
 # fp64-rate operations the recurrence needs per cell, whatever the kernel ("arithmetic floors")
 F64_OPS_PER_CELL = {"viterbi": 20.0, "forward": 65.0, "backward": 101.0, "overlap": 52.0, "overlap_single": 3.0}
@@ -128,21 +129,31 @@ def cpu_threads(a):
 
 
 def pmc_for(workload, kernel_prefix):
-    """HBM bytes per launch and issue counters of one kernel from the committed rocprofv3 --pmc summaries of this build
-    (profiles/r02_pmc_<workload>.json, written by tools/pmc_summary.py); None when there is no capture for it."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch and issue counters of one kernel from the newest committed rocprofv3 --pmc summary of this workload
+    (profiles/r<NN>_pmc_<workload>.json, written by tools/pmc_summary.py): (row, provenance) or (None, None).  These are NOT
+    measured in the run that prints them -- counter passes serialise kernels and need the profiler -- so they are replayed,
+    labelled as such, and only while the device code is still the one they were captured on (`source_hash`)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % workload)))
+    if not paths:
+        return None, None
+    doc = json.load(open(paths[-1]))
+    from quaff_amd import api
+    prov = {"file": os.path.relpath(paths[-1], ROOT), "captured_on_source_hash": doc.get("source_hash"), "captured_at_git": doc.get("git_head"),
+            "current_source_hash": api.kernel_source_hash()}
+    if doc.get("source_hash") != prov["current_source_hash"]:
+        prov["stale"] = True           # the kernels changed since the capture: nothing is replayed
+        return None, prov
     want = kernel_prefix.replace(" ", "")
-    rows = json.load(open(path)).get("kernels", [])
+    rows = doc.get("kernels", [])
     for k in rows:
         if want in k["kernel"].replace(" ", ""):
-            return k
+            return k, prov
     if want.endswith(">"):            # a template whose trailing arguments the caller did not spell out
         for k in rows:
             if want[:-1] + "," in k["kernel"].replace(" ", ""):
-                return k
-    return None
+                return k, prov
+    return None, prov
 
 
 # Bytes a kernel that does not materialise the matrix still has to stream per cell (DESIGN.md 4): a single-diagonal overlap band
@@ -159,9 +170,10 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     alg_gbs = BYTES_PER_CELL * cells / t / 1e9
     stream_bpc = STREAM_BYTES_PER_CELL.get(kind)
     valu = ops * cells / t / 1e12
-    pmc = pmc_for(workload, kernel.replace(" ", ""))
+    pmc, prov = pmc_for(workload, kernel.replace(" ", ""))
     if pmc and abs(pmc.get("cells_per_launch", 0) - cells) > 0.01 * cells:
         pmc = None                    # the committed capture is of another problem size (other --reads, another rank count)
+        prov = dict(prov, other_problem_size=True)
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
     out = {"bound": bound, "kernel": kernel, "cells_per_launch": int(cells), "ms_per_launch": round(ms, 4)}
     if bound == "fp64_valu":
@@ -176,15 +188,26 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
         out.update(achieved=round(alg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_gbs / HBM_PEAK_GBS, 4),
                    bytes_per_cell=BYTES_PER_CELL)
     out["traffic"] = traffic
+    out["traffic_source"] = ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, not measured in this run)" % prov["file"]
+                             if traffic else None)
     out["hbm"] = {"algorithmic_GBs": round(alg_gbs, 1), "algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 4),
                   "bytes_per_cell": BYTES_PER_CELL, "traffic_bytes_per_launch": traffic,
                   "traffic_GBs": round(traffic / t / 1e9, 1) if traffic else None,
                   "traffic_frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
     out["fp64_valu"] = {"f64_ops_per_cell": ops, "achieved_Tops": round(valu, 3), "peak_Tops": F64_PEAK_TOPS,
                         "frac": round(valu / F64_PEAK_TOPS, 4)}
-    if pmc:
-        out["pmc"] = {k: pmc[k] for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "valu_busy_frac",
-                                          "clock_GHz", "valu_insts_per_cell") if k in pmc}
+    if MEASURED_F64_TOPS:
+        # the spec-sheet roof (one fp64 wave-instruction per 4 clocks at 2.4 GHz) beside what this chip sustains on a stream of
+        # independent v_add_f64 (measured in this run: qf_debug_measure_f64_rate)
+        out["fp64_valu"].update(measured_add_f64_peak_Tops=round(MEASURED_F64_TOPS, 2), frac_of_measured_peak=round(valu / MEASURED_F64_TOPS, 4))
+    if prov:
+        out["replayed_counters"] = dict(prov, note="counters of a separate rocprofv3 --pmc run on the same build (tools/profile.sh), replayed here; "
+                                                   "everything outside this object and `traffic` is measured live")
+        if pmc:
+            out["replayed_counters"]["counters"] = {k: pmc[k] for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+                                                                         "GRBM_GUI_ACTIVE", "valu_busy_frac", "clock_GHz", "valu_insts_per_cell",
+                                                                         "wave_cycles_parked_frac", "wave_cycles_issue_stalled_frac",
+                                                                         "wave_cycles_lds_stalled_frac") if k in pmc}
     if extra:
         out.update(extra)
     return out
@@ -313,9 +336,23 @@ class AlignJob(Job):
             ctx.upload_reads_packed(self.seq, self.qual, self.off)
             ctx.align_resident(self.cfg, a.align_flags, raw=True)
         up_ms = (time.perf_counter() - t0) / 3 * 1e3
+        # ... and the same with the batches in flight: every step uploads its own reads (200 MB over PCIe) into its context and
+        # aligns them, len(self.ctxs) contexts at a time -- the end-to-end rate of a caller that streams batches from the host
+        up_inflight_ms = None
+        if len(self.ctxs) > 1:
+            def up_step(c):
+                c.upload_reads_packed(self.seq, self.qual, self.off)
+                c.align_resident(self.cfg, a.align_flags, raw=True)
+            for c in self.ctxs:
+                up_step(c)
+            t0 = time.perf_counter()
+            for f in [self.pool.submit(lambda c=c: [up_step(c) for _ in range(4)]) for c in self.ctxs]:
+                f.result()
+            up_inflight_ms = (time.perf_counter() - t0) / (4 * len(self.ctxs)) * 1e3
         self.extra = {"reads_per_gpu": self.n, "pairs_per_gpu": 2 * self.n, "bands": n_units, "alignments": n_align,
                       "traceback_bytes": tb_bytes, "batches_in_flight": len(self.ctxs),
                       "ms_per_step_one_at_a_time": round(seq_ms, 3), "ms_per_step_with_upload_one_at_a_time": round(up_ms, 3),
+                      "ms_per_step_with_upload_in_flight": round(up_inflight_ms, 3) if up_inflight_ms else None,
                       "fill_kernels": {self.kernel_symbol(k): {"ms": round(self.cls_ms[k] / steps, 4), "cells": self.cls_cells[k]}
                                        for k in sorted(self.cls_ms)}}
         cpu = None
@@ -574,18 +611,7 @@ class OverlapJob(Job):
         # (one host thread each; calls are synchronous) pull sub-blocks of rows off a shared list, as the reference's worker
         # threads pull tasks off the scheduler: a block's tails (wide bands, selection, traceback, copies) run beside the next
         # block's seeding.
-        row_len = (2 * n - 1 - np.arange(rows)).astype(np.float64)
-        cuts = dist.balanced_blocks(row_len, self.world)
-        r0, r1 = int(cuts[self.rank]), int(cuts[self.rank + 1])
-        self.row_block = (r0, r1)
-        self.n_pairs = int(row_len[r0:r1].sum())
-        target = max(1, a.overlap_block_pairs)
-        self.blocks, b0, acc = [], r0, 0
-        for r in range(r0, r1):
-            acc += int(row_len[r])
-            if acc >= target or r == r1 - 1:
-                self.blocks.append((b0, r + 1))
-                b0, acc = r + 1, 0
+        self.row_block, self.blocks, self.n_pairs = dist.overlap_row_plan(n, 2 * n, rows, self.rank, self.world, a.overlap_block_pairs)
         self.ctxs = []
         for _ in range(max(1, 1 if a.serial_classes else min(a.inflight, len(self.blocks)))):
             ctx = Q.Context(self.local_rank)
@@ -835,6 +861,11 @@ def main():
     if rank != 0:
         dist.finalize()
         return
+    global MEASURED_F64_TOPS
+    try:
+        MEASURED_F64_TOPS = job.ctx.measure_f64_rate() / 1e12
+    except Exception:
+        MEASURED_F64_TOPS = None
     roof, cpu = job.finish(a.steps)
     cfg = {"workload": job.describe(), "cells_per_step": total_cells // a.steps,
            "phase_ms": {k: round(v / a.steps, 3) for k, v in job.phase.items()}}

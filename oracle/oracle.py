@@ -670,6 +670,244 @@ def param_counts_json(pc, match_len, gap_len):
     return o
 
 
+# ------------------------------------------------------------------- EM (quaff train): prior, M-step, convergence
+# Counts are the flattened QuaffParamCounts of param_counts():
+#   ins[4][94] | mat[4][Km][94] | beginInsertNo[Kg] beginInsertYes[Kg] beginDeleteNo[Kg] beginDeleteYes[Kg]
+#   | extendInsertNo extendInsertYes extendDeleteNo extendDeleteYes
+# GSL (un-vendored, un-pinned: doc/manual.tex:78) supplies gsl_ran_beta_pdf / gsl_ran_dirichlet_pdf /
+# gsl_ran_negative_binomial_pdf to these functions; their published formulas are restated with libm lgamma.
+class CountsView:
+    """Named views into a flattened QuaffParamCounts vector (src/qmodel.h:205-233)."""
+
+    def __init__(self, pc, match_len, gap_len):
+        self.match_len, self.gap_len = match_len, gap_len
+        self.Km, self.Kg = 4 ** match_len, 4 ** gap_len
+        ne = (4 + 4 * self.Km) * NQUAL
+        assert len(pc) == ne + 4 * self.Kg + 4
+        self.v = pc
+        self.ins = pc[:4 * NQUAL].reshape(4, NQUAL)
+        self.mat = pc[4 * NQUAL:ne].reshape(4, self.Km, NQUAL)
+        Kg = self.Kg
+        self.beginInsertNo, self.beginInsertYes = pc[ne:ne + Kg], pc[ne + Kg:ne + 2 * Kg]
+        self.beginDeleteNo, self.beginDeleteYes = pc[ne + 2 * Kg:ne + 3 * Kg], pc[ne + 3 * Kg:ne + 4 * Kg]
+        self.ext = pc[ne + 4 * Kg:]          # extendInsertNo, extendInsertYes, extendDeleteNo, extendDeleteYes
+
+
+def negbinom_pdf(k, p, r):
+    """gsl_ran_negative_binomial_pdf, as published (see qo_log_negbinom in quaff_oracle.c)."""
+    return math.exp(math.lgamma(k + r) - math.lgamma(r) - math.lgamma(k + 1.0) + r * math.log(p) + k * math.log1p(-p))
+
+
+def init_counts(match_len, gap_len, no_begin, yes_extend, match_ident, other, null=None):
+    """QuaffParamCounts::initCounts, src/qmodel.cpp:431-456; the auto-prior is initCounts(9, 9, 5, 1, &nullModel)
+    (t/quaff.cpp:490-512).  NB the identity test `i == j` (:446, :448) compares the reference base i with the FULL context
+    k-mer index j = jPrefix + jSuffix, not with the read base jSuffix: for match contexts longer than one base only the
+    contexts whose prefix is all-A ever get matchIdentCount."""
+    Km, Kg = 4 ** match_len, 4 ** gap_len
+    pc = np.zeros(counts_size(Km, Kg))
+    cv = CountsView(pc, match_len, gap_len)
+    for j in range(4):
+        for k in range(NQUAL):
+            if null is not None:
+                cv.ins[j, k] = other * null.null[j][0] * 4 * negbinom_pdf(k, null.null[j][1], null.null[j][2])
+            else:
+                cv.ins[j, k] = other / NQUAL
+    for i in range(4):
+        for jp in range(0, Km, 4):
+            for js in range(4):
+                j = jp + js
+                for k in range(NQUAL):
+                    if null is not None:
+                        w = match_ident if i == j else other * null.null[js][0] * 4 / (1 - null.null[i][0])
+                        cv.mat[i, j, k] = w * negbinom_pdf(k, null.null[js][1], null.null[js][2])
+                    else:
+                        cv.mat[i, j, k] = (match_ident if i == j else other) / NQUAL
+    cv.beginInsertNo[:] = no_begin
+    cv.beginInsertYes[:] = other
+    cv.beginDeleteNo[:] = no_begin
+    cv.beginDeleteYes[:] = other
+    cv.ext[:] = (other, yes_extend, other, yes_extend)
+    return pc
+
+
+def log_beta_pdf(prob, yes_count, no_count):
+    """logBetaPdf, src/qmodel.cpp:35-37: log(gsl_ran_beta_pdf(prob, yes + 1, no + 1)).  GSL: 0 outside [0, 1]; at the ends
+    Gamma(a+b)/(Gamma(a)Gamma(b)) x^(a-1) (1-x)^(b-1) (0 when a, b > 1); inside exp(lgamma terms + (a-1) log x + (b-1) log1p(-x))."""
+    a, b = yes_count + 1.0, no_count + 1.0
+    if prob < 0 or prob > 1:
+        return NEG_INF
+    g = math.lgamma(a + b) - math.lgamma(a) - math.lgamma(b)
+    if prob == 0.0 or prob == 1.0:
+        pdf = 0.0 if (a > 1.0 and b > 1.0) else math.exp(g) * prob ** (a - 1) * (1 - prob) ** (b - 1)
+    else:
+        pdf = math.exp(g + math.log(prob) * (a - 1) + math.log1p(-prob) * (b - 1))
+    return math.log(pdf) if pdf > 0 else NEG_INF
+
+
+def log_dirichlet_pdf(alpha, theta):
+    """log(gsl_ran_dirichlet_pdf(K, alpha, theta)) = log(exp(sum (alpha_i - 1) log theta_i + lgamma(sum alpha) - sum lgamma(alpha_i)))."""
+    lp = sum((a - 1.0) * math.log(t) for a, t in zip(alpha, theta)) + math.lgamma(sum(alpha)) - sum(math.lgamma(a) for a in alpha)
+    pdf = math.exp(lp)
+    return math.log(pdf) if pdf > 0 else NEG_INF
+
+
+def log_qual_prob(q, r, kfreq):
+    """SymQualDist::logQualProb(kFreq), src/qmodel.cpp:83-85 -> logNegativeBinomial(kFreq, p, n), src/negbinom.cpp:34-39."""
+    lp = 0.0
+    for k in range(len(kfreq)):
+        lp += kfreq[k] * lib().qo_log_negbinom(k, q, r)
+    return lp
+
+
+def log_prior(pc, p):
+    """QuaffParamCounts::logPrior, src/qmodel.cpp:1681-1710 (pc = the pseudocounts, p = Params)."""
+    cv = CountsView(pc, p.match_len, p.gap_len)
+    lp = 0.0
+    for j in range(p.Kg):
+        lp += log_beta_pdf(p.beginInsert[j], cv.beginInsertYes[j], cv.beginInsertNo[j])
+        lp += log_beta_pdf(p.beginDelete[j], cv.beginDeleteYes[j], cv.beginDeleteNo[j])
+    lp += log_beta_pdf(p.extendInsert, cv.ext[1], cv.ext[0])
+    lp += log_beta_pdf(p.extendDelete, cv.ext[3], cv.ext[2])
+    alpha, theta = [0.0] * 4, [0.0] * 4
+    for i in range(4):
+        lp += log_qual_prob(p.insert[i][1], p.insert[i][2], cv.ins[i])
+        theta[i] = p.insert[i][0]
+        alpha[i] = 1.0 + float(np.sum(cv.ins[i]))     # accumulate(..., 1.)
+    lp += log_dirichlet_pdf(alpha, theta)
+    for i in range(4):
+        for jp in range(0, p.Km, 4):
+            for js in range(4):
+                j = jp + js
+                lp += log_qual_prob(p.match[i, j][1], p.match[i, j][2], cv.mat[i, j])
+                theta[js] = p.match[i, j][0]
+                alpha[js] = 1.0 + float(np.sum(cv.mat[i, j]))
+            lp += log_dirichlet_pdf(alpha, theta)
+    return lp
+
+
+def m_step(pc, match_len, gap_len):
+    """QuaffParamCounts::fit, src/qmodel.cpp:1733-1768."""
+    cv = CountsView(pc, match_len, gap_len)
+    p = Params(match_len, gap_len)
+    for j in range(p.Kg):
+        p.beginDelete[j] = 1. / (1. + cv.beginDeleteNo[j] / cv.beginDeleteYes[j])
+        p.beginInsert[j] = 1. / (1. + cv.beginInsertNo[j] / cv.beginInsertYes[j])
+    p.extendDelete = 1. / (1. + cv.ext[2] / cv.ext[3])
+    p.extendInsert = 1. / (1. + cv.ext[0] / cv.ext[1])
+    ins_freq = [float(np.sum(cv.ins[i])) for i in range(4)]
+    for i in range(4):
+        q, r = fit_negbinom(np.array(cv.ins[i], float))
+        p.insert[i] = (ins_freq[i] / sum(ins_freq), q, r)
+    for i in range(4):
+        for jp in range(0, p.Km, 4):
+            f = [float(np.sum(cv.mat[i, jp + js])) for js in range(4)]
+            for js in range(4):
+                q, r = fit_negbinom(np.array(cv.mat[i, jp + js], float))
+                p.match[i, jp + js] = (f[js] / sum(f), q, r)
+    return p
+
+
+def fit_ref_seqs(p, refs):
+    """QuaffParams::fitRefSeqs, src/qmodel.cpp:284-294, with totalLen initialised (the reference reads it uninitialised;
+    DESIGN.md 7)."""
+    cnt = np.zeros(4)
+    for fs in refs:
+        t = tokens(fs.seq)
+        for b in range(4):
+            cnt[b] += np.count_nonzero(t == b)
+    p.refBase = list(cnt / cnt.sum())
+
+
+def params_json(p):
+    """QuaffParams::writeJson, src/qmodel.cpp:187-228."""
+    o = "{\n"
+    if p.match_len != 1:
+        o += '  "matchOrder": %d,\n' % p.match_len
+    if p.gap_len != 0:
+        o += '  "gapOrder": %d,\n' % p.gap_len
+    o += '  "refBase": {' + ",".join(' "%s": %s' % ("ACGT"[i], fmt(p.refBase[i])) for i in range(4)) + " },\n"
+    for name in ("beginInsert", "beginDelete"):
+        v = getattr(p, name)
+        o += '  "%s": {%s },\n' % (name, ",".join(' "%s": %s' % (kmer_string(g, p.gap_len), fmt(v[g])) for g in range(p.Kg)))
+    o += '  "extendInsert": %s,\n  "extendDelete": %s,\n' % (fmt(p.extendInsert), fmt(p.extendDelete))
+    o += '  "insert": {\n'
+    for i in range(4):
+        o += '    "%s": %s%s\n' % ("ACGT"[i], sqd_json(*p.insert[i]), " }," if i == 3 else ",")
+    o += '  "match": {\n'
+    for jp in range(0, p.Km, 4):
+        o += '   "%s": {\n' % kmer_string(jp, p.match_len)[: p.match_len - 1]
+        for i in range(4):
+            o += '    "%s": {\n' % "ACGT"[i]
+            for js in range(4):
+                o += '      "%s": %s%s' % ("ACGT"[js], sqd_json(*p.match[i, jp + js]), " }" if js == 3 else ",\n")
+            o += " }" if i == 3 else ",\n"
+        o += " }" if jp == p.Km - 4 else ",\n"
+    return o + " }"
+
+
+def counts_from_json(text):
+    """QuaffParamCounts::readJson, src/qmodel.cpp:491-536 (+ QuaffEmitCounts::readJson :364-405): the flattened vector and
+    (match_len, gap_len)."""
+    jm = gason_loads(text) if isinstance(text, str) else text
+    ml, gl = int(jm.get("matchOrder", 1)), int(jm.get("gapOrder", 0))
+    Km, Kg = 4 ** ml, 4 ** gl
+    pc = np.zeros(counts_size(Km, Kg))
+    cv = CountsView(pc, ml, gl)
+    for i in range(4):
+        cv.ins[i] = jm["insert"]["ACGT"[i]]
+    for jp in range(0, Km, 4):
+        pref = kmer_string(jp, ml)[: ml - 1]
+        for i in range(4):
+            for js in range(4):
+                cv.mat[i, jp + js] = jm["match"][pref]["ACGT"[i]]["ACGT"[js]]
+    for g in range(Kg):
+        ks = kmer_string(g, gl)
+        cv.beginInsertNo[g], cv.beginInsertYes[g] = jm["beginInsertNo"][ks], jm["beginInsertYes"][ks]
+        cv.beginDeleteNo[g], cv.beginDeleteYes[g] = jm["beginDeleteNo"][ks], jm["beginDeleteYes"][ks]
+    cv.ext[:] = (jm["extendInsertNo"], jm["extendInsertYes"], jm["extendDeleteNo"], jm["extendDeleteYes"])
+    return pc, ml, gl
+
+
+def em_converged(it, llp, prev, min_inc):
+    """The stopping test of QuaffTrainer::fitUnlimited, src/qmodel.cpp:2204-2206 (it = 0-based iteration)."""
+    return it > 0 and llp < prev + abs(prev) * min_inc
+
+
+def train(refs, reads, null, prior, seed, cfg, max_iter=100, min_inc=0.01, use_null=True, e_step=None):
+    """QuaffTrainer::fitUnlimited, src/qmodel.cpp:2186-2231: E-step (one QuaffCountingTask per read, counts summed in read
+    order :2416-2422), log-prior, the convergence rule (:2204-2206: stop when iter > 0 and logLike + logPrior < previous +
+    |previous| * minFractionalLoglikeIncrement -- before the M-step of that iteration), M-step on counts + pseudocounts,
+    fitRefSeqs.  Returns (final Params, [per-iteration dict(loglike, logprior, counts, counts_with_prior, params)]); an iteration that
+    stopped has no counts_with_prior / params.  `e_step(params, sort_orders) -> (counts, loglike, new sort_orders)` replaces
+    the oracle's own E-step (tests drive the device's through the same loop)."""
+    p = seed
+    orders = [None] * len(reads)
+    prev = NEG_INF
+    log = []
+    for it in range(max_iter):
+        if e_step is not None:
+            counts, ll, orders = e_step(p, orders)
+        else:
+            sc = Scores(p)
+            counts = np.zeros(counts_size(p.Km, p.Kg))
+            ll = 0.0
+            for n, rd in enumerate(reads):
+                c, yl, orders[n] = count_read(refs, rd, sc, null, cfg, orders[n], use_null)
+                counts += c
+                ll += yl
+        lp = log_prior(prior, p)
+        rec = {"loglike": ll, "logprior": lp, "counts": counts}
+        log.append(rec)
+        if em_converged(it, ll + lp, prev, min_inc):
+            break
+        prev = ll + lp
+        rec["counts_with_prior"] = counts + 1. * prior      # addWeighted(pseudocounts, 1.), :1656-1673
+        p = m_step(rec["counts_with_prior"], p.match_len, p.gap_len)
+        fit_ref_seqs(p, refs)
+        rec["params"] = p
+    return p, log
+
+
 # ------------------------------------------------------------------- overlap
 class OverlapScores:
     """QuaffOverlapScores, src/qoverlap.cpp:9-75, for one strand flag."""

@@ -29,6 +29,18 @@ def build_library(force=False):
     return library_path()
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the device code's sources (csrc/*.hip, *.hpp, *.h, Makefile): profiles/r*_pmc_*.json
+    record it at capture time, and bench.py replays a capture's counters only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".hpp", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 class DPConfig(C.Structure):
     """qf_dp_config; defaults are `quaff align`'s (t/quaff.cpp:128, src/qmodel.h:303-335)."""
     _fields_ = [("local", C.c_int32), ("sparse", C.c_int32), ("kmer_len", C.c_int32), ("kmer_threshold", C.c_int32),
@@ -443,6 +455,13 @@ class Context:
                                           "xEnd": al.x_end, "yStart": al.y_start, "yEnd": al.y_end,
                                           "ops": "".join("MID"[int(r) & 3] * (int(r) >> 2) for r in runs)}
         return out
+
+    def measure_f64_rate(self):
+        """Tests / bench only (csrc/qf_internal.h): fp64 vector add lane-operations per second this device sustains."""
+        v = C.c_double()
+        self.L.qf_debug_measure_f64_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._chk(self.L.qf_debug_measure_f64_rate(self.h, C.byref(v)))
+        return v.value
 
     def set_overlap_block_pairs(self, pairs):
         """Tests only (csrc/qf_internal.h): pairs per internal row block of overlap_rows (0 = default)."""

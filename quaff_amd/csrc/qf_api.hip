@@ -9,6 +9,8 @@
 #include <cmath>
 #include <condition_variable>
 #include <functional>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -797,8 +799,11 @@ static int seed_pairs(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t n_pa
 // offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
 // *too_big is set (the caller splits the range).
 static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
-                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool two_in_flight, bool* too_big) {
+                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool two_in_flight, bool* too_big,
+                       uint64_t* need_bytes, uint32_t* row_granule) {
   *too_big = false;
+  *need_bytes = 0;
+  *row_granule = 0;
   const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
   const uint32_t n_pairs = n_reads * n_refs;
   const bool sparse = cfg->sparse != 0;
@@ -822,6 +827,15 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   if (tb_bytes > budget) {
     if (n_reads == 1) return fail(S, QF_ERR_MEMORY, "one read needs " + std::to_string(tb_bytes >> 20) + " MiB of traceback, over the memory budget");
     *too_big = true;
+    *need_bytes = tb_bytes;
+    // mostly row-space bands (-kmatchoff): the pieces should be whole rounds of the kernel's resident workgroups
+    if (bc.cls_count[kRowClass] && bc.cls_cells[kRowClass] * 2 > bc.total_cells) {
+      FillArgs probe{};
+      probe.dp.ematch_ninf_off = (uint32_t)((size_t)c->scores.Km * kNQ1 * 4 * 8);
+      probe.dp.Kg = c->scores.Kg;
+      probe.no_lds_tables = (c->debug & QF_DEBUG_GLOBAL_TABLES) != 0;
+      *row_granule = viterbi_rows_resident_workgroups(probe);
+    }
     return QF_OK;
   }
   if (reserve_big(S->d_tb, tb_bytes + 64, {&c->d_fw, &c->second.d_fw}) != hipSuccess) {   // less memory than the budget assumed: halve the chunk
@@ -1049,8 +1063,10 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
         ++in_flight;
       }
       bool too_big = false;
-      const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, chunk_budget(c, S->d_tb, n_chunks > 1 ? 2 : 1), out,
-                                 out_mu, n_chunks > 1, &too_big);
+      uint64_t need = 0;
+      uint32_t granule = 0;
+      const uint64_t budget = chunk_budget(c, S->d_tb, n_chunks > 1 ? 2 : 1);
+      const int rc = align_chunk(c, S, cfg, flags, job.first, job.second, budget, out, out_mu, n_chunks > 1, &too_big, &need, &granule);
       {
         std::lock_guard<std::mutex> lk(mu);
         --in_flight;
@@ -1059,9 +1075,23 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
           if (S != static_cast<Slot*>(c)) c->err = S->err;
         }
         if (too_big) {
-          const uint32_t mid = job.first + (job.second - job.first) / 2;
-          todo.push_back({mid, job.second});
-          todo.push_back({job.first, mid});
+          // Pieces of as many reads as the budget holds (by the piece's own bytes per read; a piece that still comes out too
+          // big is cut again), not blind halves: fewer wasted seeding passes and no piece much smaller than it has to be.  A
+          // full-DP batch is all row-space bands, one workgroup each: there a piece is a whole number of rounds of the
+          // kernel's resident workgroups (624 bands on 512 slots take as long as 1024).  An allocation that failed inside the
+          // budget (another context on the device) halves.
+          const uint32_t n = job.second - job.first;
+          uint32_t fit = n / 2;
+          if (need) {
+            const double per_read = (double)need / n;
+            fit = (uint32_t)std::min<double>(n - 1, std::max(1.0, std::floor(0.97 * (double)budget / per_read)));
+            const uint32_t g = granule / std::max(1u, c->n_refs);
+            if (g && fit >= g) fit = fit / g * g;
+          }
+          fit = std::max(1u, std::min(fit, n - 1));
+          std::vector<std::pair<uint32_t, uint32_t>> pieces;
+          for (uint32_t p = job.first; p < job.second; p += fit) pieces.push_back({p, std::min(job.second, p + fit)});
+          for (size_t k = pieces.size(); k-- > 0;) todo.push_back(pieces[k]);
         }
       }
       cv.notify_all();
@@ -2181,6 +2211,16 @@ uint64_t qf_overlap_rows_pairs(uint32_t n_seqs, uint32_t x0, uint32_t x1) {
   return r * (uint64_t)(n_seqs - 1 - x0) - r * (r - 1) / 2;
 }
 
+int qf_debug_measure_f64_rate(qf_ctx* c, double* lane_ops_per_s) {
+  if (!c || !lane_ops_per_s) return QF_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf tmp;
+  HIPCHK(c, tmp.reserve((size_t)1024 * 256 * 8));
+  *lane_ops_per_s = measure_f64_add_rate(tmp.as<double>(), c->stream);
+  tmp.release();
+  return *lane_ops_per_s > 0 ? QF_OK : fail(c, QF_ERR_DEVICE, "fp64 issue-rate measurement failed");
+}
+
 int qf_debug_set_overlap_block_pairs(qf_ctx* c, uint64_t pairs) {
   if (!c) return QF_ERR_ARG;
   c->ov_block_pairs = pairs;
@@ -2293,29 +2333,75 @@ struct Rccl {
   void* h = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;     // optional: an error a rank hit inside a collective
+  decltype(&ncclCommAbort) CommAbort = nullptr;                     // optional
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  std::string err;
+  std::string err, path;
   bool load() {
     if (h) return true;
-    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // An RCCL already in the process (PyTorch ships its own librccl.so and loads it with local scope) is reused whatever its
+    // path: a second copy would have its own topology state and its own idea of the devices in use.  RTLD_NOLOAD finds a
+    // resident library by soname without loading anything.
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+      if (h) { path = std::string(name) + " (already resident)"; break; }
+    }
+    if (!h)
+      for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) { path = name; break; }
+      }
     if (!h) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
-    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) err = std::string("RCCL lacks ") + n; return p; };
-    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
-    CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
-    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
-    AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
-    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
-    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    auto sym = [&](const char* n, bool required) { void* p = dlsym(h, n); if (!p && required) err = std::string("RCCL lacks ") + n; return p; };
+    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId", true);
+    CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank", true);
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll", true);
+    AllReduce = (decltype(AllReduce))sym("ncclAllReduce", true);
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy", true);
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString", true);
+    CommGetAsyncError = (decltype(CommGetAsyncError))sym("ncclCommGetAsyncError", false);
+    CommAbort = (decltype(CommAbort))sym("ncclCommAbort", false);
     if (!GetUniqueId || !CommInitRank || !CommInitAll || !AllReduce || !CommDestroy || !GetErrorString) { h = nullptr; return false; }
     return true;
   }
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
+
+// Seconds a rank waits for its peers (communicator set-up, a collective) before it gives up with an error status instead of
+// hanging: a peer that died or never started must not leave the others blocked for ever.  QUAFF_HIP_COMM_TIMEOUT overrides.
+double comm_timeout_s() {
+  if (const char* e = getenv("QUAFF_HIP_COMM_TIMEOUT")) { const double v = atof(e); if (v > 0) return v; }
+  return 180.0;
+}
+
+bool comm_trace() { static const bool on = getenv("QUAFF_HIP_COMM_TRACE") != nullptr; return on; }
+#define COMM_TRACE(...) do { if (comm_trace()) { fprintf(stderr, "[quaffhip comm] " __VA_ARGS__); fputc('\n', stderr); } } while (0)
+
+// Tear a communicator down without waiting for its peers.  ncclCommAbort itself can block -- measured: on a communicator whose
+// set-up is still in its bootstrap, waiting for a rank that never arrives, it waits for that set-up -- so it runs on a thread
+// of its own, which is given two seconds and then left behind (the caller reports an error and normally exits).
+void comm_abort(qf_ctx* c) {
+  if (!c->comm) return;
+  ncclComm_t comm = c->comm;
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_size = 1;
+  auto done = std::make_shared<std::promise<void>>();
+  std::future<void> fut = done->get_future();
+  std::thread([comm, done] {
+    COMM_TRACE("abort: start");
+    if (g_rccl.CommAbort) (void)g_rccl.CommAbort(comm);
+    else (void)g_rccl.CommDestroy(comm);
+    COMM_TRACE("abort: returned");
+    done->set_value();
+  }).detach();
+  if (fut.wait_for(std::chrono::seconds(2)) != std::future_status::ready) COMM_TRACE("abort: still running after 2 s, left behind");
+}
+
 }  // namespace
 
 int qf_comm_unique_id(uint8_t* id) {
@@ -2339,10 +2425,31 @@ int qf_comm_init_rank(qf_ctx* c, const uint8_t* id, int rank, int n_ranks) {
   }
   qf_comm_destroy(c);
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_comm.reserve(((size_t)qf_counts_size(c) + 64) * 8));   // the staging buffer now: nothing to allocate between the ranks' collectives
   ncclUniqueId u;
   memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
-  const ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, u, rank);   // blocks until all n_ranks have called it
-  if (r != ncclSuccess) { c->comm = nullptr; return fail(c, QF_ERR_DEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+  // ncclCommInitRank returns only when all n_ranks have called it, and a rank whose peer died before getting here would wait
+  // for ever.  (RCCL 2.27's non-blocking form, ncclCommInitRankConfig with blocking = 0, does not return either while the
+  // bootstrap waits for a peer -- measured on this pool.)  So the call runs on a thread of its own and this one waits for it
+  // with a deadline; a set-up that is still stuck then is left behind with its thread, and the caller gets a status.
+  const double limit = comm_timeout_s();
+  struct InitState { std::promise<ncclResult_t> done; ncclComm_t comm = nullptr; };
+  auto st = std::make_shared<InitState>();
+  std::future<ncclResult_t> fut = st->done.get_future();
+  const int device = c->device;
+  COMM_TRACE("init: ncclCommInitRank on a helper thread, rank %d of %d, limit %.0f s", rank, n_ranks, limit);
+  std::thread([st, u, rank, n_ranks, device] {
+    (void)hipSetDevice(device);
+    const ncclResult_t r = g_rccl.CommInitRank(&st->comm, n_ranks, u, rank);
+    COMM_TRACE("init: ncclCommInitRank returned %d", (int)r);
+    st->done.set_value(r);
+  }).detach();
+  if (fut.wait_for(std::chrono::duration<double>(limit)) != std::future_status::ready)
+    return fail(c, QF_ERR_DEVICE, "RCCL communicator set-up: rank " + std::to_string(rank) + " of " + std::to_string(n_ranks) + " gave up after " +
+                                      std::to_string((int)limit) + " s waiting for the other ranks");
+  const ncclResult_t r = fut.get();
+  if (r != ncclSuccess) return fail(c, QF_ERR_DEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+  c->comm = st->comm;
   c->comm_rank = rank;
   c->comm_size = n_ranks;
   return QF_OK;
@@ -2363,6 +2470,10 @@ int qf_comm_init_all(qf_ctx* const* ctxs, int n) {
     if (!g_rccl.load()) return fail(c0, QF_ERR_DEVICE, g_rccl.err);
   }
   for (int k = 0; k < n; ++k) qf_comm_destroy(ctxs[k]);
+  for (int k = 0; k < n; ++k) {     // staging buffers before the communicators exist: a failed allocation fails the call, not one rank of a collective
+    HIPCHK(ctxs[k], hipSetDevice(ctxs[k]->device));
+    HIPCHK(ctxs[k], ctxs[k]->d_comm.reserve(((size_t)qf_counts_size(ctxs[k]) + 64) * 8));
+  }
   std::vector<ncclComm_t> comms(n, nullptr);
   const ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, dev.data());
   if (r != ncclSuccess) return fail(c0, QF_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
@@ -2383,21 +2494,44 @@ void qf_comm_destroy(qf_ctx* c) {
   c->d_comm.release();
 }
 
+// Every exit that is not success aborts the communicator: a rank that fails before or inside the collective must not leave its
+// peers blocked in it (they then time out of their own wait below, or see RCCL's error), and the communicator is unusable after a
+// failed collective anyway.
 int qf_allreduce_counts(qf_ctx* c, double* counts, uint32_t n, double* loglike) {
   if (!c || (n && !counts)) return QF_ERR_ARG;
   if (!c->comm) return fail(c, QF_ERR_STATE, "no communicator (qf_comm_init_rank / qf_comm_init_all)");
   const size_t m = (size_t)n + (loglike ? 1 : 0);
   if (!m) return QF_OK;
-  HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, c->d_comm.reserve(m * 8));
+  auto bail = [&](const std::string& what) {
+    (void)hipGetLastError();
+    comm_abort(c);
+    return fail(c, QF_ERR_DEVICE, what + " (communicator aborted)");
+  };
+  if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice");
+  if (c->d_comm.reserve(m * 8) != hipSuccess) return bail("cannot allocate the all-reduce staging buffer");
   double* d = c->d_comm.as<double>();
-  if (n) HIPCHK(c, hipMemcpyAsync(d, counts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-  if (loglike) HIPCHK(c, hipMemcpyAsync(d + n, loglike, 8, hipMemcpyHostToDevice, c->stream));
+  if (n && hipMemcpyAsync(d, counts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the counts");
+  if (loglike && hipMemcpyAsync(d + n, loglike, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the log-likelihood");
+  const double limit = comm_timeout_s();
   const ncclResult_t r = g_rccl.AllReduce(d, d, m, ncclDouble, ncclSum, c->comm, c->stream);
-  if (r != ncclSuccess) return fail(c, QF_ERR_DEVICE, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
-  if (n) HIPCHK(c, hipMemcpyAsync(counts, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-  if (loglike) HIPCHK(c, hipMemcpyAsync(loglike, d + n, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (r != ncclSuccess) return bail(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  if (n && hipMemcpyAsync(counts, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the counts");
+  if (loglike && hipMemcpyAsync(loglike, d + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the log-likelihood");
+  // the collective finishes when every rank has entered it: wait with a deadline, not with hipStreamSynchronize
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return bail(std::string("all-reduce stream: ") + hipGetErrorString(q));
+    if (g_rccl.CommGetAsyncError) {
+      ncclResult_t st = ncclSuccess;
+      if (g_rccl.CommGetAsyncError(c->comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress)
+        return bail(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(st));
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+      return bail("the all-reduce did not complete within " + std::to_string((int)limit) + " s: a peer rank is missing");
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
   return QF_OK;
 }
 

@@ -3,6 +3,7 @@
 // Off the hot path; pure C++17.  GSL is not available here, so digamma/trigamma, the bracketing
 // root finder and the Newton polish are this repo's own.  Reference lines cited per function.
 #pragma once
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,13 @@ struct ParamCounts {
   std::string write_json() const;                     // :458-470, :341-362
   bool read_json(const Json& j, std::string& err);    // :491-536
 };
+
+// The EM loop's stopping rule (QuaffTrainer::fitUnlimited, src/qmodel.cpp:2204-2206), tested after the E-step of iteration
+// `iter` (0-based) and before its M-step: stop when iter > 0 and logLike + logPrior has not risen by the fraction min_inc of
+// |previous|.
+inline bool em_converged(int iter, double loglike_with_prior, double prev_loglike_with_prior, double min_inc) {
+  return iter > 0 && loglike_with_prior < prev_loglike_with_prior + std::fabs(prev_loglike_with_prior) * min_inc;
+}
 
 // QuaffNullParams(seqs, pseudocount), src/qmodel.cpp:1811-1843
 NullParams fit_null(const std::vector<std::string>& seqs, const std::vector<std::string>& quals, double pseudocount = 1);

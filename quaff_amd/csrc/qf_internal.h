@@ -34,6 +34,9 @@ uint32_t qf_debug_lse_pack_bytes(qf_ctx *ctx);
  * the per-pair kernel); counted only under QF_DEBUG_COUNT_SETTLED. */
 uint64_t qf_debug_rows_settled(const qf_ctx *ctx);
 
+/* fp64 vector add lane-operations per second this device sustains (a 5 ms microbenchmark: 8 independent v_add_f64 chains per wavefront,
+ * 4 wavefronts per SIMD, all CUs): the attainable issue roof beside the 39.3 T op/s the spec sheet implies. */
+int qf_debug_measure_f64_rate(qf_ctx *ctx, double *lane_ops_per_s);
 /* qf_overlap_rows cuts its rows into blocks of about this many pairs (0 = the default, 2^24); tests use small values to push a
  * small read set through many blocks. */
 int qf_debug_set_overlap_block_pairs(qf_ctx *ctx, uint64_t pairs);

@@ -1965,6 +1965,54 @@ void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s)
   }
 }
 
+// Workgroups of the row-space Viterbi kernel the device holds at once (one band each): a batch of bands that is not a multiple of
+// this leaves the last round of workgroups on a partly idle chip (624 bands on 512 slots run as long as 1024).
+uint32_t viterbi_rows_resident_workgroups(const FillArgs& a) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const uint32_t lds_bytes = a.dp.ematch_ninf_off + 32 + kInsRows * 8 + 4 * a.dp.Kg * 8;
+  const bool lds = lds_bytes <= 52 * 1024 && !a.no_lds_tables;
+  const hipError_t e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_viterbi_rows<true>, kVitLanes, lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_viterbi_rows<false>, kVitLanes, 0);
+  if (e != hipSuccess || per_cu <= 0 || cus <= 0) { (void)hipGetLastError(); return 0; }
+  return (uint32_t)(per_cu * cus);
+}
+
+// The chip's fp64 vector issue rate as it is, not as specified: eight independent v_add_f64 chains per wavefront, four wavefronts
+// per SIMD, every CU busy (tools/dev/valu_rate_bench.hip has the other instructions).  The Viterbi roofline's 39.3 T op/s assumes
+// one fp64 wave-instruction per 4 clocks at 2.4 GHz; measured, the instruction takes ~5 clocks and the clock under load is ~2.1 GHz.
+__global__ __launch_bounds__(256) void k_f64_add_rate(double* out, int iters) {
+  double d[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) d[c] = 1.0 + threadIdx.x * 1e-3 + c;
+  const double k = 1.0000001;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[c]) : "v"(k));
+  }
+  double acc = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc += d[c];
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+// lane-operations per second (wave-instructions x 64), or 0 on error
+double measure_f64_add_rate(double* d_out /* >= 256 K doubles */, hipStream_t s) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+  const int blocks = std::min(cus * 4, 1024), iters = 40000;   // 4 workgroups of 4 wavefronts per CU
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
+  hipLaunchKernelGGL(k_f64_add_rate, dim3(blocks), dim3(256), 0, s, d_out, 2000);   // clocks ramp up
+  (void)hipEventRecord(e0, s);
+  hipLaunchKernelGGL(k_f64_add_rate, dim3(blocks), dim3(256), 0, s, d_out, iters);
+  (void)hipEventRecord(e1, s);
+  float ms = 0;
+  const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ok ? (double)blocks * 256.0 * iters * 8.0 / (ms * 1e-3) : 0.0;
+}
+
 void launch_prep_ref(const char* seq, uint64_t total, uint8_t* tok, BatchCounters* bc, hipStream_t s) {
   if (!total) return;
   hipLaunchKernelGGL(k_prep_ref, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, seq, total, tok, bc);

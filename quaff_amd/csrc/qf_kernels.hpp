@@ -245,6 +245,8 @@ bool seed_needs_workspace(const SeedArgs& a, bool mem);
 int launch_seed(const SeedArgs& a, uint32_t n_pairs, bool mem, hipStream_t s);
 void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s);
 void launch_viterbi_fill(int cls, const FillArgs& a, bool gapctx, hipStream_t s);
+uint32_t viterbi_rows_resident_workgroups(const FillArgs& a);   // 0: unknown
+double measure_f64_add_rate(double* d_out, hipStream_t s);     // fp64 add lane-operations per second the chip sustains; 0 on error
 void launch_finalize(const FinalArgs& a, hipStream_t s);
 void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s);
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s);

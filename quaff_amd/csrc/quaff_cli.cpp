@@ -727,7 +727,7 @@ static int cmdTrainOrCount(Opts& o, bool training) {
     const double logPrior = prior.log_prior(qp);
     const double llp = logLike + logPrior;
     cerr << "EM iteration " << (iter + 1) << ": log-likelihood (" << fmt6(logLike) << ") + log-prior (" << fmt6(logPrior) << ") = " << fmt6(llp) << endl;
-    if (iter > 0 && llp < prevLL + fabs(prevLL) * minInc) break;
+    if (em_converged(iter, llp, prevLL, minInc)) break;
     prevLL = llp;
     ParamCounts withPrior = counts;
     withPrior.add_weighted(prior, 1.);
@@ -788,52 +788,39 @@ static int cmdOverlap(Opts& o) {
   bool allQual;
   packSeqs(reads.seqs, 0, reads.seqs.size(), seq, qual, off, allQual);
   for (qf_ctx* c : s.ctxs) QF(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
-  // pair order of QuaffOverlapScheduler, src/qoverlap.cpp:475-480,528-547; every device holds all reads, consecutive
-  // blocks of the pair list go to the devices in turn and are printed in list order
-  // A block is a run of the pair list, kept as (x, first y, last y + 1) segments; the device's host thread expands it into
-  // the index arrays, so the enumeration of 10^9 pairs is neither serial nor interleaved with the device calls.
-  struct Seg { uint32_t x, y0, y1; };
-  struct Block { vector<Seg> segs; size_t n = 0; };
+  // QuaffOverlapScheduler's enumeration (src/qoverlap.cpp:475-480,528-547: nx = 0 ... nOriginals - 2, ny = nx + 1 ... over the
+  // originals and then their reverse complements) happens on the device: qf_overlap_rows takes a block of rows, generates its
+  // (nx, ny, yComplemented) triples, applies the printer's threshold and returns the alignments that pass, in the
+  // scheduler's order.  Every device holds all reads; consecutive row blocks go to the devices in turn and are printed in
+  // block order.
   const size_t N = reads.nOriginals, total = reads.seqs.size(), G = s.devices();
-  size_t chunk = 1 << 21;   // pairs per device call
+  size_t chunk = (size_t)1 << 26;   // pairs per device call (the library cuts a call into blocks that fit its tables)
   if (const char* e = getenv("QUAFF_HIP_OVERLAP_CHUNK")) chunk = max<size_t>(1, (size_t)atol(e));   // tests: many small blocks
-  vector<Block> pend(1);
-  auto flush = [&]() {
-    if (pend.back().n == 0) pend.pop_back();
-    if (pend.empty()) { pend.emplace_back(); return; }
-    vector<vector<Hit>> got(pend.size());
-    onDevices(pend.size(), [&](size_t k) {
-      const Block& b = pend[k];
-      vector<uint32_t> px(b.n), py(b.n);
-      vector<uint8_t> pc(b.n);
-      size_t at = 0;
-      for (const Seg& g : b.segs) {
-        const size_t m = g.y1 - g.y0;
-        std::fill(px.begin() + at, px.begin() + at + m, g.x);
-        for (size_t q = 0; q < m; ++q) { py[at + q] = g.y0 + (uint32_t)q; pc[at + q] = g.y0 + q >= N; }
-        at += m;
-      }
+  struct Block { uint32_t x0, x1; };
+  vector<Block> blocks;
+  for (size_t nx = 0, acc = 0, b0 = 0; nx + 1 < N; ++nx) {
+    acc += total - 1 - nx;
+    if (acc >= chunk || nx + 2 == N) { blocks.push_back({(uint32_t)b0, (uint32_t)(nx + 1)}); b0 = nx + 1; acc = 0; }
+  }
+  for (size_t r0 = 0; r0 < blocks.size(); r0 += G) {
+    const size_t nrun = min(G, blocks.size() - r0);
+    vector<vector<Hit>> got(nrun);
+    onDevices(nrun, [&](size_t k) {
       qf_ctx* c = s.ctxs[k];
-      qf_overlap_result res;
-      QFT(c, qf_overlap_resident(c, &o.cfg, px.data(), py.data(), pc.data(), (uint32_t)b.n, &res));
-      for (uint32_t a = 0; a < res.n_alignments; ++a) {
-        const qf_overlap_alignment& al = res.alignments[a];
-        got[k].push_back(makeOverlapAlignment(reads.seqs[px[al.pair]], reads.seqs[py[al.pair]], al, res.state_runs + al.run_offset));
+      qf_overlap_rows_result res;
+      QFT(c, qf_overlap_rows(c, &o.cfg, (uint32_t)N, blocks[r0 + k].x0, blocks[r0 + k].x1, &res));
+      for (uint32_t a = 0; a < res.n_hits; ++a) {
+        const qf_overlap_hit& h = res.hits[a];
+        qf_overlap_alignment al;
+        al.pair = 0;
+        al.viterbi = h.viterbi; al.score = h.score;
+        al.x_start = h.x_start; al.x_end = h.x_end; al.y_start = h.y_start; al.y_end = h.y_end;
+        al.n_columns = h.n_columns; al.n_runs = h.n_runs; al.run_offset = h.run_offset;
+        got[k].push_back(makeOverlapAlignment(reads.seqs[h.x], reads.seqs[h.y], al, res.state_runs + h.run_offset));
       }
     });
     for (const auto& block : got) for (const Hit& h : block) pr.write(cout, h);
-    pend.assign(1, Block());
-  };
-  for (size_t nx = 0; nx + 1 < N; ++nx)
-    for (size_t ny = nx + 1; ny < total;) {   // the row's pairs, cut where a block fills up
-      Block& b = pend.back();
-      const size_t take = min(total - ny, chunk - b.n);
-      b.segs.push_back({(uint32_t)nx, (uint32_t)ny, (uint32_t)(ny + take)});
-      b.n += take;
-      ny += take;
-      if (b.n >= chunk) { if (pend.size() == G) flush(); else pend.emplace_back(); }
-    }
-  flush();
+  }
   return EXIT_SUCCESS;
 }
 
@@ -841,7 +828,7 @@ static int cmdOverlap(Opts& o) {
 // t/testquaffjsonio.cpp, t/testquaffnulljsonio.cpp, t/testquaffcountsjsonio.cpp, t/testnegbinom.cpp; Makefile:103-133) over
 // this build's readers, writers and fitter.  No device is touched.
 static int cmdSelfTest(deque<string>& av) {
-  Require(!av.empty(), "selftest needs a name: fasta fastq params null counts fit negbinom");
+  Require(!av.empty(), "selftest needs a name: fasta fastq params null counts fit initcounts logprior converge negbinom");
   const string what = av[0];
   av.pop_front();
   auto parsed = [&](const string& file) { Json j; string err; if (!parse_json(slurp(file), j, err)) Fail("Couldn't parse " + file + ": " + err); return j; };
@@ -873,6 +860,39 @@ static int cmdSelfTest(deque<string>& av) {
     string err;
     if (!c.read_json(parsed(av[0]), err)) Fail(err);
     cout << c.fit().write_json();
+    return EXIT_SUCCESS;
+  }
+  if (what == "initcounts") {   // QuaffParamCounts::initCounts (src/qmodel.cpp:431-456); the auto-prior is 9 9 5 1 + the null model
+    Require(av.size() == 6 || av.size() == 7, "selftest initcounts matchLen gapLen noBegin yesExtend matchIdent other [null.json]");
+    ParamCounts c((unsigned)atoi(av[0].c_str()), (unsigned)atoi(av[1].c_str()));
+    NullParams null;
+    string err;
+    if (av.size() == 7 && !null.read_json(parsed(av[6]), err)) Fail(err);
+    c.init_counts(atof(av[2].c_str()), atof(av[3].c_str()), atof(av[4].c_str()), atof(av[5].c_str()), av.size() == 7 ? &null : nullptr);
+    cout << c.write_json();
+    return EXIT_SUCCESS;
+  }
+  if (what == "logprior") {   // QuaffParamCounts::logPrior (src/qmodel.cpp:1681-1710), full precision
+    Require(av.size() == 2, "selftest logprior <pseudocounts.json> <params.json>");
+    ParamCounts c(1, 0);
+    Params p;
+    string err;
+    if (!c.read_json(parsed(av[0]), err)) Fail(err);
+    if (!p.read_json(parsed(av[1]), err)) Fail(err);
+    cout << setprecision(17) << c.log_prior(p) << ' ' << c.expected_log_like(p) << endl;
+    return EXIT_SUCCESS;
+  }
+  if (what == "converge") {   // the EM stopping rule (src/qmodel.cpp:2204-2206) over a series of logLike + logPrior values
+    Require(av.size() >= 2, "selftest converge minInc v1 v2 ...");
+    const double minInc = atof(av[0].c_str());
+    double prev = -INFINITY;
+    int iter = 0;
+    for (; iter + 1 < (int)av.size(); ++iter) {
+      const double v = atof(av[iter + 1].c_str());
+      if (em_converged(iter, v, prev, minInc)) break;
+      prev = v;
+    }
+    cout << iter << endl;      // E-steps run before the loop stopped (all of them if it never did)
     return EXIT_SUCCESS;
   }
   if (what == "negbinom") {   // t/testnegbinom.cpp with the exact expected frequencies instead of GSL's sampler

@@ -132,6 +132,24 @@ def balanced_blocks(weights, world):
     return cuts
 
 
+def overlap_row_plan(n_originals, n_seqs, rows, rank, world, block_pairs):
+    """Rows [0, rows) of QuaffOverlapScheduler's enumeration (row nx = pairs (nx, ny), ny = nx + 1 ... n_seqs - 1;
+    src/qoverlap.cpp:475-480) cut over `world` ranks into contiguous row ranges of equal pair count, and this rank's range into
+    sub-blocks of about block_pairs pairs (the unit its contexts pull off their shared list, one qf_overlap_rows call each).
+    Returns ((r0, r1), [(b0, b1), ...], pairs of the rank)."""
+    assert 0 <= rows <= n_originals - 1
+    row_len = (n_seqs - 1 - np.arange(rows)).astype(np.float64)
+    cuts = balanced_blocks(row_len, world)
+    r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
+    blocks, b0, acc = [], r0, 0
+    for r in range(r0, r1):
+        acc += int(row_len[r])
+        if acc >= max(1, block_pairs) or r == r1 - 1:
+            blocks.append((b0, r + 1))
+            b0, acc = r + 1, 0
+    return (r0, r1), blocks, int(row_len[r0:r1].sum())
+
+
 def finalize():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -73,3 +73,34 @@ def test_balanced_blocks_partition():
     sums = np.array([w[cuts[k]:cuts[k + 1]].sum() for k in range(8)])
     assert cuts[-1] == 257 and sums.max() - sums.min() <= 2 * w.max()
     assert list(balanced_blocks([1, 1, 1], 1)) == [0, 3]
+
+
+def test_overlap_row_plan_covers_the_triangle_once():
+    """config 3 over 1 / 2 / 3 / 8 ranks: the ranks' row ranges and their sub-blocks tile rows [0, n - 1) exactly once, the pair
+    counts add up to the closed form (n - 1)(2n - 1) - (n - 2)(n - 1) / 2, and the ranks' shares differ by less than two rows."""
+    from quaff_amd.dist import overlap_row_plan
+    for n, rows in ((50000, 49999), (50000, 34), (7, 6), (2, 1), (300, 299)):
+        want = sum(2 * n - 1 - r for r in range(rows))
+        if rows == n - 1:
+            assert want == (n - 1) * (2 * n - 1) - (n - 2) * (n - 1) // 2
+        for world in (1, 2, 3, 8):
+            covered, pairs, shares = [], 0, []
+            for rank in range(world):
+                (r0, r1), blocks, np_rank = overlap_row_plan(n, 2 * n, rows, rank, world, 1 << 22)
+                assert np_rank == sum(2 * n - 1 - r for r in range(r0, r1))
+                if blocks:
+                    assert blocks[0][0] == r0 and blocks[-1][1] == r1 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+                    assert all(b1 > b0 for b0, b1 in blocks)
+                else:
+                    assert r0 == r1
+                covered += blocks
+                pairs += np_rank
+                shares.append(np_rank)
+            assert pairs == want
+            flat = [r for b0, b1 in covered for r in range(b0, b1)] if rows < 1000 else None
+            if flat is not None:
+                assert flat == list(range(rows))
+            else:
+                assert covered[0][0] == 0 and covered[-1][1] == rows and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            if rows >= world:
+                assert max(shares) - min(shares) <= 2 * (2 * n - 1)

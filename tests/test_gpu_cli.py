@@ -99,6 +99,98 @@ def test_train_runs_and_improves(tmp_path):
     assert 0 < p.extendInsert < 1 and abs(p.match[0, 0, 0] + p.match[0, 1, 0] + p.match[0, 2, 0] + p.match[0, 3, 0] - 1) < 1e-5
 
 
+def _em_lines(stderr):
+    """(log-likelihood, log-prior, sum) of every "EM iteration" line (src/qmodel.cpp:2203)."""
+    import re
+    out = []
+    for l in stderr.splitlines():
+        m = re.match(r"EM iteration (\d+): log-likelihood \((\S+)\) \+ log-prior \((\S+)\) = (\S+)", l)
+        if m:
+            assert int(m.group(1)) == len(out) + 1
+            out.append(tuple(float(m.group(k)) for k in (2, 3, 4)))
+    return out
+
+
+def _numbers(text):
+    import re
+    return np.array(list(map(float, re.findall(r"-?\d+\.?\d*(?:e[-+]?\d+)?", text))))
+
+
+def _layout(text):
+    import re
+    return re.sub(r"-?\d+\.?\d*(?:e[-+]?\d+)?", "#", text).split()
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_train_files_and_stopping_iteration_match_the_oracles_em_loop(tmp_path, order):
+    """SURVEY 8(f) #2 end to end: `quaff train -maxiter 3 -saveprior -savecounts -savecountswithprior -saveparams` on 40 reads
+    against the oracle's own EM loop (QuaffTrainer::fitUnlimited, src/qmodel.cpp:2186-2231) driving the oracle's own E-step:
+    the auto-prior (initCounts(9, 9, 5, 1, null), incl. the `i == j` quirk for -order 1) byte for byte; the last E-step's
+    counts and counts + prior at 1e-4 relative; the fitted parameters (6 s.f. text; q, r come out of a Newton iteration that
+    stops at a relative 1e-4 step); log-likelihood and log-prior of every iteration; and `-mininc` stops both at the same
+    iteration."""
+    rng = np.random.default_rng(57 + order)
+    ref = rand_seq(rng, 3000)
+    reads = make_reads(rng, ref, 40, 250)
+    fa, fq = tmp_path / "ref.fa", tmp_path / "reads.fq"
+    fa.write_text(">ref\n" + ref + "\n")
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
+    null_path = os.path.join(GOLDEN, "testquaffnullparams.json")
+    null = O.NullParams.from_json(open(null_path).read())
+    ml, gl = 1 + order, order
+    x = O.FastSeq("ref", ref)
+    refs = [x, x.revcomp()]
+    prior = O.init_counts(ml, gl, 9, 9, 5, 1, null)
+    seed = O.m_step(prior, ml, gl)                          # requireParamsOrUsePrior, t/quaff.cpp:370-376
+    cfg = O.DPConfig()
+    files = {k: tmp_path / (k + ".json") for k in ("prior", "counts", "withprior", "params")}
+    extra = ["-order", str(order)] if order else []
+    out = subprocess.run([QUAFF, "train", str(fa), str(fq), "-null", null_path, "-maxiter", "3", "-mininc", "0", "-saveprior", str(files["prior"]),
+                          "-savecounts", str(files["counts"]), "-savecountswithprior", str(files["withprior"]),
+                          "-saveparams", str(files["params"])] + extra, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == ""                                  # -saveparams: nothing on stdout (src/qmodel.cpp:2224-2227; t/quaff.cpp)
+    want_p, log = O.train(refs, reads, null, prior, seed, cfg, max_iter=3, min_inc=0.0)
+    assert len(log) == 3 and "params" in log[-1]
+    assert files["prior"].read_text() == O.param_counts_json(prior, ml, gl)
+    em = _em_lines(out.stderr)
+    assert len(em) == len(log)
+    for (ll, lp, tot), rec in zip(em, log):
+        assert abs(ll - rec["loglike"]) <= 1e-4 * abs(rec["loglike"]) and abs(lp - rec["logprior"]) <= 1e-4 * abs(rec["logprior"])
+        assert abs(tot - (rec["loglike"] + rec["logprior"])) <= 1e-4 * abs(tot)
+    for name, want in (("counts", log[-1]["counts"]), ("withprior", log[-1]["counts_with_prior"])):
+        got_text, want_text = files[name].read_text(), O.param_counts_json(want, ml, gl)
+        assert _layout(got_text) == _layout(want_text), name
+        g, w = _numbers(got_text), _numbers(want_text)
+        big = np.abs(w) > 1e-6
+        np.testing.assert_allclose(g[big], w[big], rtol=1.2e-4, err_msg=name)       # 1e-4 + the 6 s.f. of the text
+        assert np.all(np.abs(g[~big]) < 2e-6)
+    got_text, want_text = files["params"].read_text(), O.params_json(want_p)
+    assert _layout(got_text) == _layout(want_text)
+    gp, wp = O.Params.from_json(got_text), O.Params.from_json(want_text)
+    np.testing.assert_allclose(gp.match[:, :, 0], wp.match[:, :, 0], rtol=2e-4, atol=1e-9)           # symbol probabilities
+    np.testing.assert_allclose(gp.insert[:, 0], wp.insert[:, 0], rtol=2e-4)
+    np.testing.assert_allclose(gp.match[:, :, 1:], wp.match[:, :, 1:], rtol=5e-3)                     # (q, r): Newton stops at 1e-4
+    np.testing.assert_allclose(gp.insert[:, 1:], wp.insert[:, 1:], rtol=5e-3)
+    for a, b in ((gp.beginInsert, wp.beginInsert), (gp.beginDelete, wp.beginDelete), ([gp.extendInsert, gp.extendDelete], [wp.extendInsert, wp.extendDelete])):
+        np.testing.assert_allclose(a, b, rtol=2e-4)
+    # the stopping rule: a -mininc between two consecutive relative rises of the oracle's series stops both after the same E-step
+    _, free = O.train(refs, reads, null, prior, seed, cfg, max_iter=5, min_inc=-1.0)
+    v = [r["loglike"] + r["logprior"] for r in free]
+    rise = [(v[k] - v[k - 1]) / abs(v[k - 1]) for k in range(1, len(v))]
+    k = max(range(len(rise) - 1), key=lambda q: rise[q] / max(rise[q + 1], 1e-300) if rise[q] > 0 else 0)
+    assert rise[k] > 1.5 * rise[k + 1], rise
+    min_inc = (rise[k] * max(rise[k + 1], rise[k] * 1e-3)) ** 0.5 if rise[k + 1] > 0 else rise[k] / 2
+    _, stopped = O.train(refs, reads, null, prior, seed, cfg, max_iter=10, min_inc=min_inc)
+    assert len(stopped) == k + 3 and "params" not in stopped[-1]       # E-steps 1 .. k + 3; the last one found the rise too small
+    out2 = subprocess.run([QUAFF, "train", str(fa), str(fq), "-null", null_path, "-maxiter", "10", "-mininc", repr(float(min_inc))] + extra,
+                          capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert len(_em_lines(out2.stderr)) == len(stopped)
+    final = O.Params.from_json(out2.stdout)                           # the parameters of the last M-step that ran
+    np.testing.assert_allclose(final.match[:, :, 0], stopped[-2]["params"].match[:, :, 0], rtol=2e-4, atol=1e-9)
+
+
 def test_batches_spread_over_devices_give_the_same_output(tmp_path):
     """`-gpus n` spreads read blocks (align, count/train) or pair-list blocks (overlap) over one context per device and
     prints in input order.  QUAFF_HIP_DEVICES names the device of each context explicitly; "0,0,0" puts three contexts

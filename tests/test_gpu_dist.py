@@ -133,3 +133,45 @@ def test_comm_init_all_wants_one_gpu_per_context():
     v, ll = a.allreduce_counts(np.arange(10.0), 2.5)
     assert np.array_equal(v, np.arange(10.0)) and ll == 2.5
     a.close(); b.close()
+
+
+LONELY = textwrap.dedent("""
+    import sys, time
+    sys.path.insert(0, %r)
+    import quaff_amd as Q
+    from quaff_amd.api import QuaffHipError
+    ctx = Q.Context(0)
+    ctx.set_params_json(None)
+    uid = Q.Context.comm_unique_id()           # (an id of its own: the other process holds a different one)
+    t0 = time.time()
+    try:
+        ctx.comm_init_rank(uid, int(sys.argv[1]), 2)
+    except QuaffHipError as e:
+        print("STATUS", e.code, "%%.1f" %% (time.time() - t0), str(e))
+        assert ctx.comm_size() == 0
+        sys.exit(3)
+    print("JOINED")
+""") % ROOT
+
+
+def test_missing_peer_returns_a_status_instead_of_hanging(tmp_path):
+    """qf_comm_init_rank when a peer never joins (it died before the E-step, or holds another id): the library gives up after
+    QUAFF_HIP_COMM_TIMEOUT seconds with QF_ERR_DEVICE and a message, it does not hang (ncclCommInitRank itself blocks until all
+    ranks have called it; src/qmodel.cpp:2416-2422 is the reduce this guards).  Two processes, each the only member of its own
+    two-rank communicator (mismatched ids): both must exit non-zero by themselves; the parent's own timeout is only the backstop
+    and, if it strikes, kills the child (no exec from a process that has touched the GPU)."""
+    script = tmp_path / "lonely.py"
+    script.write_text(LONELY)
+    env = dict(os.environ, QUAFF_HIP_COMM_TIMEOUT="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for rank in (0, 1)]
+    for rank, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            pytest.fail("rank %d was still waiting for its peer after 150 s" % rank)
+        assert p.returncode == 3, (rank, p.returncode, out[-500:], err[-1500:])
+        status = [l for l in out.splitlines() if l.startswith("STATUS")][0].split(None, 3)
+        assert int(status[1]) == -1 and 3.0 <= float(status[2]) < 60.0 and "waiting for the other ranks" in status[3]

@@ -109,3 +109,89 @@ def test_negbinom_fit_degenerate_count_vectors():
         assert np.isfinite(p) and np.isfinite(r) and 0 < p <= 1 and r > 0, (vec, status, p, r)
         qo, ro = O.fit_negbinom(np.array(vec, float))
         assert abs(p - qo) <= 2e-3 * qo and abs(r - ro) <= 2e-3 * ro, (vec, status, p, r, qo, ro)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the prior, its log-density and the EM stopping rule (src/qmodel.cpp:431-456, 1681-1710, 2204-2206) against
+# the oracle's restatement; no device.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ml,gl", [(1, 0), (2, 1), (3, 2)])
+@pytest.mark.parametrize("with_null", [True, False])
+def test_auto_prior_init_counts(ml, gl, with_null, tmp_path):
+    """QuaffParamCounts::initCounts(9, 9, 5, 1, null) -- the prior `quaff train` sets itself (t/quaff.cpp:490-512) -- for order 0,
+    1 and 2, with and without a null model, byte for byte as counts JSON.  For match contexts longer than one base the
+    reference's `i == j` test (src/qmodel.cpp:446,448) gives the identity pseudocount only to contexts with an all-A prefix."""
+    import numpy as np
+    from oracle import oracle as O
+    null_path = os.path.join(GOLDEN, "testquaffnullparams.json")
+    null = O.NullParams.from_json(golden("testquaffnullparams.json")) if with_null else None
+    want = O.init_counts(ml, gl, 9, 9, 5, 1, null)
+    got = selftest("initcounts", str(ml), str(gl), "9", "9", "5", "1", *([null_path] if with_null else []))
+    assert got == O.param_counts_json(want, ml, gl)
+    cv = O.CountsView(want, ml, gl)
+    sums = cv.mat.sum(axis=2)                      # negbinom pdf sums to ~1 over the 94 qualities: the row sum is the pseudocount
+    for i in range(4):
+        for j in range(4 ** ml):
+            ident = abs(sums[i, j] - 5) < 0.05
+            assert ident == (i == j), (i, j, sums[i, j])          # j < 4 <=> the context's prefix is all A
+    back, ml2, gl2 = O.counts_from_json(got)
+    assert (ml2, gl2) == (ml, gl) and np.allclose(back, want, rtol=2e-5, atol=0)
+
+
+def test_log_prior_and_expected_loglike(tmp_path):
+    """QuaffParamCounts::logPrior / expectedLogLike of the auto-prior under the default parameters, under the M-step's own fit of
+    the prior (the seed `quaff train` starts from without -params, t/quaff.cpp:370-376) and under -order 2 parameters: product
+    == oracle to rounding; the beta / Dirichlet terms also against scipy's densities."""
+    import math
+    import sys
+    import numpy as np
+    from scipy.stats import beta, dirichlet
+    from oracle import oracle as O
+    sys.path.insert(0, ROOT)
+    import bench
+    null_path = os.path.join(GOLDEN, "testquaffnullparams.json")
+    for ml, gl, params_text in ((1, 0, golden("defaultparams.json")), (1, 0, None), (3, 2, bench.order2_params_json())):
+        prior_text = selftest("initcounts", str(ml), str(gl), "9", "9", "5", "1", null_path)
+        pc, _, _ = O.counts_from_json(prior_text)
+        cpath, ppath = tmp_path / "prior.json", tmp_path / "params.json"
+        cpath.write_text(prior_text)
+        if params_text is None:
+            params_text = selftest("fit", str(cpath))                 # the seed: prior.fit()
+            seed = O.m_step(pc, ml, gl)
+            assert params_text == O.params_json(seed)
+        ppath.write_text(params_text)
+        p = O.Params.from_json(params_text)
+        got_lp, got_ell = (float(v) for v in selftest("logprior", str(cpath), str(ppath)).split())
+        want = O.log_prior(pc, p)
+        assert math.isfinite(want) and abs(got_lp - want) <= 1e-11 * abs(want), (ml, gl, got_lp, want)
+        # third opinion on the closed-form pieces (scipy): transitions and the symbol Dirichlets
+        cv = O.CountsView(pc, ml, gl)
+        tr = sum(beta.logpdf(p.beginInsert[g], cv.beginInsertYes[g] + 1, cv.beginInsertNo[g] + 1) +
+                 beta.logpdf(p.beginDelete[g], cv.beginDeleteYes[g] + 1, cv.beginDeleteNo[g] + 1) for g in range(p.Kg))
+        tr += beta.logpdf(p.extendInsert, cv.ext[1] + 1, cv.ext[0] + 1) + beta.logpdf(p.extendDelete, cv.ext[3] + 1, cv.ext[2] + 1)
+        di = dirichlet.logpdf(np.array(p.insert[:, 0]) / p.insert[:, 0].sum(), 1 + cv.ins.sum(axis=1))
+        ours = sum(O.log_beta_pdf(p.beginInsert[g], cv.beginInsertYes[g], cv.beginInsertNo[g]) +
+                   O.log_beta_pdf(p.beginDelete[g], cv.beginDeleteYes[g], cv.beginDeleteNo[g]) for g in range(p.Kg))
+        ours += O.log_beta_pdf(p.extendInsert, cv.ext[1], cv.ext[0]) + O.log_beta_pdf(p.extendDelete, cv.ext[3], cv.ext[2])
+        assert abs(ours - tr) <= 1e-9 * max(1.0, abs(tr))
+        if abs(p.insert[:, 0].sum() - 1) < 1e-9:
+            assert abs(O.log_dirichlet_pdf(list(1 + cv.ins.sum(axis=1)), list(p.insert[:, 0])) - di) <= 1e-9 * max(1.0, abs(di))
+        assert math.isfinite(got_ell)
+
+
+def test_em_stopping_rule():
+    """fitUnlimited's test (src/qmodel.cpp:2204-2206): never before the second E-step; stop when logLike + logPrior < previous +
+    |previous| * minInc, i.e. also on a rise smaller than the fraction."""
+    from oracle import oracle as O
+
+    def oracle_steps(min_inc, vals):
+        prev, it = float("-inf"), 0
+        for it, v in enumerate(vals):
+            if O.em_converged(it, v, prev, min_inc):
+                return it
+            prev = v
+        return len(vals)
+    for min_inc, vals in ((0.01, [-1000, -900, -895, -894]), (0.01, [-1000, -1100]), (0.0, [-5, -4, -4, -3]), (0.0, [-5, -4, -4.5]),
+                          (0.5, [-100, -40, -30]), (0.01, [-1000]), (0.01, [10, 10.05, 10.2, 10.21]), (1e-4, [-1e6, -999950, -999900, -999899])):
+        got = int(selftest("converge", repr(min_inc), *[repr(float(v)) for v in vals]))
+        assert got == oracle_steps(min_inc, vals), (min_inc, vals, got)
