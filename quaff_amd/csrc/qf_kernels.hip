@@ -1554,6 +1554,24 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
     // the column's context word is fetched a step ahead (two wavefronts per SIMD do not hide a load per step), and the
     // previous column's word is simply the previous step's
     uint32_t wPrev = ctxword(jlo - skew - 1), wCur = ctxword(jlo - skew);
+    // The row above a wavefront's lane 0 does not come by DPP: the stripe's first lane reads the previous stripe's last row from
+    // the global boundary buffer, the first lane of the other wavefronts the previous wavefront's ring in LDS.  Both are fetched
+    // ONE STEP AHEAD (the boundary row is final before the stripe starts; a ring slot is read K steps after it was written,
+    // across a workgroup barrier, instead of K + 1), so that wavefront 0 does not begin every step with a round trip to
+    // global memory: 377 -> 366 ms per 256 reads of config 5.  (Fetching the step's eight emissions a step ahead as well cost
+    // 24 registers and bought nothing: 373 ms.)
+    double nbM = QF_NEG_INF, nbI = QF_NEG_INF, nbD = QF_NEG_INF;
+    auto fetch_above = [&](int tt) {   // what lane 0 of this wavefront needs at step tt (column jlo + tt - skew)
+      if (wv == 0) {
+        const int jc = min(max(jlo + tt - skew, 0), yLen + 1);
+        nbM = bprev[jc]; nbI = bprev[(yLen + 2) + jc]; nbD = bprev[2 * (yLen + 2) + jc];
+      } else {
+        // the previous wavefront's last lane was on that column at step tt - K - 1
+        const double* x1 = s_x[wv - 1][(tt + 2 * R - K - 1) % R];
+        nbM = x1[0]; nbI = x1[1]; nbD = x1[2];
+      }
+    };
+    if (l == 0) fetch_above(0);
     for (int t = 0; t < steps; ++t) {
       const int j = jlo + t - skew;
       const bool colvalid = j >= jlo && j <= jhi;
@@ -1568,14 +1586,8 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       // wavefront, from the previous wavefront's ring, or (lane 0 of the stripe) from the boundary buffer
       double upM = dpp_from_below<64, false>(p1M), upI = dpp_from_below<64, false>(p1I), upD = dpp_from_below<64, false>(p1D);   // DPP wave shift, not ds_bpermute
       if (l == 0) {
-        if (wv == 0) {
-          const int jc = min(max(j, 0), yLen + 1);
-          upM = bprev[jc]; upI = bprev[(yLen + 2) + jc]; upD = bprev[2 * (yLen + 2) + jc];
-        } else {
-          // the previous wavefront's last lane was on column j at step t-K-1
-          const double* x1 = s_x[wv - 1][(t + 2 * R - K - 1) % R];
-          upM = x1[0]; upI = x1[1]; upD = x1[2];
-        }
+        upM = nbM; upI = nbI; upD = nbD;
+        fetch_above(t + 1);
       }
       double dgM = dgMnext, dgI = dgInext, dgD = dgDnext;
       dgMnext = upM; dgInext = upI; dgDnext = upD;
@@ -1643,7 +1655,11 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
         tbw[woff + (unsigned long long)t * G + L] = tbword;
         if (L == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
       }
-      if (t % K == K - 1) __syncthreads();   // ring slots are read K+1 / K+2 steps after they are written
+      // Ring slots are read K / K+1 steps after they are written.  The barrier orders LDS only (LDS operations complete in
+      // order: lgkmcnt(0)); __syncthreads() would also wait for every global access in flight -- the traceback store just
+      // issued and the loads fetched a step ahead -- i.e. a round trip to HBM every K steps.  The boundary row written to
+      // global memory is read by the next stripe, behind the full barrier at the end of this one.
+      if (t % K == K - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     __syncthreads();   // everybody is done with the ring and the boundary row before the next stripe resets them
     woff += (unsigned long long)steps * G;
