@@ -503,7 +503,8 @@ class TrainJob(Job):
         if self.order is None:
             self.order = res["sort_order"]     # later EM iterations run on the pruned reference order (the warm-up provides it)
         if self.world > 1 or self.rccl:
-            self.global_counts, self.global_ll = self.dist.estep_allreduce(res["counts"], res["loglike"], self.ctx)   # the E-step's only exchange
+            # the E-step's only exchange, on the order-free fixed-point words: the same totals for any number of ranks
+            self.global_counts, self.global_ll, self.global_fx = self.dist.estep_allreduce_exact(res["counts_exact"], res["loglike_exact"], self.ctx)
         for k, v in res["ms"].items():
             self.phase[k] = self.phase.get(k, 0.0) + v
         for c in res["classes"]:

@@ -26,7 +26,7 @@
  *   QuaffBackwardMatrix ctor         src/qmodel.cpp:1393-1510 qf_count_resident (backward kernels + counts)
  *   QuaffCountingTask::run           src/qmodel.cpp:2238-2271 qf_count_resident (pruning, weights, new order)
  *   QuaffParamCounts(QuaffCounts)    src/qmodel.cpp:407-417   qf_count_result.counts layout
- *   QuaffCountingScheduler::finalCounts/finalLogLike src/qmodel.cpp:2416-2422 sum over the batch, then qf_allreduce_counts across GPUs
+ *   QuaffCountingScheduler::finalCounts/finalLogLike src/qmodel.cpp:2416-2422 sum over the batch (order-free: counts_exact), then qf_allreduce_counts[_exact] across GPUs
  *   QuaffOverlapScores ctor          src/qoverlap.cpp:9-75    (built inside qf_overlap_resident, once per strand flag)
  *   QuaffOverlapViterbiMatrix ctor   src/qoverlap.cpp:77-160  qf_overlap_resident (overlap fill kernel)
  *   QuaffOverlapViterbiMatrix::alignment :162-290, scoreAdjustedAlignment :292-302   qf_overlap_resident
@@ -206,6 +206,15 @@ typedef struct qf_count_result {
   uint64_t cells_class[QF_MAX_FILL_CLASSES];
   uint32_t units_class[QF_MAX_FILL_CLASSES];
   uint32_t n_fill_classes;
+  /* The same sums as 128-bit fixed point (64 fractional bits, two's complement), (low, high) 64-bit words per value: value =
+   * high + low / 2^64.  The device adds the count terms as integers, so these words -- and `counts`, which is their
+   * conversion -- are the same whatever order the terms were added in: run to run, and however the batch was cut into pieces
+   * inside the call.  The words of several calls add exactly (qf_exact_add) and convert once (qf_exact_to_double): totals
+   * then do not depend on how the reads were split over calls, contexts or GPUs either (qf_allreduce_counts_exact).  The
+   * reference adds per-read counts in read order (src/qmodel.cpp:2416-2422), i.e. with one fixed rounding sequence; this is
+   * another fixed one. */
+  const uint64_t *counts_exact;   /* [counts_size][2] */
+  uint64_t loglike_exact[2];      /* the sum of read_loglike, same format; the "not finite" marker if a read has no finite term */
 } qf_count_result;
 
 /* One E-step over the resident reads.  sort_in / sort_n_in (optional, [n_reads*n_refs] / [n_reads]) give each
@@ -233,6 +242,16 @@ void qf_comm_destroy(qf_ctx *ctx);     /* also done by qf_ctx_destroy */
  * calls it with the same n.  Summation order inside RCCL depends on the rank count, so sums agree between runs on
  * different numbers of GPUs to rounding (1e-15 relative), not bit for bit. */
 int qf_allreduce_counts(qf_ctx *ctx, double *counts, uint32_t n, double *loglike);
+
+/* 128-bit fixed-point sums (qf_count_result.counts_exact / loglike_exact): acc[k] += add[k] for n values of two words each;
+ * conversion to / from double (values beyond +-9.2e18 and non-finite ones become a marker that absorbs every sum and converts to
+ * -inf).  Host arithmetic, no context. */
+void qf_exact_add(uint64_t *acc, const uint64_t *add, uint32_t n);
+void qf_exact_to_double(const uint64_t *fx, uint32_t n, double *out);
+void qf_exact_from_double(const double *v, uint32_t n, uint64_t *fx);
+/* The E-step reduction on the exact words (n values of two words, e.g. counts_exact followed by loglike_exact), in place:
+ * every rank ends with the same 128-bit totals, identical for any number of ranks.  Collective, like qf_allreduce_counts. */
+int qf_allreduce_counts_exact(qf_ctx *ctx, uint64_t *fx, uint32_t n);
 
 /* ---- read-vs-read overlap (quaff overlap) -------------------------------------------------- */
 typedef struct qf_overlap_alignment {

@@ -76,7 +76,8 @@ class _CountResult(C.Structure):
                 ("ms_prep", C.c_float), ("ms_seed", C.c_float), ("ms_forward", C.c_float), ("ms_plan", C.c_float),
                 ("ms_backward", C.c_float), ("ms_total", C.c_float),
                 ("ms_forward_class", C.c_float * 16), ("ms_backward_class", C.c_float * 16), ("cells_class", C.c_uint64 * 16),
-                ("units_class", C.c_uint32 * 16), ("n_fill_classes", C.c_uint32)]
+                ("units_class", C.c_uint32 * 16), ("n_fill_classes", C.c_uint32),
+                ("counts_exact", C.POINTER(C.c_uint64)), ("loglike_exact", C.c_uint64 * 2)]
 
 
 class _OverlapAlignment(C.Structure):
@@ -122,7 +123,8 @@ EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name",
            "qf_align_batch", "qf_envelope", "qf_cigar_string", "qf_synth_ref", "qf_synth_reads", "qf_scores_from_json",
            "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks",
            "qf_device_count", "qf_set_score_threshold", "qf_comm_unique_id", "qf_comm_init_rank", "qf_comm_init_all",
-           "qf_comm_size", "qf_comm_destroy", "qf_allreduce_counts", "qf_overlap_rows", "qf_overlap_rows_pairs"]
+           "qf_comm_size", "qf_comm_destroy", "qf_allreduce_counts", "qf_overlap_rows", "qf_overlap_rows_pairs",
+           "qf_exact_add", "qf_exact_to_double", "qf_exact_from_double", "qf_allreduce_counts_exact"]
 
 
 def load_library():
@@ -178,6 +180,11 @@ def load_library():
         L.qf_comm_destroy.argtypes = [C.c_void_p]
         L.qf_comm_destroy.restype = None
         L.qf_allreduce_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.qf_allreduce_counts_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        for f in (L.qf_exact_add, L.qf_exact_to_double, L.qf_exact_from_double):
+            f.restype = None
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] if f is not L.qf_exact_to_double else [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.qf_exact_from_double.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -200,6 +207,30 @@ def scores_from_json(text=None):
     if rc:
         raise QuaffHipError(rc, err.value.decode())
     return ml.value, gl.value, ins, mat, trans
+
+
+def exact_add(acc, add):
+    """acc += add for arrays of 128-bit fixed-point values ((low, high) uint64 words per value: qf_count_result.counts_exact);
+    returns a new array."""
+    a = np.ascontiguousarray(acc, np.uint64).copy().reshape(-1, 2)
+    b = np.ascontiguousarray(add, np.uint64).reshape(-1, 2)
+    assert a.shape == b.shape
+    load_library().qf_exact_add(a.ctypes.data, b.ctypes.data, len(a))
+    return a
+
+
+def exact_to_double(fx):
+    a = np.ascontiguousarray(fx, np.uint64).reshape(-1, 2)
+    out = np.zeros(len(a))
+    load_library().qf_exact_to_double(a.ctypes.data, len(a), out.ctypes.data)
+    return out
+
+
+def exact_from_double(v):
+    a = np.ascontiguousarray(v, np.float64).reshape(-1)
+    out = np.zeros((len(a), 2), np.uint64)
+    load_library().qf_exact_from_double(a.ctypes.data, len(a), out.ctypes.data)
+    return out
 
 
 def synth_ref(seed, length):
@@ -307,6 +338,13 @@ class Context:
         ll = C.c_double(float(loglike))
         self._chk(self.L.qf_allreduce_counts(self.h, v.ctypes.data, len(v), C.byref(ll)))
         return v, ll.value
+
+    def allreduce_counts_exact(self, fx):
+        """Sum 128-bit fixed-point values ((n, 2) uint64: counts_exact, loglike_exact ...) over all ranks, exactly: every rank gets
+        the same words for any number of ranks."""
+        v = np.ascontiguousarray(fx, np.uint64).copy().reshape(-1, 2)
+        self._chk(self.L.qf_allreduce_counts_exact(self.h, v.ctypes.data, len(v)))
+        return v
 
     def set_score_threshold(self, min_score):
         """Alignments scoring below min_score are not traced back / returned (-inf = all; the CLI's -threshold)."""
@@ -418,6 +456,10 @@ class Context:
                 "sort_order": (order.astype(np.uint32), cnt.astype(np.uint32)) if packed_order
                               else [list(map(int, order[r, :int(cnt[r])])) for r in range(res.n_reads)],
                 "counts": arr(res.counts, res.counts_size), "loglike": res.loglike, "total_cells": int(res.total_cells),
+                # the same sums as 128-bit fixed point, (low, high) words per value: order-free, they add exactly across calls
+                "counts_exact": (np.ctypeslib.as_array(res.counts_exact, (2 * res.counts_size,)).copy().reshape(-1, 2)
+                                 if res.counts_size else np.zeros((0, 2), np.uint64)),
+                "loglike_exact": np.array([res.loglike_exact[0], res.loglike_exact[1]], np.uint64),
                 "backward_cells": int(res.backward_cells), "forward_bytes": int(res.forward_bytes),
                 "ms": {k: getattr(res, "ms_" + k) for k in ("prep", "seed", "forward", "plan", "backward", "total")},
                 "classes": [{"cls": k, "geometry": self.L.qf_fill_class_name(k).decode().replace("k_viterbi_", ""),

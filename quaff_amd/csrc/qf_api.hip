@@ -173,7 +173,15 @@ struct qf_ctx : Slot {
   std::vector<uint64_t> read_off;
   uint64_t read_total = 0, read_maxlen = 0;
   bool reads_have_qual = false;
-  DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll;
+  uint32_t read_qmin = 0, read_qmax = 93;   // quality values the resident reads use (device scan at upload)
+  DevBuf d_seq, d_qual, d_roff, d_tok, d_ctx, d_skmer, d_nll, d_qrange;
+  // E-step: the match-emission rows of qualities read_qmin .. read_qmax, quality-major (PrepArgs::em_qmajor_Km), + a -inf row
+  DevBuf d_ematch_q;
+  uint64_t ematch_q_params_epoch = 0;
+  uint32_t ematch_q_lo = 1, ematch_q_hi = 0;
+  uint64_t params_epoch = 0;
+  uint32_t prep_qmajor_Km = 0;     // layout the next prep_reads gives the context words' emission rows (0 = k-mer major)
+  bool count_qmajor = false;       // the running E-step uses the quality-major slice
   // batch state
   DevBuf d_cover, d_lse, d_counts, d_order_in, d_order_n_in,
       d_skip, d_ctxc, d_ins_sum, d_ins_sum_c, d_nll_c, d_rbucket, d_rcursor, d_rpos,
@@ -188,7 +196,8 @@ struct qf_ctx : Slot {
   HostBuf<qf_alignment> h_align;
   struct DenseChunk { uint32_t lo, hi; size_t runs0; bool second; };
   std::vector<DenseChunk> dense_chunks;   // best-per-read mode: where each chunk's records and runs went
-  std::vector<double> h_fwd, h_weight, h_rll, h_counts, h_pcounts;
+  std::vector<double> h_fwd, h_weight, h_rll, h_pcounts;
+  std::vector<uint64_t> h_counts_fx, h_pcounts_fx;   // E-step counts as 128-bit fixed point, (low, high) per entry: raw QuaffCounts layout / QuaffParamCounts layout
   std::vector<uint32_t> h_order, h_order_n;
   bool lse_uploaded = false;
   DevBuf d_lse_pack;            // the exact table packed for LDS (qf_device.hpp: kLsePack*); 0 bytes: not usable on this device
@@ -250,6 +259,8 @@ static std::mutex& device_fill_token(int device) {
   static std::mutex tokens[64];
   return tokens[device & 63];
 }
+
+static uint32_t sc_Km(const qf_ctx* c) { return c->scores.Km; }
 
 static int fail(Slot* c, int code, const std::string& msg) {
   c->err = msg;
@@ -328,7 +339,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_qrange, &c->d_ematch_q, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
@@ -407,6 +418,7 @@ static int install_params(qf_ctx* c, const Params& p) {
   c->have_params = true;
   c->ov_scores[0] = c->ov_scores[1] = false;
   ++c->prep_epoch;
+  ++c->params_epoch;
   return QF_OK;
 }
 
@@ -617,7 +629,17 @@ int qf_upload_reads(qf_ctx* c, const char* seq, const char* qual, const uint64_t
   if (qual) HIPCHK(c, hipMemcpyAsync(c->d_qual.p, qual, tot, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_roff.p, c->read_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_ctx.p, 0, (tot + 2 * kCtxPad) * 4, c->stream));
+  uint32_t qr[2] = {0, (uint32_t)kNQual - 1};
+  if (qual && tot) {   // which quality values occur (the E-step keeps only their emission rows in LDS)
+    const uint32_t init[2] = {0xFFFFFFFFu, 0};
+    HIPCHK(c, c->d_qrange.reserve(8));
+    HIPCHK(c, hipMemcpyAsync(c->d_qrange.p, init, 8, hipMemcpyHostToDevice, c->stream));
+    launch_qual_range(c->d_qual.as<char>(), tot, c->d_qrange.as<uint32_t>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(qr, c->d_qrange.p, 8, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->read_qmin = std::min(qr[0], (uint32_t)kNQual - 1);
+  c->read_qmax = std::max(std::min(qr[1], (uint32_t)kNQual - 1), c->read_qmin);
   c->reads_have_qual = qual != nullptr;
   c->read_index_k = 0;
   ++c->prep_epoch;
@@ -652,6 +674,8 @@ static int prep_reads(qf_ctx* c, int seed_k, hipStream_t side = nullptr) {
     c->null.tables(a.null_logEmit, a.null_log1mEmit, a.null_logSym, lq.data());
     a.null_logQual = c->d_nullq.as<double>();
   }
+  a.em_qmajor_Km = c->prep_qmajor_Km;
+  a.em_qmin = c->read_qmin;
   a.bc = c->d_bc.as<BatchCounters>();
   launch_prep_reads(a, c->n_reads, c->stream);
   if (side) {
@@ -1454,6 +1478,17 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
   fa.lse_h = c->d_lse.as<double>() + kLseHermiteOffset;
   fa.dp.ematch = c->d_ematch.as<double>();
   fa.dp.ematch_ninf_off = (uint32_t)((size_t)c->scores.Km * kNQ1 * 4 * 8);
+  if (c->count_qmajor) {   // the slice of the qualities in use, quality-major (qf_count_resident)
+    fa.dp.ematch = c->d_ematch_q.as<double>();
+    fa.dp.ematch_ninf_off = (uint32_t)((size_t)(c->read_qmax - c->read_qmin + 1) * sc.Km * 32);
+    fa.em_qmajor = 1;
+    fa.em_kshift = 2 * sc.match_len;
+    fa.em_qmin = c->read_qmin;
+    // Backward runs two workgroups per CU (its registers decide that), so each may take half the CU's 160 KB: 16.9 -> 15.1 ms
+    // on config 4.  Forward runs three on 53 KB each, which the order-2 slice does not fit beside the log-sum-exp pieces: it
+    // keeps the table in global memory unless the slice is small (QF_DEBUG_BIG_FORWARD_LDS: two workgroups with the table)
+    fa.lds_limit = 78 * 1024;
+  }
   fa.dp.eins = c->d_eins.as<double>();
   fa.dp.trans = c->d_trans.as<double>();
   fa.dp.d2d = sc.trans[4 * sc.Kg + 0];
@@ -1464,7 +1499,7 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
   fa.dp.local = cfg->local;
   fa.pair_fwd = S->d_pair_score.as<double>();
   fa.pair_weight = S->d_weight.as<double>();
-  fa.counts = c->d_counts.as<double>();
+  fa.counts = c->d_counts.as<unsigned long long>();
   fa.counts_stride = (csize + 31) & ~31ull;
   fa.Km = sc.Km;
   fa.no_band_shortcuts = (c->debug & QF_DEBUG_NO_BAND_SHORTCUTS) != 0;
@@ -1473,6 +1508,7 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
         FbArgs f2 = fa;
         f2.n_cls_units = bc.cls_count[cls];
         f2.cls_list = S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
+        if (!(c->debug & QF_DEBUG_BIG_FORWARD_LDS)) f2.lds_limit = 0;   // measured (config 4): 11.9 ms with the table in global memory at three workgroups per CU, 12.1 ms with it in LDS at two
         launch_forward_fill(cls, f2, s);
       }, 0, true))   // classes with few wavefronts first, on the high-priority streams: each of their wavefronts still runs its ~1 000 dependent steps
     return rc;
@@ -1568,7 +1604,9 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   const uint32_t csize = qf_counts_size(c);
   out->counts_size = csize;
   c->h_pcounts.assign(csize, 0.0);
+  c->h_pcounts_fx.assign((size_t)csize * 2, 0);
   out->counts = c->h_pcounts.data();
+  out->counts_exact = c->h_pcounts_fx.data();
   if (!n_pairs) return QF_OK;
   if (!c->reads_have_qual)  // QuaffBackwardMatrix ctor, src/qmodel.cpp:1398
     return fail(c, QF_ERR_ARG, "Forward-Backward algorithm requires quality scores to fit model");
@@ -1581,7 +1619,37 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
   HIPCHK(c, hipMemsetAsync(c->d_bc.p, 0, sizeof(BatchCounters), c->stream));
-  if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
+  // Match-emission table of the fills.  Every cell gathers one 8-byte entry of it, 64 different rows per wavefront: from LDS
+  // that is cheap, from L2 it is a large part of the fills' time.  The whole table -- (context k-mer, quality 0 .. 94) rows of 32
+  // bytes -- fits LDS beside the log-sum-exp pieces only for one-base contexts (12 KB); at -order 1 it is 49 KB, at -order 2
+  // 195 KB.  But a read set uses few quality values (Phred 5 .. 25 in the synthetic sets, ~40 in real ones), so the E-step
+  // numbers the rows QUALITY-major -- (q - qmin) Km + k-mer, in the reads' context words (prep) and in a re-ordered copy of
+  // the table -- and the rows of the qualities in use are one contiguous slice: 43 KB at -order 2 for 21 qualities.
+  c->count_qmajor = false;
+  {
+    const uint32_t qspan = c->read_qmax - c->read_qmin + 1;
+    const size_t full = (size_t)sc_Km(c) * kNQ1 * 32, slice = (size_t)qspan * sc_Km(c) * 32;
+    if (full > 24 * 1024 && slice <= 48 * 1024 && !(c->debug & QF_DEBUG_GLOBAL_TABLES)) {
+      const Scores& s = c->scores;
+      if (c->ematch_q_params_epoch != c->params_epoch || c->ematch_q_lo != c->read_qmin || c->ematch_q_hi != c->read_qmax) {
+        std::vector<double> em((size_t)qspan * s.Km * 4 + 4, -INFINITY);   // + the -inf row slots outside a band read
+        for (uint32_t t = 0; t < 4; ++t)
+          for (uint32_t k = 0; k < s.Km; ++k)
+            for (uint32_t q = c->read_qmin; q <= c->read_qmax; ++q)
+              em[((size_t)(q - c->read_qmin) * s.Km + k) * 4 + t] = s.mat[((size_t)t * s.Km + k) * kNQ1 + q];
+        HIPCHK(c, c->d_ematch_q.reserve(em.size() * 8));
+        HIPCHK(c, hipMemcpy(c->d_ematch_q.p, em.data(), em.size() * 8, hipMemcpyHostToDevice));
+        c->ematch_q_params_epoch = c->params_epoch;
+        c->ematch_q_lo = c->read_qmin;
+        c->ematch_q_hi = c->read_qmax;
+      }
+      c->count_qmajor = true;
+    }
+  }
+  c->prep_qmajor_Km = c->count_qmajor ? c->scores.Km : 0;
+  const int prep_rc = prep_reads(c, sparse ? cfg->kmer_len : 0);
+  c->prep_qmajor_Km = 0;     // (the other entry points number the rows k-mer major; every call derives its own context words)
+  if (prep_rc) return prep_rc;
   // pairs outside the read's reference order are not even seeded (their LL stays -inf, qmodel.cpp:2245)
   HIPCHK(c, c->d_order_in.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_order_n_in.reserve((size_t)n_reads * 4));
@@ -1609,12 +1677,13 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
     if (pb.error & 4u) return fail(c, QF_ERR_SYMBOL, "Unknown symbol in read " + std::to_string(pb.error_detail));
   }
   const size_t counts_stride = (csize + 31) & ~(size_t)31;
-  HIPCHK(c, c->d_counts.reserve(counts_stride * kCountReplicas * 8));
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, counts_stride * kCountReplicas * 8, c->stream));
+  // accumulators: 128-bit fixed point (two words per entry), kCountReplicas copies; behind them the summed words and doubles
+  HIPCHK(c, c->d_counts.reserve(counts_stride * kCountReplicas * 16 + (size_t)csize * 24));
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, counts_stride * kCountReplicas * 16, c->stream));
   c->h_fwd.resize(n_pairs);
   c->h_weight.resize(n_pairs);
   c->h_rll.resize(n_reads);
-  c->h_counts.resize(csize);
+  c->h_counts_fx.resize((size_t)csize * 2);
   c->h_order.resize(n_pairs);
   c->h_order_n.resize(n_reads);
   c->h_cells.resize(n_pairs);
@@ -1681,30 +1750,45 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
     if (rc_all != QF_OK) return rc_all;
   }
   out->ms_total = out->ms_prep + (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-  launch_sum_count_replicas(c->d_counts.as<double>(), csize, counts_stride, c->stream);
+  unsigned long long* d_sum_fx = c->d_counts.as<unsigned long long>() + counts_stride * kCountReplicas * 2;
+  launch_sum_count_replicas(c->d_counts.as<unsigned long long>(), csize, counts_stride, d_sum_fx, (double*)(d_sum_fx + (size_t)csize * 2), c->stream);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts.p, (size_t)csize * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_counts_fx.data(), d_sum_fx, (size_t)csize * 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const Scores& sc = c->scores;
 
-  // QuaffParamCounts(const QuaffCounts&), src/qmodel.cpp:407-417 (linear, so it commutes with the weighted sum)
+  // QuaffParamCounts(const QuaffCounts&), src/qmodel.cpp:407-417 (linear, so it commutes with the weighted sum), in the exact
+  // words; `counts` is their conversion
   const size_t ne = (size_t)(4 + 4 * sc.Km) * kNQual, Kg = sc.Kg;
-  const double* q = c->h_counts.data();
-  double* pc = c->h_pcounts.data();
-  std::copy(q, q + ne, pc);
+  typedef unsigned __int128 u128;
+  auto rd = [&](size_t k) -> u128 { return ((u128)c->h_counts_fx[2 * k + 1] << 64) | c->h_counts_fx[2 * k]; };
+  c->h_pcounts_fx.assign((size_t)csize * 2, 0);
+  auto wr = [&](size_t k, u128 v) { c->h_pcounts_fx[2 * k] = (uint64_t)v; c->h_pcounts_fx[2 * k + 1] = (uint64_t)(v >> 64); };
+  for (size_t k = 0; k < ne; ++k) wr(k, rd(k));
   for (size_t g = 0; g < Kg; ++g) {
-    const double m2m = q[ne + g], m2i = q[ne + Kg + g], m2d = q[ne + 2 * Kg + g], m2e = q[ne + 3 * Kg + g];
-    pc[ne + g] = m2m + m2d;            // beginInsertNo
-    pc[ne + Kg + g] = m2i + m2e;       // beginInsertYes
-    pc[ne + 2 * Kg + g] = m2m;         // beginDeleteNo
-    pc[ne + 3 * Kg + g] = m2d;         // beginDeleteYes
+    const u128 m2m = rd(ne + g), m2i = rd(ne + Kg + g), m2d = rd(ne + 2 * Kg + g), m2e = rd(ne + 3 * Kg + g);
+    wr(ne + g, m2m + m2d);            // beginInsertNo
+    wr(ne + Kg + g, m2i + m2e);       // beginInsertYes
+    wr(ne + 2 * Kg + g, m2m);         // beginDeleteNo
+    wr(ne + 3 * Kg + g, m2d);         // beginDeleteYes
   }
-  pc[ne + 4 * Kg + 0] = q[ne + 4 * Kg + 3];  // extendInsertNo  = i2m
-  pc[ne + 4 * Kg + 1] = q[ne + 4 * Kg + 2];  // extendInsertYes = i2i
-  pc[ne + 4 * Kg + 2] = q[ne + 4 * Kg + 1];  // extendDeleteNo  = d2m
-  pc[ne + 4 * Kg + 3] = q[ne + 4 * Kg + 0];  // extendDeleteYes = d2d
+  wr(ne + 4 * Kg + 0, rd(ne + 4 * Kg + 3));  // extendInsertNo  = i2m
+  wr(ne + 4 * Kg + 1, rd(ne + 4 * Kg + 2));  // extendInsertYes = i2i
+  wr(ne + 4 * Kg + 2, rd(ne + 4 * Kg + 1));  // extendDeleteNo  = d2m
+  wr(ne + 4 * Kg + 3, rd(ne + 4 * Kg + 0));  // extendDeleteYes = d2d
+  qf_exact_to_double(c->h_pcounts_fx.data(), csize, c->h_pcounts.data());
   double ll = 0;
   for (uint32_t r = 0; r < n_reads; ++r) ll += c->h_rll[r];  // serial read-order sum, qmodel.cpp:2420-2422
+  {  // ... and the same sum exactly (order-free), for callers that combine several calls
+    uint64_t acc[2] = {0, 0}, term[2];
+    for (uint32_t r = 0; r < n_reads; ++r) {
+      qf_exact_from_double(&c->h_rll[r], 1, term);
+      qf_exact_add(acc, term, 1);
+    }
+    out->loglike_exact[0] = acc[0];
+    out->loglike_exact[1] = acc[1];
+  }
+  out->counts_exact = c->h_pcounts_fx.data();
   uint64_t bcells = 0;
   for (uint32_t p = 0; p < n_pairs; ++p) if (c->h_weight[p] > 0) bcells += c->h_cells[p];
   out->forward = c->h_fwd.data();
@@ -2531,6 +2615,97 @@ int qf_allreduce_counts(qf_ctx* c, double* counts, uint32_t n, double* loglike) 
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
       return bail("the all-reduce did not complete within " + std::to_string((int)limit) + " s: a peer rank is missing");
     std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  return QF_OK;
+}
+
+// ---- 128-bit fixed point (64 fractional bits, two's complement), (low, high) words per value
+static const uint64_t kExactInfHigh = 0x8000000000000000ull;   // high word of the "not finite" marker (low word 0)
+static bool exact_is_marker(const uint64_t* v) { return v[1] == kExactInfHigh && v[0] == 0; }
+
+void qf_exact_add(uint64_t* acc, const uint64_t* add, uint32_t n) {
+  for (uint32_t k = 0; k < n; ++k) {
+    uint64_t* a = acc + 2 * (size_t)k;
+    const uint64_t* b = add + 2 * (size_t)k;
+    if (exact_is_marker(a) || exact_is_marker(b)) { a[0] = 0; a[1] = kExactInfHigh; continue; }
+    const unsigned __int128 s = (((unsigned __int128)a[1] << 64) | a[0]) + (((unsigned __int128)b[1] << 64) | b[0]);
+    a[0] = (uint64_t)s;
+    a[1] = (uint64_t)(s >> 64);
+  }
+}
+
+void qf_exact_from_double(const double* v, uint32_t n, uint64_t* fx) {
+  for (uint32_t k = 0; k < n; ++k) {
+    const double x = v[k];
+    uint64_t* o = fx + 2 * (size_t)k;
+    if (!std::isfinite(x) || std::fabs(x) >= 9.2e18) { o[0] = 0; o[1] = kExactInfHigh; continue; }
+    const double ax = std::fabs(x), ip = std::floor(ax);
+    unsigned __int128 m = ((unsigned __int128)(uint64_t)ip << 64) | (uint64_t)std::ldexp(ax - ip, 64);   // (ax - ip) 2^64 < 2^64, truncated
+    if (x < 0) m = (unsigned __int128)0 - m;
+    o[0] = (uint64_t)m;
+    o[1] = (uint64_t)(m >> 64);
+  }
+}
+
+void qf_exact_to_double(const uint64_t* fx, uint32_t n, double* out) {
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint64_t* v = fx + 2 * (size_t)k;
+    if (exact_is_marker(v)) { out[k] = -INFINITY; continue; }   // (a sum that met a non-finite term: log-likelihoods of reads without any path)
+    unsigned __int128 m = ((unsigned __int128)v[1] << 64) | v[0];
+    const bool neg = (v[1] >> 63) != 0;
+    if (neg) m = (unsigned __int128)0 - m;
+    // high + low 2^-64 in double (two roundings, always the same two: |high| < 2^53 for every sum this library forms)
+    const uint64_t hi = (uint64_t)(m >> 64), lo = (uint64_t)m;
+    const double d = (double)hi + std::ldexp((double)lo, -64);
+    out[k] = neg ? -d : d;
+  }
+}
+
+// The exact E-step reduction: every value as four 32-bit limbs in 64-bit words, one ncclAllReduce(sum, uint64) -- limb sums
+// cannot overflow below 2^32 ranks -- and the carries resolved afterwards: the same 128-bit totals on every rank, whatever the
+// number of ranks and the order RCCL adds in (qf_allreduce_counts adds doubles: equal to rounding only).
+int qf_allreduce_counts_exact(qf_ctx* c, uint64_t* fx, uint32_t n) {
+  if (!c || (n && !fx)) return QF_ERR_ARG;
+  if (!c->comm) return fail(c, QF_ERR_STATE, "no communicator (qf_comm_init_rank / qf_comm_init_all)");
+  if (!n) return QF_OK;
+  // a marker (non-finite sum) travels as a count in a fifth word per value
+  std::vector<uint64_t> limbs((size_t)n * 5);
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint64_t lo = fx[2 * (size_t)k], hi = fx[2 * (size_t)k + 1];
+    const bool mark = exact_is_marker(fx + 2 * (size_t)k);
+    uint64_t* L = &limbs[(size_t)k * 5];
+    L[0] = mark ? 0 : (lo & 0xFFFFFFFFull); L[1] = mark ? 0 : (lo >> 32); L[2] = mark ? 0 : (hi & 0xFFFFFFFFull); L[3] = mark ? 0 : (hi >> 32);
+    L[4] = mark ? 1 : 0;
+  }
+  const size_t m = limbs.size();
+  auto bail = [&](const std::string& what) {
+    (void)hipGetLastError();
+    comm_abort(c);
+    return fail(c, QF_ERR_DEVICE, what + " (communicator aborted)");
+  };
+  if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice");
+  if (c->d_comm.reserve(m * 8) != hipSuccess) return bail("cannot allocate the all-reduce staging buffer");
+  uint64_t* d = c->d_comm.as<uint64_t>();
+  if (hipMemcpyAsync(d, limbs.data(), m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the counts");
+  const ncclResult_t r = g_rccl.AllReduce(d, d, m, ncclUint64, ncclSum, c->comm, c->stream);
+  if (r != ncclSuccess) return bail(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  if (hipMemcpyAsync(limbs.data(), d, m * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the counts");
+  const double limit = comm_timeout_s();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return bail(std::string("all-reduce stream: ") + hipGetErrorString(q));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+      return bail("the all-reduce did not complete within " + std::to_string((int)limit) + " s: a peer rank is missing");
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint64_t* L = &limbs[(size_t)k * 5];
+    if (L[4]) { fx[2 * (size_t)k] = 0; fx[2 * (size_t)k + 1] = kExactInfHigh; continue; }
+    unsigned __int128 v = (unsigned __int128)L[0] + ((unsigned __int128)L[1] << 32) + ((unsigned __int128)L[2] << 64) + ((unsigned __int128)L[3] << 96);
+    fx[2 * (size_t)k] = (uint64_t)v;
+    fx[2 * (size_t)k + 1] = (uint64_t)(v >> 64);
   }
   return QF_OK;
 }

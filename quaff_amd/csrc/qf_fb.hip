@@ -41,6 +41,37 @@ __device__ __forceinline__ double lse2(const double* __restrict__ tab, double a,
 __device__ __forceinline__ float count_expf(double x) { return __expf((float)x); }
 __device__ __forceinline__ double count_exp(double x) { return (double)__expf((float)x); }
 
+// Expected counts from different bands meet in shared accumulators (the emission tables in global memory, the context-dependent
+// transition counts of a wavefront in LDS).  Added as floating point with atomics, their totals depend on the order the
+// hardware serves them in: run to run, and with every way of cutting a batch into pieces, contexts or devices.  They are added
+// as FIXED POINT instead, which is exact integer arithmetic: the total is the same whatever the order (the reference adds
+// per-read counts in read order, src/qmodel.cpp:2416-2422; any fixed total is as good as its).  An accumulator is two 64-bit
+// words that never exchange a carry while terms arrive, so both adds are fire-and-forget atomics (an add that has to return the
+// old value for its carry parks the wavefront for an LDS / L2 round trip per term: measured +35 % on Backward):
+//   word 1 += floor(v 2^32)                  the term down to 2^-32; 2^32 of headroom above a count total of 4e9
+//   word 0 += floor(frac(v 2^32) 2^32)       the next 32 bits, below 2^32 per term: headroom for 2^32 terms
+// value = word 1 / 2^32 + word 0 / 2^64, normalised into 64.64 fixed point once, after the last add (k_sum_count_replicas).
+// A term is a non-negative finite double; what it has below 2^-64 is truncated (of the term itself, not an accumulated error).
+__device__ __forceinline__ void fx_add_words(unsigned long long* acc, unsigned long long w0, unsigned long long w1) {
+  if (w0) atomicAdd(acc, w0);
+  if (w1) atomicAdd(acc + 1, w1);
+}
+__device__ __forceinline__ void fx_add(unsigned long long* acc, double v) {
+  if (!(v > 0.0)) return;   // zero, and never a NaN into an integer conversion
+  const double t = v * 4294967296.0, ft = floor(t);
+  const unsigned long long w0 = (unsigned long long)__double2uint_rz((t - ft) * 4294967296.0);
+  // floor(t) < 2^52 (every term this kernel forms: v < 2^20): its integer value is the mantissa of floor(t) + 2^52
+  const unsigned long long w1 = ft < 4503599627370496.0 ? ((unsigned long long)__double_as_longlong(ft + 4503599627370496.0) & 0xFFFFFFFFFFFFFull)
+                                                        : (unsigned long long)ft;
+  fx_add_words(acc, w0, w1);
+}
+
+// (context k-mer, quality) of a match-emission row number as the context words carry it (FbArgs::em_qmajor)
+__device__ __forceinline__ void em_row_decode(const FbArgs& a, uint32_t er, uint32_t& mk, uint32_t& q) {
+  if (a.em_qmajor) { mk = er & (a.Km - 1u); q = (er >> a.em_kshift) + a.em_qmin; }
+  else { mk = er / (kNQualDev + 1); q = er % (kNQualDev + 1); }
+}
+
 // Forward / Backward are compared at 1e-4 relative, so their log(1 + exp(-x)) need not be the reference's table
 // interpolant bit for bit.  The 800 KB table is a 64-way L2 gather per call; the same function as kLsePieces quadratic
 // pieces on a 1/128 grid (20 KB; host: ensure_lse, qf_api.hip) sits in LDS: within 3.3e-10 of log1p(exp(-x)), the
@@ -466,11 +497,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
   double* s_trans = lds_fb + kLseDoubles;
   double* s_acc_all = s_trans + ((4 * Kg + 1) & ~1u);             // [4 waves][4][64 lanes] i2m, d2m, i2i, d2d counts of each lane
-  double* s_tr_all = s_acc_all + 4 * 4 * 64;                      // [4 waves][3 Kg] context-dependent transition counts
-  double* s_em = s_tr_all + (GAPCTX ? ((4 * 3 * Kg + 1) & ~1u) : 0u);
+  unsigned long long* s_tr_all = (unsigned long long*)(s_acc_all + 4 * 4 * 64);   // [4 waves][3 Kg][2] context-dependent transition counts (fixed point: fx_add)
+  double* s_em = (double*)s_tr_all + (GAPCTX ? 4 * 3 * Kg * 2 : 0u);
   lseh_load(lds_fb, a.lse_h, threadIdx.x, 256);
   for (uint32_t k = threadIdx.x; k < 4 * Kg; k += 256) s_trans[k] = a.dp.trans[k];
-  if (GAPCTX) for (uint32_t k = threadIdx.x; k < 4 * 3 * Kg; k += 256) s_tr_all[k] = 0.0;
+  if (GAPCTX) for (uint32_t k = threadIdx.x; k < 4 * 3 * Kg * 2; k += 256) s_tr_all[k] = 0ull;   // (as doubles: +0.0)
   for (uint32_t k = threadIdx.x; k < 4 * 4 * 64; k += 256) s_acc_all[k] = 0.0;
   if (EMLDS) {
     for (uint32_t k = threadIdx.x; k < n_em; k += 256) s_em[k] = a.dp.ematch[k];
@@ -507,7 +538,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   if (T == 0) return;
-  double* s_tr = s_tr_all + (size_t)wv * 3 * Kg;
+  // Context-dependent transition counts of the wavefront's bands: LDS doubles, added by ds_add_f64 from lanes of different
+  // bands in whatever order the hardware takes them -- and still order-free, because every term is first rounded to a multiple of
+  // one quantum q = trM 2^-52 (trM = a power of two above anything the wavefront's total can reach: a column's transition
+  // counts sum to at most the pair's weight <= 1, so a band's to at most its columns): sums of multiples of q below 2 trM are
+  // exact in fp64, whatever the order.  The flush turns the exact sum into fixed-point words (fx_add).  q is 2^-40 for four
+  // 1 kb bands: against transition counts in the hundreds and thousands.
+  double* s_tr = (double*)(s_tr_all + (size_t)wv * 3 * Kg * 2);
+  const double trM = __longlong_as_double((long long)(1023 + 32 - __clz((UPW * T) | 1)) << 52);   // 2^(bits of UPW T) >= UPW T + 1
 
   const int d0 = dlo + l * B;
   const int bmax = active ? dhi - d0 : -1;
@@ -519,7 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   const double c_m2m = trans[0], c_m2i = trans[Kg], c_m2d = trans[2 * Kg];
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
-  double* __restrict__ cnt = a.counts + (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // contention: see kCountReplicas
+  unsigned long long* __restrict__ cnt = a.counts + 2 * (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // (lo, hi) per entry; contention: see kCountReplicas
   const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
 
   double Bm[B], Bi[B], Bd[B];   // Backward values of this lane's diagonals at the column of its previous step
@@ -704,28 +742,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
     if (colvalid) {
       if (!GAPCTX) { acc_m2m += (double)pf[5]; acc_m2i += (double)pf[6]; acc_m2d += (double)pf[7]; }
       else {
-        if (pf[5] != 0.f) unsafeAtomicAdd(&s_tr[gk], wgt * (double)pf[5]);
-        if (pf[6] != 0.f) unsafeAtomicAdd(&s_tr[Kg + gk], wgt * (double)pf[6]);
-        if (pf[7] != 0.f) unsafeAtomicAdd(&s_tr[2 * Kg + gk], wgt * (double)pf[7]);
+        if (pf[5] != 0.f) unsafeAtomicAdd(&s_tr[gk], (wgt * (double)pf[5] + trM) - trM);
+        if (pf[6] != 0.f) unsafeAtomicAdd(&s_tr[Kg + gk], (wgt * (double)pf[6] + trM) - trM);
+        if (pf[7] != 0.f) unsafeAtomicAdd(&s_tr[2 * Kg + gk], (wgt * (double)pf[7] + trM) - trM);
       }
       if (startStep && j == 1) {  // start -> mat(i,1): emission counts of column 1, once per lane
-        const uint32_t er = w & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+        const uint32_t er = w & 0x7FFFu;
+        uint32_t mk, q;
+        em_row_decode(a, er, mk, q);
         if (q < (uint32_t)kNQualDev) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (pc0[c] != 0.f) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], wgt * (double)pc0[c]);
+            fx_add(cnt + 2 * (cMat + ((uint64_t)c * Km + mk) * kNQualDev + q), wgt * (double)pc0[c]);
         }
       }
-      if (l == 0 && j < yLen) {
-        // emission rows belong to the destination column j+1 (context word index j); column yLen has no destination
-        const uint32_t er = wNext & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
-        const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
-        if (q < (uint32_t)kNQualDev) {
+    }
+    if (colvalid && l == 0 && j < yLen) {
+      // the unit's lane 0 holds the complete sums of its column; emission rows belong to the destination column j+1 (context
+      // word index j); column yLen has no destination.  (Handing the five terms to five lanes by DPP so that they convert and add
+      // side by side measured the same: 17.4 vs 17.3 ms.)
+      const uint32_t er = wNext & 0x7FFFu;
+        uint32_t mk, q;
+        em_row_decode(a, er, mk, q);
+      const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
+      if (q < (uint32_t)kNQualDev) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (colsum[c] != 0.f) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], wgt * (double)colsum[c]);
-          if (colsum[4] != 0.f) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], wgt * (double)colsum[4]);
-        }
+        for (int c = 0; c < 4; ++c)
+          fx_add(cnt + 2 * (cMat + ((uint64_t)c * Km + mk) * kNQualDev + q), wgt * (double)colsum[c]);
+        fx_add(cnt + 2 * (cIns + (uint64_t)ytok * kNQualDev + q), wgt * (double)colsum[4]);
       }
     }
     wNext = w;
@@ -745,18 +789,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   if (GAPCTX) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t c = lane; c < 3 * Kg; c += 64) if (s_tr[c] != 0.0) unsafeAtomicAdd(&cnt[cTr + c], s_tr[c]);
+    for (uint32_t c = lane; c < 3 * Kg; c += 64) fx_add(cnt + 2 * (cTr + c), s_tr[c]);
   } else if (active && l == 0) {
-    if (acc_m2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 0], wgt * acc_m2m);
-    if (acc_m2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 1], wgt * acc_m2i);
-    if (acc_m2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 2], wgt * acc_m2d);
+    fx_add(cnt + 2 * (cTr + 0), wgt * acc_m2m);
+    fx_add(cnt + 2 * (cTr + 1), wgt * acc_m2i);
+    fx_add(cnt + 2 * (cTr + 2), wgt * acc_m2d);
   }
   if (active && l == 0) {
-    if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], wgt * acc_m2e);
-    if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], wgt * acc_d2d);
-    if (acc_d2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 1], wgt * acc_d2m);
-    if (acc_i2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 2], wgt * acc_i2i);
-    if (acc_i2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 3], wgt * acc_i2m);
+    fx_add(cnt + 2 * (cTr + 3 * Kg + gkEnd), wgt * acc_m2e);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 0), wgt * acc_d2d);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 1), wgt * acc_d2m);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 2), wgt * acc_i2i);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 3), wgt * acc_i2m);
     a.units[uid].end_val = startv;  // Backward result of this band (diagnostic: should equal Forward's)
   }
 }
@@ -895,7 +939,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   __syncthreads();
   const double* hs = s_lseh;
   constexpr int G = 64, B = 8, S = kRowStripe;
-  extern __shared__ double s_tr[];   // [3 * Kg] context-dependent transition counts of this unit
+  extern __shared__ unsigned long long s_tr[];   // [3 * Kg][2] context-dependent transition counts of this unit (fixed point: fx_add)
   const uint32_t uidx = blockIdx.x;
   if (uidx >= a.n_cls_units) return;
   const int l = threadIdx.x, rl = G - 1 - l;
@@ -913,7 +957,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   double* bnd = base + (g.nStripes + 1);            // reused: [2][2][yLen+2] Backward mat / del of a stripe's first row
   const double* __restrict__ cells = base + row_fw_header(g, yLen);
   const size_t bndStride = 2ull * (yLen + 2);
-  for (uint32_t c = l; c < 3 * a.dp.Kg; c += 64) s_tr[c] = 0.0;
+  for (uint32_t c = l; c < 3 * a.dp.Kg * 2; c += 64) s_tr[c] = 0ull;
   for (size_t c = l; c < 2 * bndStride; c += 64) bnd[c] = QF_NEG_INF;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
   __builtin_amdgcn_wave_barrier();
@@ -926,7 +970,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   const bool local = a.dp.local != 0;
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
-  double* __restrict__ cnt = a.counts + (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // contention: see kCountReplicas
+  unsigned long long* __restrict__ cnt = a.counts + 2 * (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // (lo, hi) per entry; contention: see kCountReplicas
   const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
   double acc_i2m = 0, acc_d2m = 0, acc_i2i = 0, acc_d2d = 0, acc_m2e = 0, startv = QF_NEG_INF;
   const uint32_t gkEnd = ctx[yLen - 1] >> 24;
@@ -1031,25 +1075,29 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
         for (int c = 0; c < 5; ++c) colsum[c] = colvalid ? in[c] + pc[c] : 0.0;
       }
       if (colvalid) {
-        if (pc[5] != 0.0) unsafeAtomicAdd(&s_tr[gk], pc[5]);
-        if (pc[6] != 0.0) unsafeAtomicAdd(&s_tr[Kg + gk], pc[6]);
-        if (pc[7] != 0.0) unsafeAtomicAdd(&s_tr[2 * Kg + gk], pc[7]);
+        fx_add(s_tr + 2 * gk, pc[5]);
+        fx_add(s_tr + 2 * (Kg + gk), pc[6]);
+        fx_add(s_tr + 2 * (2 * Kg + gk), pc[7]);
         if (j == 1) {
-          const uint32_t er = w & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+          const uint32_t er = w & 0x7FFFu;
+        uint32_t mk, q;
+        em_row_decode(a, er, mk, q);
           if (q < (uint32_t)kNQualDev) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              if (pc0[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], pc0[c]);
+              fx_add(cnt + 2 * (cMat + ((uint64_t)c * Km + mk) * kNQualDev + q), pc0[c]);
           }
         }
         if (l == 0 && j < yLen) {
-          const uint32_t er = wNext & 0x7FFFu, mk = er / (kNQualDev + 1), q = er % (kNQualDev + 1);
+          const uint32_t er = wNext & 0x7FFFu;
+        uint32_t mk, q;
+        em_row_decode(a, er, mk, q);
           const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
           if (q < (uint32_t)kNQualDev) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              if (colsum[c] != 0.0) unsafeAtomicAdd(&cnt[cMat + ((uint64_t)c * Km + mk) * kNQualDev + q], colsum[c]);
-            if (colsum[4] != 0.0) unsafeAtomicAdd(&cnt[cIns + (uint64_t)ytok * kNQualDev + q], colsum[4]);
+              fx_add(cnt + 2 * (cMat + ((uint64_t)c * Km + mk) * kNQualDev + q), colsum[c]);
+            fx_add(cnt + 2 * (cIns + (uint64_t)ytok * kNQualDev + q), colsum[4]);
           }
         }
       }
@@ -1065,13 +1113,13 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t c = l; c < 3 * Kg; c += 64) if (s_tr[c] != 0.0) unsafeAtomicAdd(&cnt[cTr + c], s_tr[c]);
+  for (uint32_t c = l; c < 3 * Kg; c += 64) fx_add_words(cnt + 2 * (cTr + c), s_tr[2 * c], s_tr[2 * c + 1]);
   if (l == 0) {
-    if (acc_m2e != 0.0) unsafeAtomicAdd(&cnt[cTr + 3 * Kg + gkEnd], acc_m2e);
-    if (acc_d2d != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 0], acc_d2d);
-    if (acc_d2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 1], acc_d2m);
-    if (acc_i2i != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 2], acc_i2i);
-    if (acc_i2m != 0.0) unsafeAtomicAdd(&cnt[cTr + 4 * Kg + 3], acc_i2m);
+    fx_add(cnt + 2 * (cTr + 3 * Kg + gkEnd), acc_m2e);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 0), acc_d2d);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 1), acc_d2m);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 2), acc_i2i);
+    fx_add(cnt + 2 * (cTr + 4 * Kg + 3), acc_i2m);
     a.units[uid].end_val = startv;
   }
 }
@@ -1083,9 +1131,9 @@ static uint32_t fb_lds_bytes(const FbArgs& a, bool backward, bool& emlds) {
   const uint32_t Kg = a.dp.Kg;
   uint32_t d = kLseDoubles + ((4 * Kg + 1) & ~1u);
   if (backward) d += 4 * 4 * 64;
-  if (backward && Kg > 1) d += (4 * 3 * Kg + 1) & ~1u;
+  if (backward && Kg > 1) d += 4 * 3 * Kg * 2;
   const uint32_t em = a.dp.ematch_ninf_off / 8 + 4 + kInsRows;
-  emlds = (d + em) * 8 <= 48 * 1024;
+  emlds = (d + em) * 8 <= (a.lds_limit ? a.lds_limit : 48u * 1024u);
   return (d + (emlds ? em : 0)) * 8;
 }
 template <int G, int B>
@@ -1094,6 +1142,10 @@ static void launch_fwd_gb(const FbArgs& a, hipStream_t s) {
   bool emlds;
   const uint32_t lds = fb_lds_bytes(a, false, emlds);
   const bool gap = a.dp.Kg > 1;
+  if (emlds && lds > 48 * 1024) {   // above the default cap of dynamic LDS
+    if (gap) (void)hipFuncSetAttribute((const void*)k_forward_fill<G, B, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)k_forward_fill<G, B, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (gap && emlds) hipLaunchKernelGGL((k_forward_fill<G, B, true, true>), dim3(blocks), dim3(256), lds, s, a);
   else if (gap) hipLaunchKernelGGL((k_forward_fill<G, B, true, false>), dim3(blocks), dim3(256), lds, s, a);
   else if (emlds) hipLaunchKernelGGL((k_forward_fill<G, B, false, true>), dim3(blocks), dim3(256), lds, s, a);
@@ -1105,6 +1157,10 @@ static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   bool emlds;
   const uint32_t lds = fb_lds_bytes(a, true, emlds);
   const bool gap = a.dp.Kg > 1;
+  if (emlds && lds > 48 * 1024) {   // above the default cap of dynamic LDS
+    if (gap) (void)hipFuncSetAttribute((const void*)k_backward_fill<G, B, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)k_backward_fill<G, B, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (gap && emlds) hipLaunchKernelGGL((k_backward_fill<G, B, true, true>), dim3(blocks), dim3(256), lds, s, a);
   else if (gap) hipLaunchKernelGGL((k_backward_fill<G, B, true, false>), dim3(blocks), dim3(256), lds, s, a);
   else if (emlds) hipLaunchKernelGGL((k_backward_fill<G, B, false, true>), dim3(blocks), dim3(256), lds, s, a);
@@ -1135,19 +1191,26 @@ void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
 void launch_backward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
   if (cls == 0) { launch_bwd_gb<16, 2>(a, s); return; }   // single diagonals keep the (16,2) Forward layout
-  if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), (size_t)3 * a.dp.Kg * 8, s, a); return; }
+  if (cls == kRowClass) { hipLaunchKernelGGL(k_backward_rows, dim3(a.n_cls_units), dim3(64), (size_t)3 * a.dp.Kg * 16, s, a); return; }
   QF_FB_DISPATCH(launch_bwd_gb)
 }
-// counts[0][i] += counts[1..R-1][i]
-__global__ void k_sum_count_replicas(double* counts, uint32_t n, uint64_t stride) {
+// Sum of the replicas of every accumulator (exact: 128-bit integer addition of word 1 2^32 + word 0), as 64.64 fixed-point
+// (low, high) words and as a double
+__global__ void k_sum_count_replicas(const unsigned long long* fx, uint32_t n, uint64_t stride, unsigned long long* out_fx, double* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double v = counts[i];
-  for (int r = 1; r < kCountReplicas; ++r) v += counts[(size_t)r * stride + i];
-  counts[i] = v;
+  unsigned __int128 tot = 0;
+  for (int r = 0; r < kCountReplicas; ++r) {
+    const unsigned long long w0 = fx[2 * ((size_t)r * stride + i)], w1 = fx[2 * ((size_t)r * stride + i) + 1];
+    tot += ((unsigned __int128)w1 << 32) + w0;
+  }
+  const unsigned long long lo = (unsigned long long)tot, hi = (unsigned long long)(tot >> 64);
+  out_fx[2 * (size_t)i] = lo;
+  out_fx[2 * (size_t)i + 1] = hi;
+  out[i] = (double)hi + (double)lo * 5.421010862427522170e-20;   // 2^-64
 }
-void launch_sum_count_replicas(double* counts, uint32_t n, uint64_t stride, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_sum_count_replicas, dim3((n + 255) / 256), dim3(256), 0, s, counts, n, stride);
+void launch_sum_count_replicas(const unsigned long long* fx, uint32_t n, uint64_t stride, unsigned long long* out_fx, double* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_sum_count_replicas, dim3((n + 255) / 256), dim3(256), 0, s, fx, n, stride, out_fx, out);
 }
 void launch_pair_forward(const FinalArgs& a, const double* lse, hipStream_t s) {
   if (a.n_pairs) hipLaunchKernelGGL(k_pair_forward, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a, lse);

@@ -21,7 +21,8 @@ enum qf_debug_flag {
   QF_DEBUG_GLOBAL_LSE = 128u,         /* overlap fills gather the exact log-sum-exp table from global memory, not its packed form in LDS */
   QF_DEBUG_NO_ROW_PREFILTER = 256u,   /* overlap seeding: every pair through the per-pair kernel (no chunk-of-y prefilter) */
   QF_DEBUG_COUNT_SETTLED = 512u,      /* overlap: count the pairs the prefilter settles (qf_debug_rows_settled; costs a read-back) */
-  QF_DEBUG_PAIR_ORDER_SINGLES = 1024u /* overlap: single-diagonal bands as a plain list in pair order, not by (y chunk, x row) */
+  QF_DEBUG_PAIR_ORDER_SINGLES = 1024u,/* overlap: single-diagonal bands as a plain list in pair order, not by (y chunk, x row) */
+  QF_DEBUG_BIG_FORWARD_LDS = 2048u    /* E-step: Forward may take 78 KB of LDS like Backward (two workgroups per CU, the emission slice of long contexts in LDS) */
 };
 int qf_debug_set_flags(qf_ctx *ctx, uint32_t flags);
 /* The exact log-sum-exp table packed for LDS (qf_device.hpp: kLsePack*), built on the host:

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_prep_reads2(PrepArgs a) {
           const int v = (int)(signed char)((qc.v[e >> 2] >> (8 * (e & 3))) & 0xFFu) - '!';
           q = (uint32_t)max(0, min(kNQualDev - 1, v));
         }
-        cw[e] = ctx_pack(mk * (kNQualDev + 1) + q, t * (kNQualDev + 1) + q, gk);
+        cw[e] = ctx_pack(a.em_qmajor_Km ? (q - a.em_qmin) * a.em_qmajor_Km + mk : mk * (kNQualDev + 1) + q, t * (kNQualDev + 1) + q, gk);
       }
       const bool whole = p0 + 16 <= L;
       uint32_t* cdst = a.ctx + b + p0;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void k_prep_reads2(PrepArgs a) {
       const int v = (int)(signed char)a.qual[b + i] - '!';
       q = (uint32_t)max(0, min(kNQualDev - 1, v));
     }
-    a.ctx[b + i] = ctx_pack(mk * (kNQualDev + 1) + q, tokAt(i) * (kNQualDev + 1) + q, gk);
+    a.ctx[b + i] = ctx_pack(a.em_qmajor_Km ? (q - a.em_qmin) * a.em_qmajor_Km + mk : mk * (kNQualDev + 1) + q, tokAt(i) * (kNQualDev + 1) + q, gk);
   }
 }
 
@@ -2027,6 +2027,21 @@ double measure_f64_add_rate(double* d_out /* >= 256 K doubles */, hipStream_t s)
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return ok ? (double)blocks * 256.0 * iters * 8.0 / (ms * 1e-3) : 0.0;
+}
+
+__global__ void k_qual_range(const char* __restrict__ qual, uint64_t total, uint32_t* out) {
+  uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t q = (uint32_t)max(0, min(kNQualDev - 1, (int)(signed char)qual[i] - '!'));
+    lo = min(lo, q); hi = max(hi, q);
+  }
+  for (int o = 32; o; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+  if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) { atomicMin(out, lo); atomicMax(out + 1, hi); }
+}
+void launch_qual_range(const char* qual, uint64_t total, uint32_t* out, hipStream_t s) {
+  if (!total) return;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_qual_range, dim3(blocks), dim3(256), 0, s, qual, total, out);
 }
 
 void launch_prep_ref(const char* seq, uint64_t total, uint8_t* tok, BatchCounters* bc, hipStream_t s) {

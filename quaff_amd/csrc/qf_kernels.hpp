@@ -31,6 +31,10 @@ struct PrepArgs {
   double* ins_sum;         // [n] sum of insert scores (xInsertScore / yInsertScore, src/qoverlap.cpp:105-113)
   double* ins_sum_c;       // [n] same with complemented tokens
   double* nll_c;           // [n] null log-likelihood of the reverse complement
+  // E-step only: match-emission rows numbered QUALITY-major, (q - em_qmin) * em_qmajor_Km + context k-mer, instead of
+  // k-mer * 95 + q: the rows of the qualities the resident reads actually use are then one contiguous slice of the table,
+  // small enough for LDS also with -order 2 contexts (qf_api.hip: count path).  0 = the usual numbering.
+  uint32_t em_qmajor_Km, em_qmin;
   BatchCounters* bc;
 };
 
@@ -119,10 +123,13 @@ struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
   DpParams dp;
   const double* pair_fwd;      // [n_pairs] Forward result (Backward only)
   const double* pair_weight;   // [n_pairs] posterior weight, 0 = no Backward
-  double* counts;              // flattened weighted QuaffCounts accumulators, kCountReplicas copies `counts_stride` apart
+  unsigned long long* counts;  // flattened weighted QuaffCounts accumulators as 128-bit fixed point ((low, high) words per entry: qf_fb.hip, fx_add), kCountReplicas copies `counts_stride` entries apart
   int no_band_shortcuts;   // A/B: lone diagonals through the (16,2) Forward kernel, Backward skips no band
   uint64_t counts_stride;
   uint32_t Km;
+  // quality-major emission rows (PrepArgs::em_qmajor_Km): row = (q - em_qmin) << em_kshift | k-mer; em_qmajor = 0: row = k-mer * 95 + q
+  uint32_t em_qmajor, em_kshift, em_qmin;
+  uint32_t lds_limit;          // bytes of LDS one workgroup of the fill kernels may take (tables go to LDS while they fit)
 };
 
 struct CountPlanArgs {
@@ -230,11 +237,13 @@ void launch_pack_ref(const uint8_t* tok, const uint64_t* off, const uint64_t* wo
 void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, uint64_t max_len, uint32_t k,
                       uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s);
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s);
+// smallest and largest quality value (as the prep kernels clamp them: 0 .. 93) of `total` quality characters -> out[0], out[1]
+void launch_qual_range(const char* qual, uint64_t total, uint32_t* out, hipStream_t s);
 void launch_null_ll(const PrepArgs& a, uint32_t n_reads, hipStream_t s);   // needs the token bytes of launch_prep_reads
 // Emission counts of one read column go to the accumulator table with one global fp64 atomic each; workgroups spread over
 // this many copies of the table (summed at the end) so that popular (context, quality) entries are not serialised in L2.
 constexpr int kCountReplicas = 16;
-void launch_sum_count_replicas(double* counts, uint32_t n, uint64_t stride, hipStream_t s);
+void launch_sum_count_replicas(const unsigned long long* fx, uint32_t n, uint64_t stride, unsigned long long* out_fx, double* out, hipStream_t s);
 // Sorts one class list by descending key (read length): the bands a wavefront takes together then have similar lengths
 // (a wavefront runs for its longest band) and the longest start first.  Returns 0 or a hipError_t.
 int sort_class_list(uint32_t* keys, uint32_t* list, uint32_t n, uint32_t* keys_tmp, uint32_t* list_tmp, void** temp,

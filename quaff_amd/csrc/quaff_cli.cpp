@@ -557,24 +557,26 @@ static int cmdAlign(Opts& o) {
   return EXIT_SUCCESS;
 }
 
-// One E-step over all reads (QuaffTrainer::getCounts, src/qmodel.cpp:2005-2032), batched; counts summed in read order.
+// One E-step over all reads (QuaffTrainer::getCounts, src/qmodel.cpp:2005-2032), batched.
 static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_refs, bool useNull, vector<vector<uint32_t>>& sortOrder, double& logLike) {
   ParamCounts total(s.params.match_len, s.params.gap_len);
   logLike = 0;
-  // read blocks spread over the devices, one round of blocks at a time; a round's block sums are combined by RCCL
-  // (qf_allreduce_counts) or, for several contexts on one GPU, added by the host in block order.  The device kernels add
-  // their count terms with floating-point atomics, so totals are reproducible to rounding (~1e-12 relative), not bit for
-  // bit, between runs and between device counts ("count reproducibility")
+  // Read blocks spread over the devices, one round of blocks at a time.  The library returns every block's counts and
+  // log-likelihood as 128-bit fixed-point words (qf_count_result.counts_exact: the device adds count terms as integers), which
+  // add exactly: the host's sum over blocks -- and RCCL's over devices (qf_allreduce_counts_exact) -- is the same whatever the
+  // block size, the number of devices and the order of arrival; one conversion to double at the end.  (The reference adds
+  // per-read counts in read order, src/qmodel.cpp:2416-2422: one fixed rounding sequence; this is another.)
   const size_t G = s.devices(), n = reads.seqs.size();
   const size_t perCall = max<size_t>(1, ((size_t)1 << 28) / max<size_t>(1, (size_t)n_refs));   // the library takes 2^28 pairs per call
   const size_t batch = max<size_t>(1, min<size_t>({(size_t)16384, perCall, (n + G - 1) / G}));
   const bool haveOrder = !sortOrder.empty();
   if (!haveOrder) sortOrder.assign(n, vector<uint32_t>());
+  const size_t nv = total.v.size() + 1;             // the counts, then the log-likelihood
+  vector<uint64_t> totalFx(2 * nv, 0);
   for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
     const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
     const size_t nact = s.rccl ? G : nrun;   // an all-reduce needs every rank, also those without a block in the last round
-    vector<vector<double>> counts(nact);
-    vector<double> ll(nact, 0.);
+    vector<vector<uint64_t>> fx(nact);
     onDevices(nact, [&](size_t k) {
       qf_ctx* c = s.ctxs[k];
       string failure;
@@ -598,8 +600,10 @@ static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_re
         qf_count_result res;
         QFT(c, qf_count_resident(c, &o.cfg, useNull ? 0 : QF_COUNT_FORCE, sin.empty() ? nullptr : sin.data(),
                                  snin.empty() ? nullptr : snin.data(), &res));
-        counts[k].assign(res.counts, res.counts + res.counts_size);
-        ll[k] = res.loglike;
+        if ((size_t)res.counts_size + 1 != nv) throw std::runtime_error("unexpected count vector size");
+        fx[k].assign(res.counts_exact, res.counts_exact + 2 * (size_t)res.counts_size);
+        fx[k].push_back(res.loglike_exact[0]);
+        fx[k].push_back(res.loglike_exact[1]);
         for (size_t r = lo; r < hi; ++r) {   // each block owns its reads' rows
           vector<uint32_t>& so = sortOrder[r];
           so.clear();
@@ -609,17 +613,19 @@ static ParamCounts eStep(Session& s, Opts& o, const SeqSet& reads, uint32_t n_re
       if (!s.rccl) { countBlock(); return; }
       // QuaffCountingScheduler::finalCounts / finalLogLike (src/qmodel.cpp:2416-2422) across the devices: one RCCL
       // all-reduce per round.  It is a collective: a device whose block failed (or that has no block in the last round)
-      // still takes part, with zeros, and reports afterwards - the others must not be left waiting for it.
+      // still takes part, with zeros, and reports afterwards - the others must not be left waiting for it (and if it cannot
+      // even do that, the library's deadline releases them with an error).
       try { countBlock(); } catch (const std::exception& e) { failure = e.what(); }
-      if (counts[k].size() != total.v.size() || failure.size()) { counts[k].assign(total.v.size(), 0.); ll[k] = 0; }
-      QFT(c, qf_allreduce_counts(c, counts[k].data(), (uint32_t)counts[k].size(), &ll[k]));
+      if (fx[k].size() != 2 * nv || failure.size()) fx[k].assign(2 * nv, 0);
+      QFT(c, qf_allreduce_counts_exact(c, fx[k].data(), (uint32_t)nv));
       if (failure.size()) throw std::runtime_error(failure);
     });
-    for (size_t k = 0; k < (s.rccl ? (size_t)1 : nrun); ++k) {
-      for (size_t q = 0; q < counts[k].size(); ++q) total.v[q] += counts[k][q];
-      logLike += ll[k];
-    }
+    for (size_t k = 0; k < (s.rccl ? (size_t)1 : nrun); ++k) qf_exact_add(totalFx.data(), fx[k].data(), (uint32_t)nv);
   }
+  vector<double> vals(nv);
+  qf_exact_to_double(totalFx.data(), (uint32_t)nv, vals.data());
+  std::copy(vals.begin(), vals.end() - 1, total.v.begin());
+  logLike = vals.back();
   return total;
 }
 

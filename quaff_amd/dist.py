@@ -115,6 +115,39 @@ def estep_allreduce(counts, loglike, ctx=None):
     return out[:-1], float(out[-1])
 
 
+def estep_allreduce_exact(counts_exact, loglike_exact, ctx=None):
+    """The same exchange on the order-free 128-bit fixed-point words (qf_count_result.counts_exact / loglike_exact): returns
+    (global counts, global log-likelihood, global words) with the doubles converted once from the exact totals -- identical on
+    every rank and for every number of ranks.  RCCL through the library's qf_allreduce_counts_exact when the context carries a
+    communicator; otherwise 32-bit limbs in int64 through the process group (gloo rehearsals)."""
+    from . import api
+    fx = np.concatenate([np.ascontiguousarray(counts_exact, np.uint64).reshape(-1, 2),
+                         np.ascontiguousarray(loglike_exact, np.uint64).reshape(1, 2)])
+    if ctx is not None and ctx.comm_size() > 0:
+        tot = ctx.allreduce_counts_exact(fx)
+    else:
+        import torch.distributed as dist
+        tot = fx
+        if dist.is_available() and dist.is_initialized():
+            import torch
+            marker = (fx[:, 1] == np.uint64(1 << 63)) & (fx[:, 0] == 0)
+            limbs = np.stack([fx[:, 0] & np.uint64(0xFFFFFFFF), fx[:, 0] >> np.uint64(32), fx[:, 1] & np.uint64(0xFFFFFFFF),
+                              fx[:, 1] >> np.uint64(32), marker.astype(np.uint64)], axis=1)
+            limbs[marker, :4] = 0
+            t = torch.from_numpy(limbs.astype(np.int64)).to(_dev())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            L = t.cpu().numpy().astype(object)
+            tot = np.zeros_like(fx)
+            for k in range(len(fx)):
+                if L[k, 4]:
+                    tot[k] = (0, 1 << 63)
+                else:
+                    v = (int(L[k, 0]) + (int(L[k, 1]) << 32) + (int(L[k, 2]) << 64) + (int(L[k, 3]) << 96)) & ((1 << 128) - 1)
+                    tot[k] = (v & ((1 << 64) - 1), v >> 64)
+    vals = api.exact_to_double(tot)
+    return vals[:-1], float(vals[-1]), tot
+
+
 def balanced_blocks(weights, world):
     """Cut items 0..n-1 (rows of the overlap pair triangle, reads of a full-DP batch) into `world` contiguous blocks of
     nearly equal total weight: block r = [cuts[r], cuts[r+1]).  The reference balances dynamically (a shared task queue,

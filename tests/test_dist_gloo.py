@@ -21,10 +21,14 @@ WORKER = textwrap.dedent("""
     dist.barrier()
     mx = dist.allreduce_max(1.5 + rank)
     n = dist.allreduce_sum(np.array([hi - lo], dtype=np.float64))[0]
+    # the exact (order-free) reduction: terms whose floating-point sum depends on the order, as 128-bit fixed-point words
+    from quaff_amd import api
+    terms = np.array([1e15 + 0.25, -1e15, 3.0 ** -30, 7.0]) if rank == 0 else np.array([-(1e15 + 0.25), 1e15, 5.0, 2.0 ** -40])
+    ex_c, ex_ll, ex_fx = dist.estep_allreduce_exact(api.exact_from_double(terms), api.exact_from_double([-250.5 * (rank + 1)])[0])
     # one file per rank: two processes printing to one pipe can interleave inside a line
     open(sys.argv[1] + "/rank%%d.json" %% rank, "w").write(json.dumps(
         {"rank": rank, "world": world, "lo": lo, "hi": hi, "sum_ok": bool(np.array_equal(tot, np.arange(1888) * 3.0)),
-         "ll": ll, "max": mx, "n": n}))
+         "ll": ll, "max": mx, "n": n, "ex_c": ex_c.tolist(), "ex_ll": ex_ll, "ex_fx": [[int(a), int(b)] for a, b in ex_fx]}))
     dist.finalize()
 """) % ROOT
 
@@ -44,6 +48,10 @@ def test_two_rank_gloo(tmp_path):
     assert rows[0]["lo"] == 0 and rows[0]["hi"] == rows[1]["lo"] and rows[1]["hi"] == 1001
     for r in rows:
         assert r["world"] == 2 and r["sum_ok"] and r["ll"] == -300.0 and r["max"] == 2.5 and r["n"] == 1001
+        # (1e15 + .25) - (1e15 + .25) = 0 exactly, 3^-30 + 5 and 7 + 2^-40 to the last bit (3^-30 itself truncated at 2^-64): no
+        # floating-point order of these six additions gives all four
+        assert r["ex_c"] == [0.0, 0.0, 5.0 + float(int(3.0 ** -30 * 2 ** 64)) / 2 ** 64, 7.0 + 2.0 ** -40] and r["ex_ll"] == -751.5
+        assert r["ex_fx"] == rows[0]["ex_fx"]
 
 
 def test_shard_range_partition():

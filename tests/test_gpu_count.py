@@ -306,3 +306,63 @@ def test_two_equal_weight_repeat_bands(ctx):
     res, want = run_case(ctx, both_strands(ref), reads, sc, null)
     nd = [len(ctx.envelope(r, r & 1, Q.DPConfig())) for r in range(len(reads))]
     assert min(nd) > 100                                                        # two bands of ~65+ diagonals on the true strand
+
+
+def test_estep_totals_do_not_depend_on_order_pieces_or_partition(ctx):
+    """The count terms are added as 128-bit fixed-point integers (two 64-bit integer atomics with carry), so an E-step's totals are a
+    function of the reads alone: the same words run to run, for every way the call is cut into pieces (pipeline pieces, a memory
+    budget that forces splits), and -- added with qf_exact_add -- for the whole batch, two halves, and three contexts taking a
+    third each.  (src/qmodel.cpp:2416-2422 adds per-read counts in read order: one fixed answer; this is one too.)  Order-2 contexts
+    (LDS accumulators for the context-dependent transitions) and the row-space kernels included."""
+    import quaff_amd as Q
+    from quaff_amd import api
+    rng = np.random.default_rng(81)
+    ref = rand_seq(rng, 4000)
+    refs = both_strands(ref)
+    reads = make_reads(rng, ref, 300, 350)
+    null = O.NullParams.from_json(NULL_JSON)
+    pj = synth_params_json(rng, 2, 1)
+
+    def words(res):
+        return np.concatenate([res["counts_exact"], res["loglike_exact"].reshape(1, 2)])
+
+    def run(c, lo, hi, cfg, force=False):
+        c.upload_reads([r.seq for r in reads[lo:hi]], [r.qual for r in reads[lo:hi]])
+        return c.count_resident(cfg, force=force)
+
+    others = [Q.Context(0), Q.Context(0)]
+    try:
+        for params, cfg, force in ((None, Q.DPConfig(), False), (pj, Q.DPConfig(), True), (None, Q.DPConfig(sparse=False), False)):
+            n = 300 if cfg.sparse else 24
+            for c in [ctx] + others:
+                c.set_params_json(params)
+                c.set_null_json(NULL_JSON)
+                c.set_refs([x.seq for x in refs])
+            whole = run(ctx, 0, n, cfg, force)
+            assert (whole["counts"] > 1e-6).sum() > 300 and np.array_equal(api.exact_to_double(whole["counts_exact"]), whole["counts"])
+            again = run(ctx, 0, n, cfg, force)
+            assert np.array_equal(words(again), words(whole))                       # run to run
+            for pieces, budget in ((2, 0), (5, 0), (1, (6 << 20) if cfg.sparse else (400 << 20))):   # internal pieces; a budget that forces splits
+                ctx.set_pipeline_chunks(pieces)
+                ctx.set_memory_budget(budget)
+                cut = run(ctx, 0, n, cfg, force)
+                ctx.set_pipeline_chunks(0)
+                ctx.set_memory_budget(0)
+                assert np.array_equal(words(cut), words(whole)), (pieces, budget)
+                assert np.array_equal(cut["counts"], whole["counts"]) and np.array_equal(cut["read_loglike"], whole["read_loglike"])
+            half = api.exact_add(words(run(ctx, 0, n // 2, cfg, force)), words(run(ctx, n // 2, n, cfg, force)))
+            assert np.array_equal(half, words(whole))                               # two halves
+            cuts = [0, n // 3, 2 * n // 3, n]
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(3) as ex:                                       # three contexts at once on the device
+                parts = list(ex.map(lambda k: words(run(([ctx] + others)[k], cuts[k], cuts[k + 1], cfg, force)), range(3)))
+            third = api.exact_add(api.exact_add(parts[0], parts[1]), parts[2])
+            assert np.array_equal(third, words(whole))
+            vals = api.exact_to_double(third)
+            assert np.array_equal(vals[:-1], whole["counts"]) and abs(vals[-1] - whole["loglike"]) <= 1e-12 * abs(whole["loglike"])
+    finally:
+        for c in others:
+            c.close()
+        ctx.set_params_json(None)
+        ctx.set_pipeline_chunks(0)
+        ctx.set_memory_budget(0)

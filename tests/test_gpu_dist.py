@@ -36,8 +36,8 @@ WORKER = textwrap.dedent("""
     for it in range(2):                                   # second iteration on the pruned reference order
         res = ctx.count_resident(Q.DPConfig(), sort_order=order, packed_order=True)
         order = res["sort_order"]
-        counts, ll = dist.estep_allreduce(res["counts"], res["loglike"], ctx)
-        out.append({"counts": counts.tolist(), "ll": ll, "local_ll": res["loglike"]})
+        counts, ll, fx = dist.estep_allreduce_exact(res["counts_exact"], res["loglike_exact"], ctx)
+        out.append({"counts": counts.tolist(), "ll": ll, "local_ll": res["loglike"], "fx": [[int(a), int(b)] for a, b in fx]})
     dist.barrier()
     open(sys.argv[1] + "/rank%%d.json" %% rank, "w").write(json.dumps({"rank": rank, "lo": lo, "hi": hi, "its": out}))
     ctx.close()
@@ -76,7 +76,11 @@ def test_hip_estep_on_two_ranks_matches_one_rank(tmp_path):
             big = np.abs(res["counts"]) > 1e-6
             rel = np.abs(got - res["counts"])[big] / np.abs(res["counts"])[big]
             assert rel.max() < 1e-4, (it, rel.max())
-            assert rel.max() < 1e-9, (it, rel.max())                                      # in fact: rounding of the atomic adds only
+            # in fact bit for bit: the count terms are added as 128-bit integers on the device and across the ranks, so the
+            # two-rank totals ARE the one-rank totals (counts and log-likelihood words alike)
+            assert np.array_equal(got, res["counts"]), (it, rel.max())
+            one = np.concatenate([res["counts_exact"], res["loglike_exact"].reshape(1, 2)])
+            assert [[int(a), int(b)] for a, b in one] == r["its"][it]["fx"]
             assert abs(r["its"][it]["ll"] - res["loglike"]) <= 1e-12 * abs(res["loglike"])
         assert abs(rows[0]["its"][it]["local_ll"] + rows[1]["its"][it]["local_ll"] - res["loglike"]) <= 1e-12 * abs(res["loglike"])
     ctx.close()
