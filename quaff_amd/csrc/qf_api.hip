@@ -1915,6 +1915,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         s.ref_pos = c->d_rpos.as<uint32_t>();
         s.ref_skeys = (sparse && cfg->kmer_len > kMaxRefK) ? c->d_rskeys.as<unsigned long long>() : nullptr;
         s.storage_mode = 2;
+        s.ov_use_32x3 = (c->debug & QF_DEBUG_OV32) != 0;   // measured slower (dense overlaps: fill 158 vs 141 ms): off unless asked for
         s.max_ref_len = s.max_read_len;   // the x side is a read too
         s.cls_key = c->d_cls_key.as<uint32_t>();   // (the single-diagonal list is sorted back into pair order)
       }, max_units, sa, bc))
@@ -1985,7 +1986,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.recs = c->d_recs.as<AlignRec>();
   oa.bc = c->d_bc.as<BatchCounters>();
   if (int rc = launch_classes_concurrently(c, bc, (c->debug & QF_DEBUG_SERIAL_CLASSES) != 0, [&](int cls, hipStream_t s) {
-        if (cls > 10 && cls != kRowClass) return;
+        if (cls > 10 && cls != kRowClass && cls != kOv32Class) return;
         OvArgs o2 = oa;
         o2.n_cls_units = bc.cls_count[cls];
         o2.cls_list = c->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
@@ -2038,7 +2039,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); out->ms_traceback += ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[5]); out->ms_total += ms;
   for (int cls = 0; cls < kNumClasses; ++cls) {
-    if (!seed_bc.cls_count[cls] || (cls > 10 && cls != kRowClass)) continue;
+    if (!seed_bc.cls_count[cls] || (cls > 10 && cls != kRowClass && cls != kOv32Class)) continue;
     ms = 0; (void)hipEventElapsedTime(&ms, c->cls_ev[cls], c->cls_end[cls]); out->ms_fill_class[cls] += ms;
     out->cells_class[cls] += seed_bc.cls_cells[cls];
     out->units_class[cls] += seed_bc.cls_count[cls];

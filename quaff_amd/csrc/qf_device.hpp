@@ -38,12 +38,18 @@ struct Unit {
 // Fill-kernel classes: class 0 = single diagonal (one lane per unit); class c>0 = G lanes x B
 // diagonals per lane.  Kept in one table so host and device agree.
 struct FillClass { int G, B; };
-constexpr int kNumClasses = 14;
+constexpr int kNumClasses = 15;
 constexpr int kRowClass = 13;   // row-space kernel: bands wider than the diagonal-space kernels take (full DP)
+// Overlap only, and only under QF_DEBUG_OV32 (never returned by classify_width): bands of 65 .. 96 diagonals on 32 lanes x 3
+// diagonals instead of 16 x 5 / 6.  Three diagonals per lane take 168 registers (five: 212), i.e. three wavefronts per SIMD
+// instead of two with twelve wavefronts sharing the packed table -- and the kernel got SLOWER (dense overlaps: 158 vs 141 ms):
+// it is not the chained look-ups' latency that bounds it but the CU's one LDS pipe, which every look-up crosses six times, and
+// fewer diagonals per lane mean more per-step work per cell.  Kept as the A/B it was.
+constexpr int kOv32Class = 14;
 __host__ __device__ constexpr FillClass fill_class(int c) {
   constexpr FillClass t[kNumClasses] = {{1, 1},  {16, 2}, {16, 3}, {16, 4}, {16, 5},  {16, 6},  {16, 8},
                                         {64, 3}, {64, 4}, {64, 6}, {64, 8}, {64, 12}, {64, 16},
-                                        {64, 8}};
+                                        {64, 8}, {32, 3}};
   return t[c];
 }
 constexpr int kMaxBandDiagSpace = 64 * 16;  // widest band the diagonal-space kernels take

@@ -5,23 +5,37 @@
 
 namespace qf {
 
+// lane index inside the wavefront (loop-invariant: the compiler keeps the compare below as a scalar mask)
+__device__ __forceinline__ int dpp_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // ZERO: the group's edge lane receives 0.0 (both dwords zero-filled by bound_ctrl) instead of -inf
+// G = 32 (two groups per wavefront): a wave shift, after which the second group's edge lane is patched (two selects per value)
 template <int G, bool ZERO>
 __device__ __forceinline__ double dpp_from_below(double v) {  // lane l-1's value; -inf (or 0) in the group's lane 0
   constexpr int ctrl = G == 16 ? 0x111 : 0x138;              // row_shr:1 / wave_shr:1
   const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
-  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
-                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
+  int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
+                : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  if (G == 32) {
+    const bool edge = dpp_lane() == 32;
+    lo = edge ? 0 : lo;
+    hi = edge ? (ZERO ? 0 : (int)0xFFF00000) : hi;
+  }
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 template <int G, bool ZERO>
 __device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's value; -inf (or 0) in the group's last lane
   constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
   const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
-  const int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
-                      : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);  // bound_ctrl: 0 at the edge
+  int hi = ZERO ? __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true)
+                : __builtin_amdgcn_update_dpp((int)0xFFF00000, (int)(bits >> 32), ctrl, 0xF, 0xF, false);
+  if (G == 32) {
+    const bool edge = dpp_lane() == 31;
+    lo = edge ? 0 : lo;
+    hi = edge ? (ZERO ? 0 : (int)0xFFF00000) : hi;
+  }
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 

@@ -987,6 +987,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
       yLen = (int)(a.read_off[r + 1] - a.read_off[r]);
       cls = classify_width(dhi - dlo + 1);
       if (a.storage_mode == 2 && cls > 10) cls = kRowClass;    // overlap kernels take up to 8 diagonals per lane
+      if (a.storage_mode == 2 && a.ov_use_32x3 && dhi - dlo + 1 > 64 && dhi - dlo + 1 <= 96) cls = kOv32Class;   // (qf_device.hpp)
       if (cls < 0) {
         atomicOr(&a.bc->error, 2u);
         a.bc->error_detail = (uint32_t)(dhi - dlo + 1);

@@ -168,8 +168,13 @@ __global__ __launch_bounds__(64) void k_overlap_sums(PrepArgs a, const uint32_t*
 // exchanges) and keeps everything that does not depend on the chain out of its way -- the pair emissions of step t+1 and the
 // context words of step t+2 are fetched at step t, and the insert state's look-ups (which read only the previous column)
 // are issued before the delete chain starts.
+#ifndef QF_OV_PACK_WAVES
+#define QF_OV_PACK_WAVES 8     // wavefronts of the one workgroup per CU that shares the packed table (8: two per SIMD)
+#endif
+// (32, 3): twelve wavefronts share the table -- three per SIMD -- which its 168 registers allow
+constexpr int ov_pack_waves(int G, int B) { return G == 32 && B == 3 ? 12 : QF_OV_PACK_WAVES; }
 template <int G, int B, bool GAPCTX, bool PACKED>
-__global__ __launch_bounds__(PACKED ? 512 : 256) __attribute__((amdgpu_waves_per_eu(PACKED ? 2 : B <= 5 ? 3 : 2)))
+__global__ __launch_bounds__(PACKED ? 64 * ov_pack_waves(G, B) : 256) __attribute__((amdgpu_waves_per_eu(PACKED ? ov_pack_waves(G, B) / 4 : B <= 5 ? 3 : 2)))
 void k_overlap_fill(OvArgs a) {
   constexpr int UPW = 64 / G;
   extern __shared__ __attribute__((aligned(16))) char s_pack[];
@@ -868,7 +873,8 @@ static void launch_ov_gb(const OvArgs& a, hipStream_t s) {
   if (a.lse_pack) {   // the packed table takes most of a CU's LDS: one workgroup of eight wavefronts per CU
     auto fn = a.Kg > 1 ? k_overlap_fill<G, B, true, true> : k_overlap_fill<G, B, false, true>;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lse_pack_bytes);
-    hipLaunchKernelGGL(fn, dim3((waves + 7) / 8), dim3(512), a.lse_pack_bytes, s, a);
+    constexpr uint32_t W = ov_pack_waves(G, B);
+    hipLaunchKernelGGL(fn, dim3((waves + W - 1) / W), dim3(64 * W), a.lse_pack_bytes, s, a);
   } else {
     auto fn = a.Kg > 1 ? k_overlap_fill<G, B, true, false> : k_overlap_fill<G, B, false, false>;
     hipLaunchKernelGGL(fn, dim3((waves + 3) / 4), dim3(256), 0, s, a);
@@ -907,6 +913,7 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
     case 9: launch_ov_gb<64, 6>(a, s); break;
     case 10: launch_ov_gb<64, 8>(a, s); break;
     case 13: hipLaunchKernelGGL(k_overlap_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); break;
+    case 14: launch_ov_gb<32, 3>(a, s); break;
   }
 }
 bool overlap_single_stages_rows(uint32_t Km) { return 2ull * kSingleSub * Km * (kNQualDev + 1) * 8 <= 64 * 1024; }
