@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -267,13 +268,22 @@ static int fail(Slot* c, int code, const std::string& msg) {
   return code;
 }
 
-// Bytes one chunk may spend on its traceback / Forward storage: the caller's figure (qf_set_memory_budget), else what the
-// device has free right now plus what `own` already holds (it is reused), less 1/16 for the per-pair arrays of the batch.
+// Contexts alive on each device (qf_ctx_create / qf_ctx_destroy): callers keep a few per GPU, one host thread each.
+static std::atomic<int>& device_contexts(int device) {
+  static std::atomic<int> n[64];
+  return n[device & 63];
+}
+
+// Bytes one chunk may spend on its traceback / Forward storage: the caller's figure (qf_set_memory_budget), else this context's
+// share of what the device has free right now -- the contexts of a device (bench --inflight, QUAFF_HIP_DEVICES=0,0) read that
+// figure at the same moment, and each claiming all of it would send all but one into the allocation-failure path -- plus what
+// `own` already holds (it is reused), less 1/16 for the per-pair arrays of the batch.
 static uint64_t chunk_budget(const qf_ctx* c, const DevBuf& own, int slots_in_flight) {
   if (c->tb_budget) return c->tb_budget / (uint64_t)slots_in_flight;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (16ull << 30) / (uint64_t)slots_in_flight;
-  const uint64_t avail = (uint64_t)free_b + own.cap;
+  const uint64_t share = (uint64_t)free_b / (uint64_t)std::max(1, device_contexts(c->device).load());
+  const uint64_t avail = share + own.cap;
   return (avail - avail / 16) / (uint64_t)slots_in_flight;
 }
 
@@ -329,12 +339,14 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   }
   (void)hipEventCreateWithFlags(&c->ev_tok, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_nll, hipEventDisableTiming);
+  ++device_contexts(device_id);
   *out = c;
   return QF_OK;
 }
 
 void qf_ctx_destroy(qf_ctx* c) {
   if (!c) return;
+  --device_contexts(c->device);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,

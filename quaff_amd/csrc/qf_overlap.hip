@@ -406,11 +406,11 @@ __global__ __launch_bounds__(256) void k_overlap_single(OvArgs a) {
 // whose band differs from the first band's (x, diagonal, strand) gathers from global memory as before.  Each lane also
 // takes a whole 128-byte line (32 columns) of its y context words at a time.  (The per-lane gathers of the plain kernel are
 // bound by L1 line fills: one 128-byte line per 8-byte entry.)
-constexpr int kSingleSub = 4;    // columns per block (one barrier per block); each of the four wavefronts stages kSingleSub / 4 rows.
+constexpr int kSingleSub = 8;    // columns per block (one barrier per block); each of the four wavefronts stages kSingleSub / 4 rows.
                                  // (8 measured the same 24 ms on config 3 at either 2 or 3 wavefronts per SIMD: the kernel streams ~30 GB of
                                  // y context words and traceback at 2.7 TB/s; barriers are not what it waits for.)
 template <bool GAPCTX>
-__global__ __launch_bounds__(256) void k_overlap_single_lds(OvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_overlap_single_lds(OvArgs a) {
   struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
   typedef double D2 __attribute__((ext_vector_type(2)));
   extern __shared__ double s_rows[];   // [2][kSingleSub][KQ]
