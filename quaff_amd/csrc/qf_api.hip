@@ -268,21 +268,26 @@ static int fail(Slot* c, int code, const std::string& msg) {
   return code;
 }
 
-// Contexts alive on each device (qf_ctx_create / qf_ctx_destroy): callers keep a few per GPU, one host thread each.
-static std::atomic<int>& device_contexts(int device) {
+// Calls of the batch entry points in progress on each device: callers keep a few contexts per GPU, one host thread each.
+static std::atomic<int>& device_calls(int device) {
   static std::atomic<int> n[64];
   return n[device & 63];
 }
+struct CallInProgress {
+  int device;
+  explicit CallInProgress(int d) : device(d) { ++device_calls(d); }
+  ~CallInProgress() { --device_calls(device); }
+};
 
-// Bytes one chunk may spend on its traceback / Forward storage: the caller's figure (qf_set_memory_budget), else this context's
-// share of what the device has free right now -- the contexts of a device (bench --inflight, QUAFF_HIP_DEVICES=0,0) read that
-// figure at the same moment, and each claiming all of it would send all but one into the allocation-failure path -- plus what
+// Bytes one chunk may spend on its traceback / Forward storage: the caller's figure (qf_set_memory_budget), else this call's
+// share of what the device has free right now -- the calls in progress on a device (bench --inflight, QUAFF_HIP_DEVICES=0,0) read
+// that figure at the same moment, and each claiming all of it would send all but one into the allocation-failure path -- plus what
 // `own` already holds (it is reused), less 1/16 for the per-pair arrays of the batch.
 static uint64_t chunk_budget(const qf_ctx* c, const DevBuf& own, int slots_in_flight) {
   if (c->tb_budget) return c->tb_budget / (uint64_t)slots_in_flight;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (16ull << 30) / (uint64_t)slots_in_flight;
-  const uint64_t share = (uint64_t)free_b / (uint64_t)std::max(1, device_contexts(c->device).load());
+  const uint64_t share = (uint64_t)free_b / (uint64_t)std::max(1, device_calls(c->device).load());
   const uint64_t avail = share + own.cap;
   return (avail - avail / 16) / (uint64_t)slots_in_flight;
 }
@@ -339,14 +344,12 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   }
   (void)hipEventCreateWithFlags(&c->ev_tok, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_nll, hipEventDisableTiming);
-  ++device_contexts(device_id);
   *out = c;
   return QF_OK;
 }
 
 void qf_ctx_destroy(qf_ctx* c) {
   if (!c) return;
-  --device_contexts(c->device);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
@@ -1040,6 +1043,7 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   if (int rc = check_cfg(c, cfg)) return rc;
   if (!out) return fail(c, QF_ERR_ARG, "null result");
   HIPCHK(c, hipSetDevice(c->device));
+  const CallInProgress in_progress(c->device);
   memset(out, 0, sizeof *out);
   const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
   const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
@@ -1606,6 +1610,7 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
   if (!out) return fail(c, QF_ERR_ARG, "null result");
   if ((sort_in == nullptr) != (sort_n_in == nullptr)) return fail(c, QF_ERR_ARG, "sort_in and sort_n_in go together");
   HIPCHK(c, hipSetDevice(c->device));
+  const CallInProgress in_progress(c->device);
   memset(out, 0, sizeof *out);
   const uint32_t n_reads = c->n_reads, n_refs = c->n_refs;
   const uint64_t n_pairs64 = (uint64_t)n_reads * n_refs;
@@ -2118,6 +2123,7 @@ static int prep_overlap_reads(qf_ctx* c, const qf_dp_config* cfg, int prep_k) {
 // alignment records in c->h_recs (AlignRec::read = index into the list) and their runs in c->h_runs.
 static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t n_pairs, qf_overlap_result* out,
                        const std::function<int()>& put_pairs) {
+  const CallInProgress in_progress(c->device);
   const uint32_t n_seqs = c->n_reads;
   const bool sparse = cfg->sparse != 0;
   if (int rc = ensure_lse(c)) return rc;
