@@ -2032,16 +2032,27 @@ double measure_f64_add_rate(double* d_out /* >= 256 K doubles */, hipStream_t s)
 
 __global__ void k_qual_range(const char* __restrict__ qual, uint64_t total, uint32_t* out) {
   uint32_t lo = 0xFFFFFFFFu, hi = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t q = (uint32_t)max(0, min(kNQualDev - 1, (int)(signed char)qual[i] - '!'));
+  auto take = [&](uint32_t c) {
+    const uint32_t q = (uint32_t)max(0, min(kNQualDev - 1, (int)(signed char)c - '!'));
     lo = min(lo, q); hi = max(hi, q);
+  };
+  // 16 characters per lane and load (the buffer is a hipMalloc allocation: 16-byte aligned, and reserved 16 bytes past `total`)
+  const uint64_t n16 = total / 16;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = ((const uint4*)qual)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) take((w[k] >> (8 * b)) & 0xFFu);
   }
+  if (blockIdx.x == 0 && threadIdx.x < total - n16 * 16) take((uint32_t)(unsigned char)qual[n16 * 16 + threadIdx.x]);
   for (int o = 32; o; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
   if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) { atomicMin(out, lo); atomicMax(out + 1, hi); }
 }
 void launch_qual_range(const char* qual, uint64_t total, uint32_t* out, hipStream_t s) {
   if (!total) return;
-  const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, (total + 255) / 256);
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, (total / 16 + 255) / 256 + 1);
   hipLaunchKernelGGL(k_qual_range, dim3(blocks), dim3(256), 0, s, qual, total, out);
 }
 
