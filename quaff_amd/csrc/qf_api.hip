@@ -1987,6 +1987,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.lse = c->d_lse.as<double>();
   if (c->lse_pack_bytes && !(c->debug & QF_DEBUG_GLOBAL_LSE)) { oa.lse_pack = c->d_lse_pack.as<uint8_t>(); oa.lse_pack_bytes = c->lse_pack_bytes; }
   oa.min_score = c->min_score;
+  oa.per_pair = c->ov_per_pair ? 1 : 0;
   oa.no_lds_rows = (c->debug & QF_DEBUG_GLOBAL_OVERLAP_ROWS) != 0;
   oa.Km = sc.Km;
   oa.Kg = sc.Kg;

@@ -163,6 +163,7 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   const double* mmi[2];     // pair-emission tables [plain, yComplemented]
   double min_score;         // alignments scoring below it are neither traced back nor returned (-inf: keep all)
   int no_lds_rows;          // A/B: single-diagonal bands gather their emissions from global memory (k_overlap_single)
+  int per_pair;             // 1: pair_result / pair_score / pair_end_unit / pair_end_ij for every pair (qf_overlap_resident); 0: only what the kept alignments need
   const double* gap[2];
   const uint32_t* slot_list;  // single-diagonal bands by (y chunk, x row, y) instead of cls_list (SeedArgs::slot_list)
   uint32_t slot_rows, slot_ychunks;

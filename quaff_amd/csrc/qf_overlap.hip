@@ -755,19 +755,24 @@ __global__ void k_overlap_finalize(OvArgs a) {
     if (rb > cb) { end = rb; ei = xLen; ej = rj; eu = ru; }
     const double yins = comp ? a.ins_sum_c[y] : a.ins_sum[y];
     const double result = end + a.ins_sum[x] + yins;
-    a.pair_result[p] = result;
     double score = result - a.nll[x];
     score -= comp ? a.nll_c[y] : a.nll[y];
-    a.pair_score[p] = score;
-    a.pair_end_unit[p] = end > QF_NEG_INF ? eu : kNoUnit;
-    a.pair_end_ij[2 * p] = ei;
-    a.pair_end_ij[2 * p + 1] = ej;
+    const bool keep = end > QF_NEG_INF && score >= a.min_score;
+    if (a.per_pair) {   // the per-pair arrays of the pair-list entry point; a row block reports totals and the kept alignments only
+      a.pair_result[p] = result;
+      a.pair_score[p] = score;
+      a.pair_end_unit[p] = end > QF_NEG_INF ? eu : kNoUnit;
+    }
+    if (a.per_pair || keep) {   // (the traceback starts from here)
+      a.pair_end_ij[2 * p] = ei;
+      a.pair_end_ij[2 * p + 1] = ej;
+    }
     t_ndiag = a.pair_ndiag[p];
     if (end > QF_NEG_INF) {
       t_finite = 1;
       t_bits = (unsigned long long)__double_as_longlong(result);
     }
-    if (end > QF_NEG_INF && score >= a.min_score) {
+    if (keep) {
       const Unit& u = a.units[eu];
       const uint32_t cap = xLen + yLen + (uint32_t)(u.dhi - u.dlo + 1) + 4;
       const uint32_t idx = atomicAdd(&a.bc->n_align, 1u);
