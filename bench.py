@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument("--read-len", type=int, default=0, help="default 1000 (align, train), 2000 (overlap), 5000 (fulldp)")
     ap.add_argument("--ref-len", type=int, default=0, help="default 10000 (align, train), 100000 (fulldp); overlap: genome = 20 x reads")
     ap.add_argument("--band", type=int, default=64)
+    ap.add_argument("--train-order", type=int, default=2, choices=[1, 2], help="train: -order of the parameters (BASELINE config 4: 2)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="units in the CPU-baseline / parity sample (reads; pairs for overlap); 0 = skip; default per workload")
     ap.add_argument("--overlap-rows", type=int, default=-1,
@@ -100,21 +101,22 @@ def golden(name):
     return open(os.path.join(ROOT, "tests", "golden", name)).read()
 
 
-def order2_params_json():
-    """-order 2 shaped parameters (matchOrder 3, gapOrder 2) made by repeating the built-in order-0/1 values for every
-    context, as `quaff train -order 2` would start from a context-free prior."""
+def order2_params_json(order=2):
+    """-order 2 shaped parameters (matchOrder 3, gapOrder 2; `order` = 1: matchOrder 2, gapOrder 1) made by repeating the built-in
+    order-0/1 values for every context, as `quaff train -order 2` would start from a context-free prior."""
     import re
+    import itertools
     base = golden("defaultparams.json")
     bi = re.search(r'"beginInsert": \{ "": ([0-9.e-]+)', base).group(1)
     bd = re.search(r'"beginDelete": \{ "": ([0-9.e-]+)', base).group(1)
     block = base[base.index('"match": {') + len('"match": {'):]
     block = block[block.index('{', 1) + 1:block.rindex('} } }')]           # the four reference-base rows of the "" context
-    ctxs = [a + b2 for a in "ACGT" for b2 in "ACGT"]
+    ctxs = ["".join(t) for t in itertools.product("ACGT", repeat=order)]
     gaps = ",".join(' "%s": %s' % (c, bi) for c in ctxs), ",".join(' "%s": %s' % (c, bd) for c in ctxs)
     head = base[:base.index('"beginInsert"')]
     mid = base[base.index('"extendInsert"'):base.index('"match": {')]
     match = ",\n".join('   "%s": {%s }' % (c, block.rstrip().rstrip("}").rstrip() + " }") for c in ctxs)
-    return ('{\n  "matchOrder": 3,\n  "gapOrder": 2,\n' + head[head.index('"refBase"') - 2:] + '"beginInsert": {%s },\n  "beginDelete": {%s },\n  '
+    return ('{\n  "matchOrder": %d,\n  "gapOrder": %d,\n' % (order + 1, order) + head[head.index('"refBase"') - 2:] + '"beginInsert": {%s },\n  "beginDelete": {%s },\n  '
             % gaps + mid + '"match": {\n' + match + " } }\n")
 
 
@@ -474,7 +476,7 @@ class TrainJob(Job):
         self.read_len = a.read_len or 1000
         self.ref_len = a.ref_len or 10000
         self.ctx = ctx = Q.Context(self.local_rank)
-        self.params_json = order2_params_json()
+        self.params_json = order2_params_json(a.train_order)
         ctx.set_params_json(self.params_json)
         ctx.set_null_json(golden("testquaffnullparams.json"))
         self.ref = api.synth_ref(1, self.ref_len)
@@ -515,8 +517,8 @@ class TrainJob(Job):
         return res["total_cells"] + res["backward_cells"]
 
     def describe(self):
-        return ("BASELINE config 4%s: quaff train E-step (Forward-Backward), -order 2, %d bp ref (+revcomp) x %d x %d bp reads sharded over "
-                "%d GPU(s), band %d, counts all-reduced by %s" % ("" if self.total_reads == 20000 else " shape", self.ref_len, self.total_reads,
+        return ("BASELINE config 4%s: quaff train E-step (Forward-Backward), -order %d, %d bp ref (+revcomp) x %d x %d bp reads sharded over "
+                "%d GPU(s), band %d, counts all-reduced by %s" % ("" if (self.total_reads, self.a.train_order) == (20000, 2) else " shape", self.a.train_order, self.ref_len, self.total_reads,
                                                                   self.read_len, self.world, self.a.band,
                                                                   "RCCL (qf_allreduce_counts)" if self.rccl else "the host (one rank)" if self.world == 1 else "gloo (one-GPU rehearsal)"))
 

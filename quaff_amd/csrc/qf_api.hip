@@ -1524,7 +1524,10 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
         FbArgs f2 = fa;
         f2.n_cls_units = bc.cls_count[cls];
         f2.cls_list = S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-        if (!(c->debug & QF_DEBUG_BIG_FORWARD_LDS)) f2.lds_limit = 0;   // measured (config 4): 11.9 ms with the table in global memory at three workgroups per CU, 12.1 ms with it in LDS at two
+        // Forward keeps the quality-major slice in global memory (lds_limit 1: nothing fits): its LDS pipe is already busy with the
+        // log-sum-exp pieces.  Measured: order 2, 11.9 ms from global memory at three workgroups per CU against 12.1 ms from LDS
+        // at two; order 1 (an 11 KB slice, three workgroups either way), 11.9 against 12.6 ms.
+        if (c->count_qmajor && !(c->debug & QF_DEBUG_BIG_FORWARD_LDS)) f2.lds_limit = 1;
         launch_forward_fill(cls, f2, s);
       }, 0, true))   // classes with few wavefronts first, on the high-priority streams: each of their wavefronts still runs its ~1 000 dependent steps
     return rc;
