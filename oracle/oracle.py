@@ -579,10 +579,13 @@ def round_half_away(x):
     return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
 
 
-def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True):
+def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True, skip_pathless=False):
     """QuaffCountingTask::run, src/qmodel.cpp:2238-2271.  Returns (yCounts as flattened
     QuaffParamCounts-style QuaffCounts sum, yLogLike, new sort order).  The returned counts are
-    still in QuaffCounts layout (m2m,m2i,m2d,m2e,...); param_counts() converts."""
+    still in QuaffCounts layout (m2m,m2i,m2d,m2e,...); param_counts() converts.
+    skip_pathless: under -force (use_null False) the running yLogLike starts at -inf, so a reference without any path (Forward
+    = -inf) passes the `>= yLogLike - 20` test (:2252), gets a Backward pass whose counts are NaN, and 0 x NaN (:2259-2261) makes
+    the read's -- and the E-step's -- totals NaN in the reference.  True leaves such references out (what the library does)."""
     rc = ReadCtx(read, sc)
     ynull = null.loglike(read) if use_null else NEG_INF
     ylog = ynull
@@ -594,7 +597,7 @@ def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True):
         d = envelope(xt, rc.tok, cfg, 48)
         f, _, _ = forward_backward(xt, rc, sc, d, cfg.local, want_back=False)
         xyll[nx] = f
-        if f >= ylog - 20:
+        if f >= ylog - 20 and not (skip_pathless and f == NEG_INF):
             _, _, cnt = forward_backward(xt, rc, sc, d, cfg.local, want_back=True)
             xyc[nx] = cnt
         ylog = lse(ylog, f)

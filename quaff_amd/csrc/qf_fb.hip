@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   double* s_em = (double*)s_tr_all + (GAPCTX ? 4 * 3 * Kg * 2 : 0u);
   lseh_load(lds_fb, a.lse_h, threadIdx.x, 256);
   for (uint32_t k = threadIdx.x; k < 4 * Kg; k += 256) s_trans[k] = a.dp.trans[k];
-  if (GAPCTX) for (uint32_t k = threadIdx.x; k < 4 * 3 * Kg * 2; k += 256) s_tr_all[k] = 0ull;   // (as doubles: +0.0)
+  if (GAPCTX) for (uint32_t k = threadIdx.x; k < 4 * 3 * Kg * 2; k += 256) s_tr_all[k] = 0ull;
   for (uint32_t k = threadIdx.x; k < 4 * 4 * 64; k += 256) s_acc_all[k] = 0.0;
   if (EMLDS) {
     for (uint32_t k = threadIdx.x; k < n_em; k += 256) s_em[k] = a.dp.ematch[k];
@@ -538,15 +538,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   if (T == 0) return;
-  // Context-dependent transition counts of the wavefront's bands: LDS doubles, added by ds_add_f64 from lanes of different
-  // bands in whatever order the hardware takes them -- and still order-free, because every term is first rounded to a multiple of
-  // one quantum q = trM 2^-52 (trM = a power of two above anything the wavefront's total can reach: a column's transition
-  // counts sum to at most the pair's weight <= 1, so a band's to at most its columns): sums of multiples of q below 2 trM are
-  // exact in fp64, whatever the order.  The flush turns the exact sum into fixed-point words (fx_add).  q is 2^-40 for four
-  // 1 kb bands: against transition counts in the hundreds and thousands.
-  double* s_tr = (double*)(s_tr_all + (size_t)wv * 3 * Kg * 2);
-  const double trM = __longlong_as_double((long long)(1023 + 32 - __clz((UPW * T) | 1)) << 52);   // 2^(bits of UPW T) >= UPW T + 1
-
+  // Context-dependent transition counts of the wavefront's bands: fixed-point words in LDS like the global accumulators (fx_add:
+  // two ds_add_u64 without return per term), flushed word for word at the end.  (A cheaper-looking scheme -- fp64 ds_add_f64 of
+  // terms rounded to a multiple of one quantum, whose sums are exact whatever the order -- is order-free only for a FIXED
+  // quantum; one sized from the wavefront's own longest band makes a term's rounding depend on which bands share the wavefront,
+  // i.e. on how the batch was cut: tests/soak_count_overlap.py found totals differing in the 14th digit between a call and the
+  // same call in pieces.  A fixed quantum safe for 1 M-base reads is 2^-29: too coarse for the rare contexts' small counts.)
+  unsigned long long* s_tr = s_tr_all + (size_t)wv * 3 * Kg * 2;
   const int d0 = dlo + l * B;
   const int bmax = active ? dhi - d0 : -1;
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
@@ -742,9 +740,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
     if (colvalid) {
       if (!GAPCTX) { acc_m2m += (double)pf[5]; acc_m2i += (double)pf[6]; acc_m2d += (double)pf[7]; }
       else {
-        if (pf[5] != 0.f) unsafeAtomicAdd(&s_tr[gk], (wgt * (double)pf[5] + trM) - trM);
-        if (pf[6] != 0.f) unsafeAtomicAdd(&s_tr[Kg + gk], (wgt * (double)pf[6] + trM) - trM);
-        if (pf[7] != 0.f) unsafeAtomicAdd(&s_tr[2 * Kg + gk], (wgt * (double)pf[7] + trM) - trM);
+        fx_add(s_tr + 2 * gk, wgt * (double)pf[5]);
+        fx_add(s_tr + 2 * (Kg + gk), wgt * (double)pf[6]);
+        fx_add(s_tr + 2 * (2 * Kg + gk), wgt * (double)pf[7]);
       }
       if (startStep && j == 1) {  // start -> mat(i,1): emission counts of column 1, once per lane
         const uint32_t er = w & 0x7FFFu;
@@ -789,7 +787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   if (GAPCTX) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t c = lane; c < 3 * Kg; c += 64) fx_add(cnt + 2 * (cTr + c), s_tr[c]);
+    for (uint32_t c = lane; c < 3 * Kg; c += 64) fx_add_words(cnt + 2 * (cTr + c), s_tr[2 * c], s_tr[2 * c + 1]);
   } else if (active && l == 0) {
     fx_add(cnt + 2 * (cTr + 0), wgt * acc_m2m);
     fx_add(cnt + 2 * (cTr + 1), wgt * acc_m2i);

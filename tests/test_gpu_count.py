@@ -25,11 +25,19 @@ def ctx():
 
 
 def oracle_estep(refs, reads, sc, null, cfg, orders=None, use_null=True):
+    """Sum of the oracle's per-read counts.  A read without any finite Forward likelihood under -force (no null model in the
+    normalisation; e.g. -global with a band that misses the corners) has posterior weights exp(-inf - (-inf)) = NaN in the
+    reference (src/qmodel.cpp:2258-2262) and poisons its E-step totals, and so does a pathless reference that comes first in a
+    read's order (0 x the NaN counts of its Backward pass); the library gives neither any weight, so the expected
+    totals leave them out."""
     tot = np.zeros(O.counts_size(sc.Km, sc.Kg))
     ylogs, new_orders, fwd = [], [], []
     for r, read in enumerate(reads):
-        c, yl, no = O.count_read(refs, read, sc, null, cfg, None if orders is None else orders[r], use_null)
-        tot += c
+        c, yl, no = O.count_read(refs, read, sc, null, cfg, None if orders is None else orders[r], use_null, skip_pathless=not use_null)
+        if np.isfinite(yl):
+            tot += c
+        else:
+            assert not use_null
         ylogs.append(yl)
         new_orders.append(no)
     return tot, np.array(ylogs), new_orders
@@ -55,7 +63,9 @@ def run_case(ctx, refs, reads, sc, null, cfg_kw=None, orders=None, force=False):
     ocfg = O.DPConfig(local=cfg_kw.get("local", True), kmer_threshold=cfg_kw.get("kmer_threshold", 20),
                       band=cfg_kw.get("band_size", 64), kmer_len=cfg_kw.get("kmer_len", 6), sparse=cfg_kw.get("sparse", True))
     want, ylogs, new_orders = oracle_estep(refs, reads, sc, null, ocfg, orders, use_null=not force)
-    np.testing.assert_allclose(res["read_loglike"], ylogs, rtol=RTOL)
+    fin = np.isfinite(ylogs)
+    assert np.array_equal(np.isfinite(res["read_loglike"]), fin)
+    np.testing.assert_allclose(res["read_loglike"][fin], ylogs[fin], rtol=RTOL)
     assert res["loglike"] == ylogs.sum() or abs(res["loglike"] - ylogs.sum()) <= RTOL * abs(ylogs.sum())
     assert_counts_close(res["counts"], want, "counts")
     assert res["sort_order"] == new_orders
@@ -320,6 +330,12 @@ def test_estep_totals_do_not_depend_on_order_pieces_or_partition(ctx):
     ref = rand_seq(rng, 4000)
     refs = both_strands(ref)
     reads = make_reads(rng, ref, 300, 350)
+    for k in range(0, 300, 3):            # ragged lengths (40 .. 700): which bands share a wavefront changes with every way of cutting the batch
+        L = int(rng.integers(40, 700))
+        s0 = int(rng.integers(0, len(ref) - L))
+        src = ref[s0:s0 + L] if k & 1 == 0 else O.revcomp_str(ref[s0:s0 + L])
+        seq = mutate(rng, src)
+        reads[k] = O.FastSeq("x%d" % k, seq, rand_qual(rng, len(seq)))
     null = O.NullParams.from_json(NULL_JSON)
     pj = synth_params_json(rng, 2, 1)
 
@@ -342,7 +358,7 @@ def test_estep_totals_do_not_depend_on_order_pieces_or_partition(ctx):
             assert (whole["counts"] > 1e-6).sum() > 300 and np.array_equal(api.exact_to_double(whole["counts_exact"]), whole["counts"])
             again = run(ctx, 0, n, cfg, force)
             assert np.array_equal(words(again), words(whole))                       # run to run
-            for pieces, budget in ((2, 0), (5, 0), (1, (6 << 20) if cfg.sparse else (400 << 20))):   # internal pieces; a budget that forces splits
+            for pieces, budget in ((2, 0), (5, 0), (1, (48 << 20) if cfg.sparse else (400 << 20))):   # internal pieces; a budget that forces splits
                 ctx.set_pipeline_chunks(pieces)
                 ctx.set_memory_budget(budget)
                 cut = run(ctx, 0, n, cfg, force)
