@@ -58,12 +58,16 @@ __device__ __forceinline__ void fx_add_words(unsigned long long* acc, unsigned l
 }
 __device__ __forceinline__ void fx_add(unsigned long long* acc, double v) {
   if (!(v > 0.0)) return;   // zero, and never a NaN into an integer conversion
+  // floor(v 2^32) is read off the mantissa of floor(v 2^32) + 2^52, which needs v 2^32 < 2^52.  Every term this kernel forms is
+  // a sum of posterior weights over at most one band's columns (v <= 2^20 for the longest read the library takes): a term of
+  // 2^19 or more goes in as two exact halves.
+  const bool big = v >= 524288.0;
+  if (big) v *= 0.5;
   const double t = v * 4294967296.0, ft = floor(t);
   const unsigned long long w0 = (unsigned long long)__double2uint_rz((t - ft) * 4294967296.0);
-  // floor(t) < 2^52 (every term this kernel forms: v < 2^20): its integer value is the mantissa of floor(t) + 2^52
-  const unsigned long long w1 = ft < 4503599627370496.0 ? ((unsigned long long)__double_as_longlong(ft + 4503599627370496.0) & 0xFFFFFFFFFFFFFull)
-                                                        : (unsigned long long)ft;
+  const unsigned long long w1 = (unsigned long long)__double_as_longlong(ft + 4503599627370496.0) & 0xFFFFFFFFFFFFFull;
   fx_add_words(acc, w0, w1);
+  if (big) fx_add_words(acc, w0, w1);
 }
 
 // (context k-mer, quality) of a match-emission row number as the context words carry it (FbArgs::em_qmajor)
