@@ -3,20 +3,24 @@
 
 Default (the headline line, `--workload align`) = BASELINE config 2: banded Viterbi align, 1 synthetic 10 kb reference (+ its
 reverse complement) x 100 k synthetic 1 kb reads per GPU, -kmatchband 64 (k = 6, threshold 20).  `--workload train | overlap |
-fulldp` = configs 4 / 3 / 5 (supplementary lines, same JSON shape; the driver runs only the default).
+fulldp` = configs 4 / 3 / 5 at their stated extents (supplementary lines, same JSON shape; the driver runs only the default):
+train = one E-step over 20 k reads at -order 2; overlap = the WHOLE pair triangle of 50 k reads (3.75e9 pairs) through
+qf_overlap_rows (a step takes ~20 s: default --steps 1 --warmup 1); fulldp = all 10 000 reads (1e13 cells, ~15 s a step).
 
 A "step" is one pass of the whole hot path (read prep, k-mer seeding, DP fill, selection, traceback / count reduction, results
 on the host) over one batch that is already resident in HBM.  N > 1: one process per GPU.  `python bench.py --gpus N` starts
 the N ranks itself (torch.distributed.run as a child process, before anything touches HIP); under the driver's own
 `python -m torch.distributed.run ... bench.py --gpus N` the ranks come from the environment.  Read x reference pairs are
 independent, so there is no data-path collective: torch.distributed (backend nccl = RCCL) carries the barrier and the
-max-over-ranks time; `train` adds the E-step's one exchange, an RCCL all-reduce of the counts through the library's own
-qf_allreduce_counts.
+max-over-ranks time; `train` adds the E-step's one exchange, an RCCL all-reduce of the counts' fixed-point words through the
+library's own qf_allreduce_counts_exact (the same totals for any number of ranks).
 
 Prints ONE JSON line (rank 0) with
   roofline      the dominant kernel against the roof that binds it: fp64 vector issue for the Viterbi kernels (DESIGN.md 4:
                 20 f64 operations per cell, 39.3 T op/s), HBM at the algorithmic 24 B/cell for Forward / Backward (which do
-                materialise the matrix); the HBM view (algorithmic GB/s, PMC traffic) is always given beside it;
+                materialise the matrix); the HBM view (algorithmic GB/s) and the fp64 issue rate MEASURED in the same run are
+                always given beside it; `traffic` / `replayed_counters` are replayed, labelled, from the committed rocprofv3
+                capture of the same build (profiles/), never measured here;
   cpu_baseline  the oracle (oracle/, a bit-exact CPU port of the reference's algorithm) timed on a bounded sample on this
                 box's host cores, which also re-checks the GPU's results for that sample (`gpu_parity_mismatches`).
 """
