@@ -134,3 +134,41 @@ def test_packed_lse_table_rebuilds_the_table(api):
 
     for n in list(range(0, 100000, 53)) + [255, 256, 511, 512, 99839, 99840, 99999]:
         assert entry(n >> 8, n & 255) == tab[n] and entry(n >> 8, (n & 255) + 1) == tab[n + 1], n
+
+
+def test_exact_fixed_point_helpers(api):
+    """qf_exact_from_double / qf_exact_add / qf_exact_to_double (the host side of qf_count_result.counts_exact): 64.64 two's
+    complement words whose sums do not depend on the order; values that are not finite (a read without any path has log-likelihood
+    -inf) become a marker that absorbs every sum and converts to -inf."""
+    from fractions import Fraction
+    rng = np.random.default_rng(7)
+    v = np.concatenate([rng.random(400) * rng.choice([1e-12, 1e-3, 1.0, 1e6], 400), -rng.random(100) * 1e4, [0.0, 1.0, -1.0, 2.0 ** -64, 2.0 ** 40]])
+    fx = api.exact_from_double(v)
+    assert fx.shape == (len(v), 2) and fx.dtype == np.uint64
+    # each value: truncated toward zero at 2^-64, exactly
+    for x, (lo, hi) in zip(v, fx):
+        w = (int(hi) << 64) | int(lo)
+        if w >> 127:
+            w -= 1 << 128
+        mag = abs(Fraction(float(x)))
+        assert abs(w) == int(mag * (1 << 64)) and (w < 0) == (x < 0 and abs(w) > 0)
+    assert np.array_equal(api.exact_to_double(api.exact_from_double([1.5, -2.25, 3.0 ** -10])), np.array([1.5, -2.25, float(Fraction(int(Fraction(3.0 ** -10) * (1 << 64)), 1 << 64))]))
+    # the sum is the same in any order and equals the exact rational sum
+    def total(order):
+        acc = np.zeros((1, 2), np.uint64)
+        for k in order:
+            acc = api.exact_add(acc, fx[k:k + 1])
+        return acc
+    a, b = total(range(len(v))), total(rng.permutation(len(v)))
+    assert np.array_equal(a, b)
+    exact = sum(((int(hi) << 64 | int(lo)) - ((1 << 128) if int(hi) >> 63 else 0)) for lo, hi in fx)
+    got = (int(a[0, 1]) << 64 | int(a[0, 0])) - ((1 << 128) if int(a[0, 1]) >> 63 else 0)
+    assert got == exact and abs(api.exact_to_double(a)[0] - float(Fraction(exact, 1 << 64))) <= 1e-9 * abs(float(Fraction(exact, 1 << 64)))
+    # vectors add element-wise
+    two = api.exact_add(fx, fx)
+    np.testing.assert_allclose(api.exact_to_double(two), 2 * api.exact_to_double(fx), rtol=1e-15, atol=0)
+    # not finite -> marker; it absorbs
+    m = api.exact_from_double([float("-inf"), float("nan"), 1e19, 5.0])
+    assert [int(x) for x in m[0]] == [0, 1 << 63] and np.array_equal(m[0], m[1]) and np.array_equal(m[0], m[2])
+    out = api.exact_to_double(api.exact_add(m, api.exact_from_double([1.0, 2.0, 3.0, 4.0])))
+    assert np.all(np.isneginf(out[:3])) and out[3] == 9.0
