@@ -1,3 +1,6 @@
+"""Diagnostic companion of tests/soak_count_overlap.py (not collected by pytest): re-runs given count seeds of that soak and prints the
+worst count entries against the oracle, with the emission tables in LDS and in global memory, and the same call in pieces.
+`python tests/soak_debug_count.py SEED ...` from the repo root."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import quaff_amd as Q
