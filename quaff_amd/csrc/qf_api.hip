@@ -231,6 +231,10 @@ struct qf_ctx : Slot {
   bool ov_per_pair = true;
   bool ov_slot_collision = false;   // set by a chunk whose slotted single-diagonal list had a collision: plain lists for the rest of the call
   struct OvTotals { uint64_t n_finite = 0, sum_ndiag = 0, result_sum = 0; } ov_tot;
+  // k_overlap_single_rows: compact pair-emission tables per strand flag, per-base row offsets, transposed column offsets
+  DevBuf d_mmic0, d_mmic1, d_xrowoff, d_ycol0, d_ycol1, d_ygoff;
+  uint32_t ov_pitch = 0, ov_cpr = 0;      // row pitch (doubles) / 16-byte chunks per row; 0: the compact form does not apply
+  uint64_t ov_cols_epoch = 0, ov_mmic_epoch[2] = {0, 0};
   uint64_t ov_block_pairs = 0;   // qf_debug_set_overlap_block_pairs: pairs per internal row block (0 = default)
   std::vector<qf_overlap_hit> h_hits;
   std::vector<uint32_t> h_hit_runs;
@@ -355,6 +359,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
                     &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_qrange, &c->d_ematch_q, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list,
+                    &c->d_mmic0, &c->d_mmic1, &c->d_xrowoff, &c->d_ycol0, &c->d_ycol1, &c->d_ygoff,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
                     &c->d_rbucket, &c->d_rcursor, &c->d_rpos, &c->d_px, &c->d_py, &c->d_pc, &c->d_mmi0, &c->d_mmi1,
@@ -1986,7 +1991,22 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.gap[1] = c->d_gap1.as<double>();
   if (!need[0]) { oa.mmi[0] = oa.mmi[1]; oa.gap[0] = oa.gap[1]; }
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
-  if (slot_rows) { oa.slot_list = c->d_slot_list.as<uint32_t>(); oa.slot_rows = slot_rows; oa.slot_ychunks = slot_ychunks; }
+  if (slot_rows) {
+    oa.slot_list = c->d_slot_list.as<uint32_t>(); oa.slot_rows = slot_rows; oa.slot_ychunks = slot_ychunks; oa.slot_x0 = slot_x0;
+    if (c->ov_pitch && c->ov_cols_epoch == c->prep_epoch && !(c->debug & QF_DEBUG_OLD_SINGLE_ROWS) &&
+        (!need[0] || c->ov_mmic_epoch[0] == c->prep_epoch) && (!need[1] || c->ov_mmic_epoch[1] == c->prep_epoch)) {
+      oa.mmic_pitch = c->ov_pitch;
+      oa.mmic_cpr = c->ov_cpr;
+      oa.mmic[0] = c->d_mmic0.as<double>();
+      oa.mmic[1] = c->d_mmic1.as<double>();
+      if (!need[0]) oa.mmic[0] = oa.mmic[1];
+      if (!need[1]) oa.mmic[1] = oa.mmic[0];
+      oa.xrowoff = c->d_xrowoff.as<uint32_t>();
+      oa.ycolT[0] = c->d_ycol0.as<uint4>();
+      oa.ycolT[1] = c->d_ycol1.as<uint4>();
+      oa.ygoff = c->d_ygoff.as<uint64_t>();
+    }
+  }
   oa.lse = c->d_lse.as<double>();
   if (c->lse_pack_bytes && !(c->debug & QF_DEBUG_GLOBAL_LSE)) { oa.lse_pack = c->d_lse_pack.as<uint8_t>(); oa.lse_pack_bytes = c->lse_pack_bytes; }
   oa.min_score = c->min_score;
@@ -2118,6 +2138,34 @@ static int prep_overlap_reads(qf_ctx* c, const qf_dp_config* cfg, int prep_k) {
     launch_prep_overlap(pa, n_seqs, c->stream);
     HIPCHK(c, hipGetLastError());
   }
+  // k_overlap_single_rows: row / column offsets into the compact pair-emission table (the quality values the reads use)
+  const uint32_t qmin = c->reads_have_qual ? c->read_qmin : (uint32_t)kNQualDev, nq = c->reads_have_qual ? c->read_qmax - c->read_qmin + 1 : 1u;
+  c->ov_pitch = overlap_compact_pitch(sc.Km, nq);
+  c->ov_cpr = sc.Km * nq / 2;
+  c->ov_cols_epoch = 0;
+  if (c->ov_pitch && n_seqs) {
+    const uint32_t groups = (n_seqs + 63) / 64;
+    std::vector<uint64_t> goff(groups + 1, 0);
+    uint32_t max_blocks = 1;
+    for (uint32_t g = 0; g < groups; ++g) {
+      uint64_t longest = 1;
+      for (uint32_t y = g * 64; y < std::min(n_seqs, g * 64 + 64); ++y) longest = std::max(longest, c->read_off[y + 1] - c->read_off[y]);
+      const uint32_t blocks = (uint32_t)((longest + 7) / 8);
+      max_blocks = std::max(max_blocks, blocks);
+      goff[g + 1] = goff[g] + (uint64_t)blocks * 64;
+    }
+    HIPCHK(c, c->d_ygoff.reserve((size_t)(groups + 1) * 8));
+    HIPCHK(c, c->d_xrowoff.reserve((c->read_total + 16) * 4));
+    HIPCHK(c, c->d_ycol0.reserve((size_t)goff[groups] * 16));
+    HIPCHK(c, c->d_ycol1.reserve((size_t)goff[groups] * 16));
+    HIPCHK(c, hipMemcpyAsync(c->d_ygoff.p, goff.data(), (size_t)(groups + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    launch_overlap_cols(c->d_ctx.as<uint32_t>() + kCtxPad, c->d_ctxc.as<uint32_t>() + kCtxPad, c->d_roff.as<uint64_t>(), n_seqs, c->read_total,
+                        c->d_ygoff.as<uint64_t>(), max_blocks, sc.Km, qmin, c->ov_pitch, c->d_xrowoff.as<uint32_t>(), c->d_ycol0.as<uint4>(),
+                        c->d_ycol1.as<uint4>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // `goff` is a stack-lifetime host buffer
+    c->ov_cols_epoch = c->prep_epoch;
+  }
   return QF_OK;
 }
 
@@ -2163,6 +2211,17 @@ static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], u
   const bool prepped = c->ov_prep_epoch == c->prep_epoch && c->ov_prep_k == prep_k;   // a later block of the same pair list
   if (!prepped)
     if (int rc = prep_overlap_reads(c, cfg, prep_k)) return rc;
+  if (c->ov_pitch && c->ov_cols_epoch == c->prep_epoch) {   // compact pair-emission tables for the quality values in use
+    const uint32_t qmin = c->reads_have_qual ? c->read_qmin : (uint32_t)kNQualDev, nq = c->reads_have_qual ? c->read_qmax - c->read_qmin + 1 : 1u;
+    for (int v = 0; v < 2; ++v) {
+      if (!need[v] || c->ov_mmic_epoch[v] == c->prep_epoch) continue;
+      DevBuf& dc = v ? c->d_mmic1 : c->d_mmic0;
+      HIPCHK(c, dc.reserve((size_t)sc.Km * nq * c->ov_pitch * 8 + 4096));   // (+ slack: a staged row is fetched in whole 16-byte chunks)
+      launch_mmi_compact((v ? c->d_mmi1 : c->d_mmi0).as<double>(), sc.Km, qmin, nq, c->ov_pitch, dc.as<double>(), c->stream);
+      HIPCHK(c, hipGetLastError());
+      c->ov_mmic_epoch[v] = c->prep_epoch;
+    }
+  }
   HIPCHK(c, c->d_px.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_py.reserve((size_t)n_pairs * 4));
   HIPCHK(c, c->d_pc.reserve((size_t)n_pairs));

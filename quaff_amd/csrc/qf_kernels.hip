@@ -1036,7 +1036,8 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
     const uint32_t x = a.pair_x[pair], y = a.pair_y[pair];
     // The host admits the slotted list only for lists in which (x, y) is unique and a pair has one single-diagonal band; should
     // that ever not hold, the second claimant of a slot raises error bit 4 and the host redoes the chunk with the plain list.
-    if (atomicCAS(&a.slot_list[((uint64_t)(y >> 8) * a.slot_rows + (x - a.slot_x0)) * 256 + (y & 255u)], kNoUnit, uid) != kNoUnit)
+    // (and that the band is the forced diagonal 0, src/diagenv.cpp:53: bands are at least 2 wide otherwise)
+    if (dlo != 0 || atomicCAS(&a.slot_list[((uint64_t)(y >> 8) * a.slot_rows + (x - a.slot_x0)) * 256 + (y & 255u)], kNoUnit, uid) != kNoUnit)
       atomicOr(&a.bc->error, 16u);
   } else
     a.cls_list[(uint64_t)cls * a.max_units + s_base[cls] + lrank] = uid;

@@ -167,6 +167,15 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   const double* gap[2];
   const uint32_t* slot_list;  // single-diagonal bands by (y chunk, x row, y) instead of cls_list (SeedArgs::slot_list)
   uint32_t slot_rows, slot_ychunks;
+  // k_overlap_single_rows (qf_overlap.hip): compact pair-emission tables (rows mmic_pitch doubles apart, mmic_cpr 16-byte chunks
+  // used per row), per-base row offsets of every sequence, per-base 16-bit column offsets transposed per 64 sequences
+  uint32_t slot_x0;
+  uint32_t mmic_pitch;        // 0: not available (the kernels above run)
+  uint32_t mmic_cpr;
+  const double* mmic[2];
+  const uint32_t* xrowoff;
+  const uint4* ycolT[2];
+  const uint64_t* ygoff;      // [groups + 1] first chunk of each group of 64 sequences
   const double* lse;
   const uint8_t* lse_pack;  // the same table packed for LDS (qf_device.hpp: kLsePack*) (null: not available)
   uint32_t lse_pack_bytes;
@@ -273,7 +282,12 @@ void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs
 // LDS bytes per sequence of a chunk in the row prefilter (coarse counters of one pair), or 0 if the prefilter does not apply
 size_t seed_row_stride_bytes(const SeedArgs& a);
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);
-bool overlap_single_stages_rows(uint32_t Km);   // the single-diagonal kernel that stages emission rows through LDS applies
+bool overlap_single_stages_rows(uint32_t Km);
+// compact tables / offsets of k_overlap_single_rows: row pitch in doubles for Km x nq entries per row (0: does not apply)
+uint32_t overlap_compact_pitch(uint32_t Km, uint32_t nq);
+void launch_mmi_compact(const double* mmi, uint32_t Km, uint32_t qmin, uint32_t nq, uint32_t pitch, double* out, hipStream_t s);
+void launch_overlap_cols(const uint32_t* ctx, const uint32_t* ctxc, const uint64_t* off, uint32_t n_seqs, uint64_t total, const uint64_t* goff,
+                         uint32_t max_blocks, uint32_t Km, uint32_t qmin, uint32_t pitch, uint32_t* xrowoff, uint4* col0, uint4* col1, hipStream_t s);   // the single-diagonal kernel that stages emission rows through LDS applies
 // entries of the exact log-sum-exp table that its packed form (qf_device.hpp) does not reproduce on this device; ~0u on a HIP error
 uint32_t lse_pack_mismatches(const uint8_t* pack, uint32_t pack_bytes, const double* tab, uint32_t* d_bad, hipStream_t s);
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s);

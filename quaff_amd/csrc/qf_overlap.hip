@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "qf_dpp.hpp"
 #include "qf_kernels.hpp"
@@ -582,6 +583,210 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Single-diagonal bands of the scheduler's row blocks, rebuilt around what bounded k_overlap_single_lds (profiles/r03_pmc_
+// overlap.json: 12.9 instructions per cell for two additions; the L1 busy with one 128-byte line per lane for the y words and
+// 12 bytes per cell of row staging; one barrier per 8 columns of a 256-pair workgroup):
+//  * the pair-emission table is kept COMPACT -- only the quality values the resident sequences use, quality-major, rows
+//    P doubles apart (k_mmi_compact) -- so a staged row is Km x nq doubles (672 bytes for 21 quality values) instead of 3 040,
+//    and the rows reach LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write, one instruction per KB);
+//  * what a lane needs of its y per column is the LDS byte offset of that base's column, two bytes, in arrays TRANSPOSED per
+//    64 consecutive sequences (k_overlap_cols): a wavefront's fetch of 8 columns for its 64 bands is one contiguous KB;
+//  * a lane runs TWO bands (y and y + 2048: the same XCD's chunks), so a workgroup is one x against 512 y: half the staging and
+//    barriers per cell, and two independent add chains per lane;
+//  * a cell is one mask-or-shift (the offset), one ds_read_b64 whose row and buffer sit in the instruction's offset field,
+//    and the two additions of the recurrence.  Only the 8-column blocks in which some lane's diagonal starts or ends (its
+//    first cell may start the alignment, src/qoverlap.cpp:141; its last is the band's only end cell, :153-170) run the
+//    general form that captures them.
+// Applies to the slotted list (x rows of the scheduler, band >= 2 so that the only single diagonal is the forced diagonal 0,
+// src/diagenv.cpp:53), context-free gap scores and compact rows of at most 512 entries; everything else keeps the kernels above.
+__global__ void k_mmi_compact(const double* __restrict__ mmi, uint32_t Km, uint32_t qmin, uint32_t nq, uint32_t pitch, double* __restrict__ out) {
+  const uint32_t RS = Km * nq, KQ = Km * (kNQualDev + 1);
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= RS * RS) return;
+  const uint32_t r = idx / RS, c = idx % RS;
+  const uint32_t fr = (r % Km) * (kNQualDev + 1) + qmin + r / Km, fc = (c % Km) * (kNQualDev + 1) + qmin + c / Km;
+  out[(size_t)r * pitch + c] = mmi[(size_t)fr * KQ + fc];
+}
+// compact index of a context word's emission row: (quality - qmin) * Km + context k-mer
+__device__ __forceinline__ uint32_t ctx_compact(uint32_t word, uint32_t Km, uint32_t qmin) {
+  const uint32_t erow = word & 0x7FFFu, k = erow / (kNQualDev + 1), q = erow - k * (kNQualDev + 1);
+  return (q - qmin) * Km + k;
+}
+// per base of every sequence: byte offset of its row in the compact table (x side)
+__global__ void k_overlap_xrows(const uint32_t* __restrict__ ctx, uint64_t total, uint32_t Km, uint32_t qmin, uint32_t pitch, uint32_t* __restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = ctx_compact(ctx[i], Km, qmin) * pitch * 8u;
+}
+// per base of every sequence, both strands: byte offset of its column inside a row (y side), 16 bits, transposed per group of
+// 64 consecutive sequences: chunk (goff[g] + b * 64 + l) holds columns 8b + 1 ... 8b + 8 of sequence 64g + l (zeros past its end)
+__global__ __launch_bounds__(256) void k_overlap_cols(const uint32_t* __restrict__ ctx, const uint32_t* __restrict__ ctxc, const uint64_t* __restrict__ off,
+                                                      uint32_t n_seqs, const uint64_t* __restrict__ goff, uint32_t Km, uint32_t qmin,
+                                                      uint4* __restrict__ out0, uint4* __restrict__ out1) {
+  const uint32_t g = blockIdx.x, l = threadIdx.x & 63u, y = g * 64 + l;
+  const uint64_t g0 = goff[g];
+  const uint32_t blocks = (uint32_t)((goff[g + 1] - g0) >> 6);
+  const uint64_t yb = y < n_seqs ? off[y] : 0;
+  const uint32_t len = y < n_seqs ? (uint32_t)(off[y + 1] - yb) : 0;
+  for (uint32_t b = blockIdx.y * 4 + (threadIdx.x >> 6); b < blocks; b += gridDim.y * 4) {
+    uint32_t v0[4] = {0, 0, 0, 0}, v1[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c) {
+      const uint32_t i = b * 8 + c;
+      if (i < len) {
+        v0[c >> 1] |= (ctx_compact(ctx[yb + i], Km, qmin) * 8u) << (16 * (c & 1));
+        v1[c >> 1] |= (ctx_compact(ctxc[yb + i], Km, qmin) * 8u) << (16 * (c & 1));
+      }
+    }
+    out0[g0 + (uint64_t)b * 64 + l] = make_uint4(v0[0], v0[1], v0[2], v0[3]);
+    out1[g0 + (uint64_t)b * 64 + l] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+  }
+}
+
+constexpr int kRowsSub = 8;                    // columns per staged block
+template <int P> constexpr uint32_t single_rows_lds() { return 2u * kRowsSub * P * 8u + 64u; }
+template <int P>
+__global__ __launch_bounds__(256) void k_overlap_single_rows(OvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char s_crow[];     // [2][kRowsSub][P] doubles, then control words
+  constexpr uint32_t kBufBytes = kRowsSub * P * 8u;
+  int* s_ctl = (int*)(s_crow + 2 * kBufBytes);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup b: XCD b % 8 (workgroup ids go round the XCDs), y chunks 16 s + xcd and 16 s + 8 + xcd of chunk set s = b / 8 / rows,
+  // x row (b / 8) % rows: the rows of one set follow each other on one XCD, whose L2 then serves the set's column offsets
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, set = slot / a.slot_rows, row = slot % a.slot_rows;
+  const uint32_t x = a.slot_x0 + row;
+  const uint64_t xb = a.seq_off[x];
+  const int xLen = (int)(a.seq_off[x + 1] - xb);
+  uint32_t uid[2], comp[2] = {0, 0}, yblocks[2] = {1, 1};
+  int n[2] = {0, 0}, yLen[2] = {0, 0};
+  const uint4* yp[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t ch = set * 16 + 8 * k + xcd;
+    uid[k] = ch < a.slot_ychunks ? a.slot_list[((uint64_t)ch * a.slot_rows + row) * 256 + tid] : kNoUnit;
+    yp[k] = a.ycolT[0] + lane;                                      // (a lane without a band reads somewhere harmless)
+    if (uid[k] != kNoUnit) {
+      const uint32_t pair = a.units[uid[k]].pair, y = a.pair_y[pair];   // y = ch * 256 + tid: lane == y % 64
+      comp[k] = a.pair_comp[pair] ? 1u : 0u;
+      yLen[k] = (int)(a.seq_off[y + 1] - a.seq_off[y]);
+      n[k] = min(xLen, yLen[k]);
+      const uint64_t g0 = a.ygoff[y >> 6];
+      yblocks[k] = (uint32_t)((a.ygoff[(y >> 6) + 1] - g0) >> 6);
+      yp[k] = a.ycolT[comp[k]] + g0 + lane;
+    }
+  }
+  if (!__syncthreads_or(uid[0] != kNoUnit || uid[1] != kNoUnit)) return;   // an empty slot group (below the diagonal of the pair triangle)
+  const uint32_t* __restrict__ xro = a.xrowoff + xb;
+  for (uint32_t cp = 0; cp < 2; ++cp) {                              // the strand flag selects the table: one pass per flag present
+    int nn[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) nn[k] = (uid[k] != kNoUnit && comp[k] == cp) ? n[k] : 0;
+    int gEnd[2] = {(nn[0] - 1) >> 3, (nn[1] - 1) >> 3};              // block of the band's last cell (-1: no band in this pass)
+    int T = max(nn[0], nn[1]), gFirst = min(gEnd[0] < 0 ? 0x7FFFFFFF : gEnd[0], gEnd[1] < 0 ? 0x7FFFFFFF : gEnd[1]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { T = max(T, __shfl_xor(T, o)); gFirst = min(gFirst, __shfl_xor(gFirst, o)); }
+    __syncthreads();
+    if (tid == 0) s_ctl[0] = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_ctl[0], T);
+    __syncthreads();
+    T = s_ctl[0];
+    if (T == 0) continue;
+    gFirst = __builtin_amdgcn_readfirstlane(gFirst);
+    const int nBlocks = (T + kRowsSub - 1) / kRowsSub;
+    const char* __restrict__ tab = (const char*)a.mmic[cp];
+    const double g0 = a.gap[cp][0];
+    // x's row offsets for block g, this wavefront's two rows (fetched a block ahead of the staging that uses them)
+    struct Ro { uint32_t v[kRowsSub / 4]; };
+    auto row_offsets = [&](int g) -> Ro {
+      Ro r;
+#pragma unroll
+      for (uint32_t rr = 0; rr < kRowsSub / 4; ++rr) r.v[rr] = xro[min(kRowsSub * g + (int)(w + 4 * rr), xLen - 1)];
+      return r;
+    };
+    auto stage = [&](const Ro& r, uint32_t buf) {                     // this wavefront's two rows of a block -> LDS buffer `buf`
+#pragma unroll
+      for (uint32_t rr = 0; rr < kRowsSub / 4; ++rr) {
+        const uint32_t c = w + 4 * rr;
+        const uint32_t ro = __builtin_amdgcn_readfirstlane(r.v[rr]);
+        const char* src = tab + ro + lane * 16;
+        char* dst = s_crow + buf * kBufBytes + c * (P * 8u);
+#pragma unroll
+        for (uint32_t i = 0; i < P / 128; ++i)
+          if (lane + 64 * i < a.mmic_cpr)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+    };
+    uint4 yr[2][2];                                                  // [block parity][band]: column offsets of the block
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      yr[0][k] = yp[k][0];
+      yr[1][k] = yp[k][(size_t)min(1u, yblocks[k] - 1) * 64];
+    }
+    double M[2] = {0, 0}, res[2] = {QF_NEG_INF, QF_NEG_INF};
+    uint32_t flag[2] = {0, 0};
+    stage(row_offsets(0), 0);
+    Ro roNext = row_offsets(1);
+    auto block = [&](auto BUFC, int g) {
+      constexpr uint32_t BUF = decltype(BUFC)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wavefront's rows of block g have landed ...
+      __syncthreads();                                              // ... and everybody's; buffer BUF ^ 1 is no longer being read
+      uint32_t ad[2][kRowsSub];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t wd[4] = {yr[BUF][k].x, yr[BUF][k].y, yr[BUF][k].z, yr[BUF][k].w};
+#pragma unroll
+        for (int c = 0; c < kRowsSub; ++c) ad[k][c] = (c & 1) ? wd[c >> 1] >> 16 : wd[c >> 1] & 0xFFFFu;
+      }
+      double e[2][kRowsSub];
+#pragma unroll
+      for (int c = 0; c < kRowsSub; ++c)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) e[k][c] = *(const double*)(s_crow + BUF * kBufBytes + c * (P * 8u) + ad[k][c]);
+      if (g + 1 < nBlocks) stage(roNext, BUF ^ 1u);
+      roNext = row_offsets(g + 2);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) yr[BUF][k] = yp[k][(size_t)min((uint32_t)g + 2, yblocks[k] - 1) * 64];
+      const bool general = g == 0 || (g >= gFirst && __any(gEnd[0] == g || gEnd[1] == g));
+      if (!general) {
+#pragma unroll
+        for (int c = 0; c < kRowsSub; ++c)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) M[k] = (M[k] + g0) + e[k][c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < kRowsSub; ++c)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            double m = (M[k] + g0) + e[k][c];
+            if (g == 0 && c == 0) {                                 // the diagonal's first cell: Start -> Match beats -inf + ... (src/qoverlap.cpp:141)
+              m = e[k][c];
+              flag[k] = e[k][c] > QF_NEG_INF ? 3u : 0u;
+            }
+            M[k] = m;
+            if (kRowsSub * g + c + 1 == nn[k]) res[k] = m;          // the band's last cell, its only end cell
+          }
+      }
+    };
+    for (int g = 0; g < nBlocks; g += 2) {
+      block(std::integral_constant<uint32_t, 0>(), g);
+      if (g + 1 < nBlocks) block(std::integral_constant<uint32_t, 1>(), g + 1);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (nn[k] > 0) {
+        Unit* u = &a.units[uid[k]];
+        const bool colEnd = yLen[k] <= xLen, rowEnd = xLen <= yLen[k];   // the last cell is in y's last column / x's last row
+        u->end_val = colEnd ? res[k] : QF_NEG_INF; u->end_i = colEnd ? (uint32_t)nn[k] : 0u;
+        u->end2_val = rowEnd ? res[k] : QF_NEG_INF; u->end2_j = rowEnd ? (uint32_t)nn[k] : 0u;
+        u->tb_off = flag[k];   // the band's whole traceback (see k_overlap_single)
+      }
+  }
+}
+
+
 // Row-space overlap Viterbi for bands wider than 512 diagonals (-kmatchoff, or a sequence shorter than 2(k+threshold):
 // full envelope).  Geometry of k_viterbi_rows (qf_kernels.hip): one wavefront per unit, stripes of 64 lanes x 8 rows,
 // lane l one column behind lane l-1, the stripe's last row handed on through a boundary buffer.  Arithmetic, candidate
@@ -897,6 +1102,17 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;
   switch (cls) {
     case 0: {
+      if (a.slot_list && a.mmic_pitch && a.Kg == 1 && !a.no_lds_rows) {
+        const uint32_t blocks = ((a.slot_ychunks + 15) / 16) * 8 * a.slot_rows;
+        auto go = [&](auto fn, uint32_t lds) {
+          (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), lds, s, a);
+        };
+        if (a.mmic_pitch == 128) go(k_overlap_single_rows<128>, single_rows_lds<128>());
+        else if (a.mmic_pitch == 256) go(k_overlap_single_rows<256>, single_rows_lds<256>());
+        else go(k_overlap_single_rows<512>, single_rows_lds<512>());
+        break;
+      }
       const size_t row_lds = 2ull * kSingleSub * a.Km * (kNQualDev + 1) * 8;   // order 0 / 1 emission rows fit, longer contexts do not
       if (row_lds <= 64 * 1024 && !a.no_lds_rows) {
         auto fn = a.Kg > 1 ? k_overlap_single_lds<true> : k_overlap_single_lds<false>;
@@ -920,6 +1136,22 @@ void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s) {
     case 13: hipLaunchKernelGGL(k_overlap_rows, dim3(a.n_cls_units), dim3(64), 0, s, a); break;
     case 14: launch_ov_gb<32, 3>(a, s); break;
   }
+}
+uint32_t overlap_compact_pitch(uint32_t Km, uint32_t nq) {
+  const uint32_t rs = Km * nq;
+  return rs > 512 || (rs & 1u) ? 0u : rs <= 128 ? 128u : rs <= 256 ? 256u : 512u;
+}
+void launch_mmi_compact(const double* mmi, uint32_t Km, uint32_t qmin, uint32_t nq, uint32_t pitch, double* out, hipStream_t s) {
+  const uint32_t n = Km * nq * Km * nq;
+  hipLaunchKernelGGL(k_mmi_compact, dim3((n + 255) / 256), dim3(256), 0, s, mmi, Km, qmin, nq, pitch, out);
+}
+void launch_overlap_cols(const uint32_t* ctx, const uint32_t* ctxc, const uint64_t* off, uint32_t n_seqs, uint64_t total, const uint64_t* goff,
+                         uint32_t max_blocks, uint32_t Km, uint32_t qmin, uint32_t pitch, uint32_t* xrowoff, uint4* col0, uint4* col1, hipStream_t s) {
+  if (!n_seqs) return;
+  hipLaunchKernelGGL(k_overlap_xrows, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0, s, ctx, total, Km, qmin, pitch, xrowoff);
+  const uint32_t groups = (n_seqs + 63) / 64;
+  hipLaunchKernelGGL(k_overlap_cols, dim3(groups, std::max(1u, std::min(64u, (max_blocks + 3) / 4))), dim3(256), 0, s, ctx, ctxc, off, n_seqs, goff, Km, qmin,
+                     col0, col1);
 }
 bool overlap_single_stages_rows(uint32_t Km) { return 2ull * kSingleSub * Km * (kNQualDev + 1) * 8 <= 64 * 1024; }
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s) {
