@@ -17,7 +17,8 @@ class QuaffHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "libquaffhip.so")
+    # QUAFF_HIP_LIBRARY: developer A/B builds of the same library (tools/dev/variant.sh); never a different implementation
+    return os.environ.get("QUAFF_HIP_LIBRARY") or os.path.join(HERE, "libquaffhip.so")
 
 
 def build_library(force=False):

@@ -220,10 +220,18 @@ struct qf_ctx : Slot {
   std::vector<PairRow> row_items_rows;   // the runs / block / chunk size d_row_items was built for
   uint32_t row_items_lo = 0, row_items_hi = 0, row_items_n = 0;
   int row_items_cl = -1;
+  bool row_items_lds = false;
   uint64_t row_items_epoch = 0;
   uint64_t rows_settled = 0;    // QF_DEBUG_COUNT_SETTLED: pairs the prefilter settled during the last qf_overlap_resident
   uint64_t chunk_epoch = 0;
   int chunk_k = -1, chunk_log2 = 0;
+  uint64_t chunk_estride = 0;    // > 0: the chunk index is the padded one of k_seed_rows_lds
+  // k_seed_rows_lds (the prefilter with the chunk's index in LDS): whether the current chunk size was chosen for it, 16-bit entries,
+  // the most k-mer positions a chunk holds; its chunk-major items (RowItemL) and pieces
+  bool row_lds = false, row_e16 = false;
+  uint64_t row_max_entries = 0;
+  DevBuf d_row_sorted, d_row_pieces;
+  uint32_t row_pieces_n = 0;
   HostBuf<double> h_ov_result, h_ov_score;
   std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
@@ -358,7 +366,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_qrange, &c->d_ematch_q, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_qrange, &c->d_ematch_q, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list, &c->d_row_sorted, &c->d_row_pieces,
                     &c->d_mmic0, &c->d_mmic1, &c->d_xrowoff, &c->d_ycol0, &c->d_ycol1, &c->d_ygoff,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
@@ -1851,7 +1859,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     // it, instead of once per x from HBM (the index of a 100 k-sequence set is 900 MB).  The list depends only on the runs
     // and the block, so a later call with the same pair list reuses the device copy.
     const int cl = c->chunk_log2;
-    const bool cached = c->row_items_epoch == c->prep_epoch && c->row_items_lo == lo && c->row_items_hi == hi && c->row_items_cl == cl && c->row_items_rows.size() == c->ov_rows.size() &&
+    const bool cached = c->row_items_epoch == c->prep_epoch && c->row_items_lo == lo && c->row_items_hi == hi && c->row_items_cl == cl && c->row_items_lds == c->row_lds && c->row_items_rows.size() == c->ov_rows.size() &&
                         !memcmp(c->row_items_rows.data(), c->ov_rows.data(), c->ov_rows.size() * sizeof(qf_ctx::PairRow));
     if (!cached) {
       const uint32_t n_chunks = (c->n_reads + (1u << cl) - 1) >> cl;
@@ -1874,6 +1882,26 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
             sorted[first[ch]++] = {r.x, ch, yy, stop, p + (yy - y)};
             yy = stop;
           }
+      if (c->row_lds) {   // k_seed_rows_lds: the chunk-major list itself, with x's offset and length, in pieces of one chunk each
+        constexpr uint32_t kPiece = 64;
+        std::vector<RowItemL> sl(sorted.size());
+        std::vector<uint2> pieces;
+        for (size_t q = 0; q < sorted.size(); ++q) {
+          const RowItem& r = sorted[q];
+          const uint64_t xb = c->read_off[r.x];
+          sl[q] = {r.x, r.ylo, r.yhi, r.pbase, (uint32_t)(c->read_off[r.x + 1] - xb), (uint32_t)xb, (uint32_t)(xb >> 32), r.chunk};
+          if (pieces.empty() || sorted[pieces.back().x].chunk != r.chunk || pieces.back().y == kPiece) pieces.push_back(make_uint2((uint32_t)q, 0u));
+          ++pieces.back().y;
+        }
+        c->row_pieces_n = (uint32_t)pieces.size();
+        if (!sl.empty()) {
+          HIPCHK(c, c->d_row_sorted.reserve(sl.size() * sizeof(RowItemL)));
+          HIPCHK(c, c->d_row_pieces.reserve(pieces.size() * sizeof(uint2)));
+          HIPCHK(c, hipMemcpyAsync(c->d_row_sorted.p, sl.data(), sl.size() * sizeof(RowItemL), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->d_row_pieces.p, pieces.data(), pieces.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));   // stack-lifetime host buffers
+        }
+      }
       // deal: segments of kSeg consecutive items go to XCD 0, 1, ... 7, 0, ...; workgroup b sits on XCD b % 8
       constexpr uint32_t kSeg = 32, kXcd = 8;
       const uint32_t n_items = (uint32_t)sorted.size(), n_seg = (n_items + kSeg - 1) / kSeg, seg_rounds = (n_seg + kXcd - 1) / kXcd;
@@ -1889,7 +1917,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         HIPCHK(c, hipStreamSynchronize(c->stream));   // `items` is a stack-lifetime host buffer
       }
       c->row_items_rows = c->ov_rows;
-      c->row_items_lo = lo; c->row_items_hi = hi; c->row_items_cl = cl; c->row_items_epoch = c->prep_epoch;
+      c->row_items_lo = lo; c->row_items_hi = hi; c->row_items_cl = cl; c->row_items_lds = c->row_lds; c->row_items_epoch = c->prep_epoch;
     }
     n_row_items = c->row_items_n;
     if (n_row_items) HIPCHK(c, c->d_row_skip.reserve(n_pairs));
@@ -1931,7 +1959,16 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
           s.chunk_start = c->d_cstart.as<uint32_t>();
           s.chunk_entries = c->d_centries.as<uint32_t>();
           s.chunk_log2 = c->chunk_log2;
+          s.chunk_estride = c->chunk_estride;
           s.row_skip = c->d_row_skip.as<uint8_t>();
+          if (c->row_lds && c->row_pieces_n) {
+            s.row_sorted = c->d_row_sorted.p;
+            s.row_pieces = c->d_row_pieces.as<uint2>();
+            s.n_row_pieces = c->row_pieces_n;
+            s.row_n_seqs = c->n_reads;
+            s.row_max_entries = c->row_max_entries;
+            s.row_e16 = c->row_e16 ? 1 : 0;
+          }
         }
         s.pair_x = c->d_px.as<uint32_t>() + lo;
         s.pair_y = c->d_py.as<uint32_t>() + lo;
@@ -2245,22 +2282,41 @@ static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], u
     t.ref_skeys = nullptr;
     const size_t stride = seed_row_stride_bytes(t);
     int cl = 6;
-    while (stride && cl > 3 && (stride << cl) > kSeedRowLdsMax) --cl;   // two workgroups' counters per CU
-    if (stride && (stride << cl) <= kSeedRowLdsMax) {
-      if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl) {
+    // First choice: chunks small enough that counters AND the chunk's index fit one CU's LDS (k_seed_rows_lds); entries take 16
+    // bits when every position fits beside the sequence-in-chunk bits.
+    c->row_lds = false;
+    if (stride && (c->debug & QF_DEBUG_LDS_ROW_INDEX)) {   // (measured: 16.3 ms against k_seed_rows' 13.9 per row block, and its 156 KB of LDS shut every other kernel out of the CU: off unless asked for)
+      for (int tcl = 6; tcl >= 2 && !c->row_lds; --tcl) {
+        uint64_t most = 0;
+        for (uint64_t y = 0; y < n_seqs; y += 1ull << tcl) most = std::max(most, c->read_off[std::min<uint64_t>(n_seqs, y + (1ull << tcl))] - c->read_off[y]);
+        bool e16 = false;
+        const size_t need = seed_rows_lds_fit(t, tcl, most, &e16);
+        if (need && need <= kSeedRowLdsBig) {
+          c->row_lds = true; c->row_e16 = e16; c->row_max_entries = most; cl = tcl;
+        }
+      }
+    }
+    if (!c->row_lds)
+      while (stride && cl > 3 && (stride << cl) > kSeedRowLdsMax) --cl;   // two workgroups' counters per CU
+    if (stride && (c->row_lds || (stride << cl) <= kSeedRowLdsMax)) {
+      const uint64_t estride = c->row_lds ? ((c->row_max_entries + (1ull << (2 * cfg->kmer_len)) + 16 + 15) & ~15ull) : 0;   // padded index: entries per chunk
+      if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl || c->chunk_estride != estride) {
         const uint32_t nb = 1u << (2 * cfg->kmer_len), n_chunks = (n_seqs + (1u << cl) - 1) >> cl;
         const size_t bytes = (size_t)n_chunks * (nb + 1) * 4;
+        const size_t ebytes = estride ? (size_t)n_chunks * estride * 4 : (c->read_total + 16) * 4;
         HIPCHK(c, c->d_cstart.reserve(bytes));
         HIPCHK(c, c->d_ccursor.reserve(bytes));
-        HIPCHK(c, c->d_centries.reserve((c->read_total + 16) * 4));
+        HIPCHK(c, c->d_centries.reserve(ebytes));
         HIPCHK(c, hipMemsetAsync(c->d_cstart.p, 0, bytes, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ccursor.p, 0, bytes, c->stream));
+        if (estride) HIPCHK(c, hipMemsetAsync(c->d_centries.p, 0xFF, ebytes, c->stream));   // pad entries
         launch_chunk_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len, nb, cl,
-                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), c->stream);
+                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), estride, c->stream);
         HIPCHK(c, hipGetLastError());
         c->chunk_epoch = c->prep_epoch;
         c->chunk_k = cfg->kmer_len;
         c->chunk_log2 = cl;
+        c->chunk_estride = estride;
       }
       c->ov_use_rows = true;
     }

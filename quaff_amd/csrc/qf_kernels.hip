@@ -67,12 +67,15 @@ __global__ void k_ref_kmer_count(const uint8_t* __restrict__ tok, const uint64_t
 }
 
 // exclusive scan of each reference's bucket counts (one block per reference)
-__global__ __launch_bounds__(1024) void k_bucket_scan(uint32_t* __restrict__ counts, uint32_t nbuckets) {
+// pad: every bucket's count rounded up to a multiple of `pad` first (1 = as counted): the padded chunk index of k_seed_rows_lds
+__global__ __launch_bounds__(1024) void k_bucket_scan(uint32_t* __restrict__ counts, uint32_t nbuckets, uint32_t pad = 1) {
   __shared__ uint32_t part[1024];
   uint32_t* c = counts + (uint64_t)blockIdx.x * (nbuckets + 1);
   const uint32_t tid = threadIdx.x, per = (nbuckets + 1 + 1023) / 1024;
   const uint32_t lo = tid * per, hi = min(lo + per, nbuckets + 1);
   uint32_t s = 0;
+  if (pad > 1)
+    for (uint32_t a = lo; a < hi; ++a) c[a] = (c[a] + pad - 1) / pad * pad;
   for (uint32_t a = lo; a < hi; ++a) s += c[a];
   part[tid] = s;
   __syncthreads();
@@ -926,6 +929,188 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
   }
 }
 
+// The same prefilter with the chunk's k-mer index IN LDS and one 32-bit counter per coarse bin.  What bounded k_seed_rows was its
+// instruction count at a third of the lanes (profiles/r03_pmc_overlap.json; 49 lane-instructions per k-mer match): ~15
+// instructions to turn an index entry into a counter address and a 16-bit increment, behind 16-byte gathers of the entries,
+// each lane from its own 128-byte line.  Here a workgroup takes one chunk and MANY x rows (a piece of the chunk-major item
+// list).  It copies the chunk's bucket starts and entries to LDS once, each entry already as
+//     L = (sequence in chunk) x W + (len - 1 - j)        W = a sequence's counters in units of 2^(CB-2) diagonals
+// so that the counter of a match of x position i is at byte address ((L + i) >> (CB - 2)) & ~3: with CB = 2 (the overlap
+// default: bins of 4 diagonals, a byte of address per diagonal) and 16-bit entries a match is one sdwa add, one mask, one
+// compare that sets the execution mask, and a ds_add_u32.  Everything a match touches is LDS; the only global loads left are
+// x's own k-mers (coalesced, fetched one x ahead).  The threshold scan of x's counters also clears them for the next x.
+// The index is built with every bucket padded to an even number of entries (launch_chunk_index: estride > 0), so that a lane
+// reads its lists four entries at a time from 4-byte aligned addresses; a pad entry (0xFFFFFFFF in the index) becomes
+// L = 2^cl x W, whose increments land in a dummy zone behind the counters.  16 sequences of 2 kb: 64 KB of counters, 72 KB of
+// 16-bit entries, 16 KB of bucket starts -- one workgroup of 16 wavefronts per CU.
+__host__ __device__ inline uint32_t seed_rows_dummy_bytes(uint32_t max_len, int cb) { return (((max_len >> (cb - 2)) + 8u) + 15u) & ~15u; }
+template <int CB, typename ET>
+__global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows_lds(SeedArgs a, uint32_t stride) {
+  extern __shared__ uint32_t cnt[];   // [2^cl][stride] counters | dummy zone | bucket starts [nbuckets + 1] | sequence lengths [2^cl] | entries
+  static_assert(CB >= 2, "an entry carries its position in units of 2^(CB-2) diagonals");
+  const uint2 piece = a.row_pieces[blockIdx.x];
+  const RowItemL* __restrict__ items = (const RowItemL*)a.row_sorted + piece.x;
+  const int cl = a.chunk_log2, k = a.kmer_len;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, csize = 1u << cl, nb1 = a.nbuckets + 1, chunk = items[0].chunk, y0 = chunk << cl;
+  uint32_t* st = cnt + csize * stride + seed_rows_dummy_bytes(a.max_read_len, CB) / 4;
+  uint32_t* ylen = st + nb1;
+  ET* ents = (ET*)(ylen + csize);
+  const uint32_t* __restrict__ cs = a.chunk_start + (uint64_t)chunk * nb1;
+  const uint32_t* __restrict__ ce = a.chunk_entries + (uint64_t)chunk * a.chunk_estride;
+  const uint32_t nent = cs[a.nbuckets];
+  const uint32_t W = stride << CB;                                  // a sequence's counters in address units (4 x 2^(2 - CB) per byte)
+  for (uint32_t w = tid; w < csize * stride; w += kSeedRowThreads) cnt[w] = 0;
+  for (uint32_t q = tid; q < nb1; q += kSeedRowThreads) st[q] = cs[q];
+  for (uint32_t q = tid; q < nent + 8; q += kSeedRowThreads) {      // (+ the slack the four-at-a-time reads may touch)
+    const uint32_t e = q < nent ? ce[q] : 0xFFFFFFFFu;
+    ents[q] = (ET)(e == 0xFFFFFFFFu ? csize * W : (e >> 26) * W + (e & 0x3FFFFFFu));
+  }
+  if (tid < csize) ylen[tid] = y0 + tid < a.row_n_seqs ? (uint32_t)(a.read_off[y0 + tid + 1] - a.read_off[y0 + tid]) : 0u;
+  __syncthreads();
+  constexpr int R = 2;                                               // x positions per thread whose k-mers are fetched one x ahead
+  auto load_km = [&](const RowItemL& it, uint32_t* km) {
+    const uint32_t* __restrict__ xk = a.skmer + (((uint64_t)it.xb_hi << 32) | it.xb_lo);
+    const int nkx = (int)it.xlen - k + 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) km[r] = (int)(tid + r * kSeedRowThreads) < nkx ? xk[tid + r * kSeedRowThreads] : 0u;
+  };
+  const uint32_t thr = a.threshold > 1 ? (uint32_t)a.threshold : 1u, minLen = 2u * (uint32_t)(k + a.threshold);
+  const uint32_t cnt_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt;   // LDS address of the counters
+  const uint32_t ents_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) ET*)ents;
+  // Two x in flight: a counter word holds x (even item)'s count in its low half and x (odd item)'s in its high half (a bin holds
+  // fewer than 65 536 matches: seed_row_stride_bytes), so while the wavefronts walk item p they also scan and clear item p - 1's
+  // halves -- one workgroup barrier per x, and each wavefront has the other activity to issue while one waits on LDS.
+  auto settle = [&](const RowItemL& it, uint32_t half) {            // scan + clear the counters of `it`, one wavefront per y
+    const uint32_t yylo = it.ylo - y0, yyhi = it.yhi - y0;
+    const int xLen = (int)it.xlen;
+    const unsigned long long keep = half ? 0x0000FFFF0000FFFFull : 0xFFFF0000FFFF0000ull;
+    for (uint32_t yy = yylo + (tid >> 6); yy < yyhi; yy += kSeedRowThreads / 64) {
+      const int yLen = (int)ylen[yy];
+      const uint32_t nwords = (uint32_t)(((xLen + yLen - 1 + (1 << CB) - 1) >> CB) + 1);
+      bool hit = false;
+      for (uint32_t w = lane * 4; w < nwords; w += 256) {           // (rows are a multiple of four words long)
+        uint32_t* q = &cnt[yy * stride + w];
+        const uint4 v = *(const uint4*)q;
+        const uint32_t sh = 16 * half;
+        hit |= ((v.x >> sh) & 0xFFFFu) >= thr || ((v.y >> sh) & 0xFFFFu) >= thr || ((v.z >> sh) & 0xFFFFu) >= thr || ((v.w >> sh) & 0xFFFFu) >= thr;
+        atomicAnd((unsigned long long*)q, keep);                   // (the walkers of the other x are adding to the other halves)
+        atomicAnd((unsigned long long*)q + 1, keep);
+      }
+      // (sequences shorter than 2 (k + threshold) take the full envelope, diagenv.cpp:23-29: left to the per-pair kernel)
+      const bool cand = __any(hit) || (uint32_t)xLen < minLen || (uint32_t)yLen < minLen;
+      if (lane == 0) {
+        const uint32_t p = it.pbase + (y0 + yy - it.ylo);
+        if (!cand) {   // the pair's one band, the forced diagonal 0 (nobody else records bands of a settled pair)
+          a.pair_bands[(uint64_t)(a.pair_base + p) * kMaxBandsPerPair] = make_int2(0, 0);
+          a.pair_nbands[a.pair_base + p] = 1;
+          a.pair_ndiag[a.pair_base + p] = 1;
+        }
+        a.row_skip[p] = cand ? 0 : 1;
+      }
+    }
+  };
+  RowItemL cur = items[0], prev = cur;
+  uint32_t kmc[R];
+  load_km(cur, kmc);
+  for (uint32_t itn = 0; itn < piece.y; ++itn) {
+    const RowItemL nxt = items[min(itn + 1, piece.y - 1)];
+    uint32_t kmn[R];
+    load_km(nxt, kmn);
+    const int xLen = (int)cur.xlen, nkx = xLen - k + 1;
+    const uint32_t yylo = cur.ylo - y0, yyhi = cur.yhi - y0;
+    const bool whole = yylo == 0 && yyhi == csize;                   // the item takes every sequence of the chunk (all but a row's end chunks)
+    const uint32_t Llo = yylo * W, Lhi = yyhi * W;                   // (a pad entry, L = csize x W, is outside every such range)
+    const uint32_t inc = (itn & 1u) ? 0x10000u : 1u;
+    auto count = [&](uint32_t i, uint32_t L) {                       // bin = i - j + yLen - 1 (diagenv.cpp:33-40)
+      atomicAdd((uint32_t*)((char*)cnt + (((L + i) >> (CB - 2)) & ~3u)), inc);
+    };
+    uint32_t s[R], n[R], nmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool in = (int)(tid + r * kSeedRowThreads) < nkx;
+      s[r] = st[kmc[r]];
+      n[r] = in ? st[kmc[r] + 1] - s[r] : 0u;                        // (even: the pad entry is counted into the dummy zone)
+      nmax = max(nmax, n[r]);
+    }
+    if (whole && CB == 2 && sizeof(ET) == 2) {
+      // The thread's first two positions side by side, four entries of each list per round, the next round's entries fetched
+      // before this round's are counted.  Written out: two 4-byte reads per list (the lists start on even entries), then per
+      // entry the address (sdwa add of the 16-bit entry to the position, which also carries the counters' LDS address; mask)
+      // and the count under an execution mask set by the compare itself (lanes whose list still has entry t + u) and put back
+      // by one scalar move.  LDS returns in order: with the four reads of the next round and at most eight counts behind them
+      // in flight, lgkmcnt(8) at the top of a round says this round's entries have arrived.
+      static_assert(R == 2, "the counting block is written out for two lists");
+      const uint32_t ipos0 = tid + cnt_base, ipos1 = tid + kSeedRowThreads + cnt_base;
+      uint32_t p0 = ents_base + s[0] * 2, p1 = ents_base + s[1] * 2;
+      int rem0 = (int)n[0], rem1 = (int)n[1];
+      uint32_t w00, w01, w10, w11;
+      asm volatile("ds_read_b32 %0, %4\n ds_read_b32 %1, %4 offset:4\n ds_read_b32 %2, %5\n ds_read_b32 %3, %5 offset:4\n"
+                   : "=&v"(w00), "=&v"(w01), "=&v"(w10), "=&v"(w11) : "v"(p0), "v"(p1) : "memory");
+      if (itn) settle(prev, (itn - 1) & 1u);                         // (the first round's entries arrive meanwhile)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (uint32_t t = 0; t < nmax; t += 4) {
+        uint32_t a0, a1, a2, a3, a4, a5, a6, a7, c00, c01, c10, c11;
+        unsigned long long sv;
+        p0 += 8; p1 += 8;
+        asm volatile(
+            "s_waitcnt lgkmcnt(8)\n"
+            "v_mov_b32 %[c00], %[w00]\n v_mov_b32 %[c01], %[w01]\n v_mov_b32 %[c10], %[w10]\n v_mov_b32 %[c11], %[w11]\n"
+            "ds_read_b32 %[w00], %[p0]\n ds_read_b32 %[w01], %[p0] offset:4\n ds_read_b32 %[w10], %[p1]\n ds_read_b32 %[w11], %[p1] offset:4\n"
+            "v_add_u32_sdwa %[a0], %[i0], %[c00] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "v_add_u32_sdwa %[a1], %[i0], %[c00] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+            "v_add_u32_sdwa %[a2], %[i0], %[c01] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "v_add_u32_sdwa %[a3], %[i0], %[c01] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+            "v_add_u32_sdwa %[a4], %[i1], %[c10] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "v_add_u32_sdwa %[a5], %[i1], %[c10] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+            "v_add_u32_sdwa %[a6], %[i1], %[c11] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "v_add_u32_sdwa %[a7], %[i1], %[c11] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+            "v_and_b32 %[a0], -4, %[a0]\n v_and_b32 %[a1], -4, %[a1]\n v_and_b32 %[a2], -4, %[a2]\n v_and_b32 %[a3], -4, %[a3]\n"
+            "v_and_b32 %[a4], -4, %[a4]\n v_and_b32 %[a5], -4, %[a5]\n v_and_b32 %[a6], -4, %[a6]\n v_and_b32 %[a7], -4, %[a7]\n"
+            "s_mov_b64 %[sv], exec\n"
+            "v_cmpx_lt_i32 vcc, 0, %[r0]\n ds_add_u32 %[a0], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 0, %[r1]\n ds_add_u32 %[a4], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 1, %[r0]\n ds_add_u32 %[a1], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 1, %[r1]\n ds_add_u32 %[a5], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 2, %[r0]\n ds_add_u32 %[a2], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 2, %[r1]\n ds_add_u32 %[a6], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 3, %[r0]\n ds_add_u32 %[a3], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            "v_cmpx_lt_i32 vcc, 3, %[r1]\n ds_add_u32 %[a7], %[inc]\n s_mov_b64 exec, %[sv]\n"
+            : [w00] "+&v"(w00), [w01] "+&v"(w01), [w10] "+&v"(w10), [w11] "+&v"(w11), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),
+              [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6), [a7] "=&v"(a7), [c00] "=&v"(c00), [c01] "=&v"(c01),
+              [c10] "=&v"(c10), [c11] "=&v"(c11), [sv] "=&s"(sv)
+            : [p0] "v"(p0), [p1] "v"(p1), [i0] "v"(ipos0), [i1] "v"(ipos1), [r0] "v"(rem0), [r1] "v"(rem1), [inc] "v"(inc)
+            : "vcc", "memory");
+        rem0 -= 4; rem1 -= 4;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the last round's look-ahead reads land in registers nobody uses)
+    } else {
+      if (itn) settle(prev, (itn - 1) & 1u);
+      for (uint32_t t = 0; t < nmax; ++t) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (t < n[r]) {
+            const uint32_t L = ents[s[r] + t];
+            if (L >= Llo && L < Lhi) count(tid + r * kSeedRowThreads, L);
+          }
+      }
+    }
+    const uint32_t* __restrict__ xk = a.skmer + (((uint64_t)cur.xb_hi << 32) | cur.xb_lo);
+    for (int i = (int)tid + R * kSeedRowThreads; i < nkx; i += kSeedRowThreads) {   // sequences longer than R x 1024 bases
+      const uint32_t km = xk[i], s0 = st[km], e0 = st[km + 1];
+      for (uint32_t q = s0; q < e0; ++q) {
+        const uint32_t L = ents[q];
+        if (L >= Llo && L < Lhi) count((uint32_t)i, L);
+      }
+    }
+    __syncthreads();
+    prev = cur;
+    cur = nxt;
+#pragma unroll
+    for (int r = 0; r < R; ++r) kmc[r] = kmn[r];
+  }
+  settle(prev, (piece.y - 1) & 1u);
+}
+
 __global__ void k_chunk_kmer_count(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k, uint32_t nbuckets,
                                    int cl, uint32_t* __restrict__ counts) {
   const uint32_t x = blockIdx.y;
@@ -938,7 +1123,7 @@ __global__ void k_chunk_kmer_count(const uint8_t* __restrict__ tok, const uint64
 }
 __global__ void k_chunk_kmer_scatter(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k, uint32_t nbuckets,
                                      int cl, const uint32_t* __restrict__ starts, uint32_t* __restrict__ cursor,
-                                     uint32_t* __restrict__ entries) {
+                                     uint32_t* __restrict__ entries, uint64_t estride) {
   const uint32_t x = blockIdx.y;
   const uint64_t b = off[x], len = off[x + 1] - b;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -947,16 +1132,21 @@ __global__ void k_chunk_kmer_scatter(const uint8_t* __restrict__ tok, const uint
   for (uint32_t c = 0; c < k; ++c) km = km * 4 + tok[b + i + c];
   const uint64_t bi = (uint64_t)(x >> cl) * (nbuckets + 1) + km;
   const uint32_t slot = starts[bi] + atomicAdd(&cursor[bi], 1u);
-  entries[off[(uint64_t)(x >> cl) << cl] + slot] = ((x & ((1u << cl) - 1)) << 26) | (uint32_t)(len - 1 - i);
+  // a chunk's entries: behind those of the chunks before it, or (padded index) `estride` entries per chunk
+  const uint64_t cbase = estride ? (uint64_t)(x >> cl) * estride : off[(uint64_t)(x >> cl) << cl];
+  entries[cbase + slot] = ((x & ((1u << cl) - 1)) << 26) | (uint32_t)(len - 1 - i);
 }
 
 // Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
 // (pair, band slot); one global atomic per workgroup and counter.
-__global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs, uint32_t n_ovf) {
+// (1 024 threads per workgroup: the handful of global atomics a workgroup makes all go to the same few words, and at 256
+// threads a 2^24-pair row block made 800 000 of them -- 5 ms of serialised L2 atomics per block)
+constexpr int kBinThreads = 1024;
+__global__ __launch_bounds__(kBinThreads) void k_bin_units(SeedArgs a, uint32_t n_pairs, uint32_t n_ovf) {
   __shared__ uint32_t s_cnt[kNumClasses], s_base[kNumClasses], s_nact, s_ubase;
-  __shared__ unsigned long long s_cells[kNumClasses], s_scan[256], s_tb_base;
+  __shared__ unsigned long long s_cells[kNumClasses], s_wtot[kBinThreads / 64], s_wbase[kBinThreads / 64], s_tb_total, s_tb_base;
   const uint32_t tid = threadIdx.x;
-  const uint64_t idx = (uint64_t)blockIdx.x * 256 + tid;
+  const uint64_t idx = (uint64_t)blockIdx.x * kBinThreads + tid;
   const uint32_t pidx = (uint32_t)(idx / kMaxBandsPerPair), slot = (uint32_t)(idx % kMaxBandsPerPair);
   if (tid < kNumClasses) { s_cnt[tid] = 0; s_cells[tid] = 0; }
   if (tid == 0) s_nact = 0;
@@ -1008,14 +1198,28 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
       }
     }
   }
-  s_scan[tid] = tbw;
-  __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {
-    const unsigned long long v = tid >= d ? s_scan[tid - d] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
+  // exclusive prefix of the units' storage over the workgroup: inside a wavefront by shifts, across wavefronts through LDS
+  unsigned long long incl = tbw;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long v = (unsigned long long)__shfl_up((long long)incl, o, 64);
+    if ((int)(tid & 63u) >= o) incl += v;
   }
+  if ((tid & 63u) == 63u) s_wtot[tid >> 6] = incl;
+  __syncthreads();
+  if (tid < 64) {
+    const unsigned long long t = tid < kBinThreads / 64 ? s_wtot[tid] : 0ull;
+    unsigned long long ti = t;
+#pragma unroll
+    for (int o = 1; o < kBinThreads / 64; o <<= 1) {
+      const unsigned long long v = (unsigned long long)__shfl_up((long long)ti, o, 64);
+      if ((int)tid >= o) ti += v;
+    }
+    if (tid < kBinThreads / 64) s_wbase[tid] = ti - t;
+    if (tid == kBinThreads / 64 - 1) s_tb_total = ti;
+  }
+  __syncthreads();
+  const unsigned long long excl = s_wbase[tid >> 6] + incl - tbw;
   if (tid < kNumClasses && s_cnt[tid]) {
     s_base[tid] = atomicAdd(&a.bc->cls_count[tid], s_cnt[tid]);
     atomicAdd(&a.bc->cls_cells[tid], s_cells[tid]);
@@ -1023,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
   }
   if (tid == 0 && s_nact) {
     s_ubase = atomicAdd(&a.bc->n_units, s_nact);
-    s_tb_base = atomicAdd(&a.bc->tb_words, s_scan[255]);
+    s_tb_base = atomicAdd(&a.bc->tb_words, s_tb_total);
   }
   __syncthreads();
   if (!act) return;
@@ -1050,7 +1254,7 @@ __global__ __launch_bounds__(256) void k_bin_units(SeedArgs a, uint32_t n_pairs,
   u.pair = pair;
   u.dlo = dlo;
   u.dhi = dhi;
-  u.tb_off = s_tb_base + s_scan[tid] - tbw;
+  u.tb_off = s_tb_base + excl;
   u.end_val = QF_NEG_INF;
   u.end_i = 0;
   u.cls = (uint32_t)cls;
@@ -2070,16 +2274,18 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
                       uint32_t nbuckets, uint32_t* starts, uint32_t* cursor, uint32_t* pos, hipStream_t s) {
   const dim3 grid((uint32_t)((max_len + 255) / 256), n_refs);
   hipLaunchKernelGGL(k_ref_kmer_count, grid, dim3(256), 0, s, tok, off, k, nbuckets, starts);
-  hipLaunchKernelGGL(k_bucket_scan, dim3(n_refs), dim3(1024), 0, s, starts, nbuckets);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(n_refs), dim3(1024), 0, s, starts, nbuckets, 1u);
   hipLaunchKernelGGL(k_ref_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, starts, cursor, pos);
 }
+// estride = 0: a chunk's entries follow the chunks before it; > 0 (k_seed_rows_lds): buckets padded to even length (the pad
+// entry stays 0xFFFFFFFF: the caller fills the array with it first), `estride` entries per chunk
 void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
-                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, hipStream_t s) {
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, hipStream_t s) {
   const dim3 grid((uint32_t)((max_len + 255) / 256), n_seqs);
   const uint32_t n_chunks = (n_seqs + (1u << chunk_log2) - 1) >> chunk_log2;
   hipLaunchKernelGGL(k_chunk_kmer_count, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts);
-  hipLaunchKernelGGL(k_bucket_scan, dim3(n_chunks), dim3(1024), 0, s, starts, nbuckets);
-  hipLaunchKernelGGL(k_chunk_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts, cursor, entries);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(n_chunks), dim3(1024), 0, s, starts, nbuckets, estride ? 2u : 1u);
+  hipLaunchKernelGGL(k_chunk_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts, cursor, entries, estride);
 }
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;
@@ -2124,6 +2330,25 @@ size_t seed_row_stride_bytes(const SeedArgs& a) {
   if (((uint64_t)a.max_read_len << cb) >= 65280u || a.max_read_len >= (1u << 26)) return 0;   // 16-bit coarse counters, 26-bit positions
   return (size_t)((((a.max_nd + (1 << cb) - 1) >> cb) + 1) / 2 + 1) * 4;
 }
+// k_seed_rows_lds: bytes of 32-bit coarse counters per sequence of a chunk (0: the prefilter does not apply)
+size_t seed_rows_lds_stride_bytes(const SeedArgs& a) {
+  if (!seed_row_stride_bytes(a) || seed_row_bits(a) < 2) return 0;
+  const int cb = seed_row_bits(a);
+  return (((size_t)(((a.max_nd + (1 << cb) - 1) >> cb) + 1) + 3) & ~(size_t)3) * 4;   // (whole 16-byte groups: the scan reads four words at a time)
+}
+// LDS of one k_seed_rows_lds workgroup for chunks of 2^cl sequences holding at most max_entries k-mer positions (every bucket
+// padded to even: + one entry per bucket); *e16: entries fit 16 bits (all the chunk's counters, in the entries' address units,
+// below 65 536).  0: the kernel does not apply.
+size_t seed_rows_lds_fit(const SeedArgs& a, int cl, uint64_t max_entries, bool* e16) {
+  const size_t stride = seed_rows_lds_stride_bytes(a);
+  if (!stride) return 0;
+  *e16 = (((uint64_t)stride << (seed_row_bits(a) - 2)) << cl) < 65536;
+  return seed_rows_lds_bytes(a, stride, cl, max_entries, *e16);
+}
+size_t seed_rows_lds_bytes(const SeedArgs& a, size_t stride, int cl, uint64_t max_entries, bool e16) {
+  return (stride << cl) + seed_rows_dummy_bytes(a.max_read_len, seed_row_bits(a)) + ((size_t)a.nbuckets + 1 + ((size_t)1 << cl)) * 4 +
+         ((size_t)max_entries + a.nbuckets + 8) * (e16 ? 2 : 4) + 16;
+}
 bool seed_needs_workspace(const SeedArgs& a, bool mem) {
   if (!a.sparse) return false;
   if (seed_needs_deep_counters(a)) return true;
@@ -2148,7 +2373,21 @@ void with_seed_variant(bool wide, int cb, F&& f) {   // f(std::bool_constant<WID
 int launch_seed(const SeedArgs& a_in, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
   SeedArgs a = a_in;
-  if (a.row_items && a.n_row_items && !mem) {   // settle the pairs with nothing but the forced diagonal a chunk of y at a time
+  if (a.row_pieces && a.n_row_pieces && !mem) {   // the same with the chunk's index in LDS, one workgroup per chunk and piece of x rows
+    const size_t stride = seed_rows_lds_stride_bytes(a);
+    const size_t lds = seed_rows_lds_bytes(a, stride, a.chunk_log2, a.row_max_entries, a.row_e16 != 0);
+    if (stride && lds <= kSeedRowLdsBig) {
+      const int cb = seed_row_bits(a);
+      auto go = [&](auto fn) {
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(fn, dim3(a.n_row_pieces), dim3(kSeedRowThreads), lds, s, a, (uint32_t)(stride / 4));
+      };
+      if (a.row_e16) { if (cb == 4) go(k_seed_rows_lds<4, uint16_t>); else if (cb == 3) go(k_seed_rows_lds<3, uint16_t>); else go(k_seed_rows_lds<2, uint16_t>); }
+      else { if (cb == 4) go(k_seed_rows_lds<4, uint32_t>); else if (cb == 3) go(k_seed_rows_lds<3, uint32_t>); else go(k_seed_rows_lds<2, uint32_t>); }
+      static_assert(sizeof(RowItemL) == 32, "host and device agree on the item layout");
+      a.pair_skip = a.row_skip;
+    }
+  } else if (a.row_items && a.n_row_items && !mem) {   // settle the pairs with nothing but the forced diagonal a chunk of y at a time
     const size_t stride = seed_row_stride_bytes(a);
     const size_t lds = stride << a.chunk_log2;
     if (stride && lds <= kSeedRowLdsMax) {
@@ -2226,7 +2465,7 @@ int launch_seed(const SeedArgs& a_in, uint32_t n_pairs, bool mem, hipStream_t s)
 void launch_bin_units(const SeedArgs& a, uint32_t n_pairs, uint32_t n_ovf, hipStream_t s) {
   const uint64_t threads = n_ovf ? (uint64_t)n_ovf : (uint64_t)n_pairs * kMaxBandsPerPair;
   if (!threads) return;
-  hipLaunchKernelGGL(k_bin_units, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, a, n_pairs, n_ovf);
+  hipLaunchKernelGGL(k_bin_units, dim3((uint32_t)((threads + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0, s, a, n_pairs, n_ovf);
 }
 void launch_finalize(const FinalArgs& a, hipStream_t s) {
   if (a.n_pairs) hipLaunchKernelGGL(k_finalize_pairs, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a);

@@ -38,6 +38,12 @@ struct PrepArgs {
   BatchCounters* bc;
 };
 
+constexpr size_t kSeedRowLdsBig = 160 * 1024;  // LDS of one k_seed_rows_lds workgroup (counters + the chunk's k-mer index): one per CU
+struct RowItemL { uint32_t x, ylo, yhi, pbase, xlen, xb_lo, xb_hi, chunk; };   // RowItem + x's offset and length (no dependent loads in the kernel)
+size_t seed_rows_lds_stride_bytes(const struct SeedArgs& a);
+size_t seed_rows_lds_stride_bytes(const struct SeedArgs& a);
+size_t seed_rows_lds_fit(const struct SeedArgs& a, int cl, uint64_t max_entries, bool* e16);
+size_t seed_rows_lds_bytes(const struct SeedArgs& a, size_t stride, int cl, uint64_t max_entries, bool e16);
 constexpr size_t kSeedRowLdsMax = 76 * 1024;   // LDS of one row-prefilter workgroup (per-y coarse counters of a chunk): two fit a CU
 struct RowItem { uint32_t x, chunk, ylo, yhi, pbase; };   // pairs (x, y) for y in [ylo, yhi), all inside one chunk; pair index of ylo
 
@@ -80,9 +86,17 @@ struct SeedArgs {
   const RowItem* row_items;    // optional
   uint32_t n_row_items;
   const uint32_t* chunk_start; // [n_chunks][nbuckets + 1] bucket starts of each chunk of 2^chunk_log2 consecutive sequences
-  const uint32_t* chunk_entries; // per chunk, from position read_off[first sequence of the chunk]: (sequence in chunk) << 26 | (len - 1 - j)
+  const uint32_t* chunk_entries; // per chunk, from position read_off[first sequence of the chunk] (or chunk x chunk_estride): (sequence in chunk) << 26 | (len - 1 - j)
+  uint64_t chunk_estride;      // > 0: the padded index of k_seed_rows_lds (buckets of even length, pad entries 0xFFFFFFFF)
   int chunk_log2;
   uint8_t* row_skip;           // [n_pairs], zero-initialised: set for the pairs the prefilter settled
+  // the prefilter with the chunk's index in LDS (k_seed_rows_lds): the items chunk-major with x's offset / length (RowItemL),
+  // cut into pieces (first item, count) of one chunk each; LDS sizing: most k-mer positions of a chunk, 16-bit entries or not
+  const void* row_sorted;
+  const uint2* row_pieces;
+  uint32_t n_row_pieces, row_n_seqs;
+  uint64_t row_max_entries;
+  int row_e16;
   // slotted single-diagonal list (overlap, x-major lists with consecutive x): unit of pair (x, y) at
   // slot_list[((y >> 8) * slot_rows + (x - slot_x0)) * 256 + (y & 255)], holes = ~0u (kNoUnit)
   uint32_t* slot_list;         // optional, ~0u-initialised
@@ -278,7 +292,7 @@ int sort_kmer_index(const uint8_t* tok, const uint64_t* d_off, const int* d_off3
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s);
 // k-mer index of chunks of 2^chunk_log2 consecutive sequences (row prefilter of the overlap seeding)
 void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
-                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, hipStream_t s);
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, hipStream_t s);
 // LDS bytes per sequence of a chunk in the row prefilter (coarse counters of one pair), or 0 if the prefilter does not apply
 size_t seed_row_stride_bytes(const SeedArgs& a);
 void launch_overlap_fill(int cls, const OvArgs& a, hipStream_t s);

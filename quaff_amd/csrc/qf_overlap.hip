@@ -643,10 +643,16 @@ __global__ __launch_bounds__(256) void k_overlap_cols(const uint32_t* __restrict
   }
 }
 
-constexpr int kRowsSub = 8;                    // columns per staged block
+#ifndef QF_SR_SUB
+#define QF_SR_SUB 8
+#endif
+#ifndef QF_SR_WAVES
+#define QF_SR_WAVES 3
+#endif
+constexpr int kRowsSub = QF_SR_SUB;            // columns per staged block
 template <int P> constexpr uint32_t single_rows_lds() { return 2u * kRowsSub * P * 8u + 64u; }
 template <int P>
-__global__ __launch_bounds__(256) void k_overlap_single_rows(OvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF_SR_WAVES))) void k_overlap_single_rows(OvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char s_crow[];     // [2][kRowsSub][P] doubles, then control words
   constexpr uint32_t kBufBytes = kRowsSub * P * 8u;
   int* s_ctl = (int*)(s_crow + 2 * kBufBytes);
@@ -941,11 +947,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
-__global__ void k_overlap_finalize(OvArgs a) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < a.n_pairs;
+// (A fixed grid striding over the pairs: the totals are three words, and one atomic per wavefront on each -- 800 000 of them per
+// 2^24-pair row block -- serialised in L2 for 6 ms; now one per workgroup of the fixed grid.)
+constexpr int kFinalizeBlocks = 2048;
+__global__ __launch_bounds__(256) void k_overlap_finalize(OvArgs a) {
+  __shared__ unsigned long long s_tot[3];
+  if (threadIdx.x < 3) s_tot[threadIdx.x] = 0;
+  __syncthreads();
   unsigned long long t_finite = 0, t_ndiag = 0, t_bits = 0;
-  if (live) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < a.n_pairs; p += gridDim.x * blockDim.x) {
     const uint32_t x = a.pair_x[p], y = a.pair_y[p], comp = a.pair_comp[p];
     const uint32_t xLen = (uint32_t)(a.seq_off[x + 1] - a.seq_off[x]), yLen = (uint32_t)(a.seq_off[y + 1] - a.seq_off[y]);
     double cb = QF_NEG_INF, rb = QF_NEG_INF;
@@ -972,10 +982,10 @@ __global__ void k_overlap_finalize(OvArgs a) {
       a.pair_end_ij[2 * p] = ei;
       a.pair_end_ij[2 * p + 1] = ej;
     }
-    t_ndiag = a.pair_ndiag[p];
+    t_ndiag += a.pair_ndiag[p];
     if (end > QF_NEG_INF) {
-      t_finite = 1;
-      t_bits = (unsigned long long)__double_as_longlong(result);
+      t_finite += 1;
+      t_bits += (unsigned long long)__double_as_longlong(result);
     }
     if (keep) {
       const Unit& u = a.units[eu];
@@ -991,14 +1001,20 @@ __global__ void k_overlap_finalize(OvArgs a) {
       a.recs[idx] = rec;
     }
   }
-  // totals over the pairs (what the row-block entry point reports instead of per-pair arrays): one atomic per wavefront each
+  // totals over the pairs (what the row-block entry point reports instead of per-pair arrays): one atomic per workgroup each
   t_finite = wave_sum_u64(t_finite);
   t_ndiag = wave_sum_u64(t_ndiag);
   t_bits = wave_sum_u64(t_bits);
   if ((threadIdx.x & 63) == 0) {
-    if (t_finite) atomicAdd(&a.bc->n_finite, t_finite);
-    if (t_ndiag) atomicAdd(&a.bc->sum_ndiag, t_ndiag);
-    if (t_bits) atomicAdd(&a.bc->result_sum, t_bits);
+    atomicAdd(&s_tot[0], t_finite);
+    atomicAdd(&s_tot[1], t_ndiag);
+    atomicAdd(&s_tot[2], t_bits);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_tot[0]) atomicAdd(&a.bc->n_finite, s_tot[0]);
+    if (s_tot[1]) atomicAdd(&a.bc->sum_ndiag, s_tot[1]);
+    if (s_tot[2]) atomicAdd(&a.bc->result_sum, s_tot[2]);
   }
 }
 
@@ -1160,7 +1176,7 @@ void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_overlap_sums, dim3((n + 63) / 64), dim3(64), 0, s, a, (const uint32_t*)a.ctx, n);
 }
 void launch_overlap_finalize(const OvArgs& a, hipStream_t s) {
-  if (a.n_pairs) hipLaunchKernelGGL(k_overlap_finalize, dim3((a.n_pairs + 255) / 256), dim3(256), 0, s, a);
+  if (a.n_pairs) hipLaunchKernelGGL(k_overlap_finalize, dim3(std::min<uint32_t>((a.n_pairs + 255) / 256, kFinalizeBlocks)), dim3(256), 0, s, a);
 }
 void launch_overlap_row_pairs(uint32_t x0, uint32_t rows, uint32_t n_seqs, uint32_t n_orig, uint32_t* px, uint32_t* py, uint8_t* pc,
                               hipStream_t s) {
