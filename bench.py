@@ -162,10 +162,13 @@ def pmc_for(workload, kernel_prefix):
     return None, prov
 
 
-# Bytes a kernel that does not materialise the matrix still has to stream per cell: a single-diagonal overlap band
-# keeps no per-cell traceback and shares its x context and emission rows with its workgroup; what is its own is the 4-byte
-# context word of its y base.
-STREAM_BYTES_PER_CELL = {"overlap_single": 4.0}
+# A single-diagonal overlap band materialises neither the matrix nor a traceback, and its x emission rows and its own column
+# offsets come out of L2 (2.8 GB of HBM traffic per 2^24-pair block, profiles/r03_pmc_overlap.json): no HBM roof binds it.  What
+# every cell does need is one 8-byte gather of its pair emission from the staged rows in LDS and the recurrence's
+# fp64 operations; its roofline is quoted against the smaller of the two hardware fractions, the LDS one: 256 B per clock per CU
+# (MI355X_MICROARCH.md, LDS) x 256 CUs x 2.4 GHz.
+LDS_BYTES_PER_CELL = {"overlap_single": 8.0}
+LDS_PEAK_GBS = 256 * 256 * 2.4
 
 
 def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
@@ -174,7 +177,7 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     ops = F64_OPS_PER_CELL[kind]
     t = ms * 1e-3
     alg_gbs = BYTES_PER_CELL * cells / t / 1e9
-    stream_bpc = STREAM_BYTES_PER_CELL.get(kind)
+    lds_bpc = LDS_BYTES_PER_CELL.get(kind)
     valu = ops * cells / t / 1e12
     pmc, prov = pmc_for(workload, kernel.replace(" ", ""))
     if pmc and abs(pmc.get("cells_per_launch", 0) - cells) > 0.01 * cells:
@@ -185,11 +188,11 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     if bound == "fp64_valu":
         out.update(achieved=round(valu, 3), peak=F64_PEAK_TOPS, unit="TFLOP/s", frac=round(valu / F64_PEAK_TOPS, 4),
                    f64_ops_per_cell=ops)
-    elif stream_bpc:
-        gbs = stream_bpc * cells / t / 1e9
-        out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), bytes_per_cell=stream_bpc,
-                   note="bytes this kernel has to stream per cell (it materialises neither the matrix nor a traceback); the 24 B/cell "
-                        "of SURVEY 8(d) is under `hbm`")
+    elif bound == "lds" and lds_bpc:
+        gbs = lds_bpc * cells / t / 1e9
+        out.update(achieved=round(gbs, 1), peak=LDS_PEAK_GBS, unit="GB/s", frac=round(gbs / LDS_PEAK_GBS, 4), lds_bytes_per_cell=lds_bpc,
+                   note="one ds_read_b64 of the pair emission per cell against the CUs' LDS rate (256 B/clk/CU); the smaller of this and "
+                        "the fp64 fraction below; nothing this kernel reads has to come from HBM (`hbm` keeps SURVEY 8(d)'s 24 B/cell view)")
     else:
         out.update(achieved=round(alg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_gbs / HBM_PEAK_GBS, 4),
                    bytes_per_cell=BYTES_PER_CELL)
@@ -686,7 +689,7 @@ class OverlapJob(Job):
     def kernel_symbol(self, cls):
         name = self.ctx.L.qf_fill_class_name(cls).decode()
         if cls == 0:
-            return "qf::k_overlap_single_lds"
+            return "qf::k_overlap_single_rows"
         if name == "k_viterbi_rows":
             return "qf::k_overlap_rows"
         return "qf::" + name.replace("k_viterbi_fill", "k_overlap_fill")
@@ -700,7 +703,7 @@ class OverlapJob(Job):
         launches = max(1, self.tot["n_blocks"])
         sym = self.kernel_symbol(dom)
         kind = "overlap_single" if dom == 0 else "overlap"
-        roof = roofline_entry(a.workload, sym, kind, e["cells"] / launches, e["ms"] / launches, "fp64_valu" if dom else "hbm")
+        roof = roofline_entry(a.workload, sym, kind, e["cells"] / launches, e["ms"] / launches, "fp64_valu" if dom else "lds")
         roof["launches_per_step"] = launches // steps
         if not a.serial_classes and self.blocks:
             # the dominant kernel alone, on one internal block: in the timed region it shares the GPU with the other fill classes
@@ -714,7 +717,7 @@ class OverlapJob(Job):
             sres = self.ctx.overlap_rows(self.n, b0, b1, self.cfg, raw=True)
             self.ctx.set_debug_flags(a.debug_flags)
             if sres.units_class[dom]:
-                iso = roofline_entry(a.workload, sym, kind, int(sres.cells_class[dom]), float(sres.ms_fill_class[dom]), "fp64_valu" if dom else "hbm")
+                iso = roofline_entry(a.workload, sym, kind, int(sres.cells_class[dom]), float(sres.ms_fill_class[dom]), "fp64_valu" if dom else "lds")
                 roof["isolated"] = {"rows": [b0, b1], "cells_per_launch": iso["cells_per_launch"], "ms_per_launch": iso["ms_per_launch"],
                                     "achieved": iso["achieved"], "frac": iso["frac"]}
         t = {k: v // steps if k != "checksum" else v for k, v in self.tot.items()}
@@ -854,6 +857,7 @@ def main():
         if "WORLD_SIZE" in os.environ:
             dist.barrier()                    # barrier + torch.cuda.synchronize() on both sides
 
+    rccl = dist.rccl_report(job.ctx, a.single_device) if "WORLD_SIZE" in os.environ else {"ranks": 1, "distinct_devices": 1, "backend": None}
     job.run_steps(a.warmup)
     if hasattr(job, "reset"):
         job.reset()
@@ -879,7 +883,9 @@ def main():
     cfg.update(job.extra)
     out = {"metric": job.metric, "value": total_cells / dt, "unit": "DP cells/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": job.scaling,
-           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu, "rccl": rccl}
+    if world > 1 and not a.single_device:
+        assert rccl["ranks"] == world and rccl["distinct_devices"] == world, rccl
     print(json.dumps(out))
     sys.stdout.flush()
     for c in getattr(job, "ctxs", [job.ctx]):

@@ -123,6 +123,9 @@ int qf_ctx_create(int device_id, qf_ctx **ctx);
 void qf_ctx_destroy(qf_ctx *ctx);
 const char *qf_last_error(const qf_ctx *ctx);   /* ctx may be NULL: last creation error */
 int qf_device_name(const qf_ctx *ctx, char *buf, size_t cap);
+/* PCI bus id of the context's device ("0000:c1:00.0"): what tells two ranks' GPUs apart when a job reports how many distinct
+ * devices its ranks really ran on (bench.py's `rccl` object; the reference has no counterpart: its workers are host threads). */
+int qf_device_bus_id(const qf_ctx *ctx, char *buf, size_t cap);
 /* Alignments whose null-adjusted score is below `min_score` are not traced back and not returned by qf_align_* /
  * qf_overlap_resident (the per-pair score arrays are still complete).  This is the reference printer's `-threshold`
  * (QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600; default there 0, `-nothreshold` = -inf) applied before the traceback

@@ -579,13 +579,15 @@ def round_half_away(x):
     return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
 
 
-def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True, skip_pathless=False):
+def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True, skip_pathless=False, details=None):
     """QuaffCountingTask::run, src/qmodel.cpp:2238-2271.  Returns (yCounts as flattened
     QuaffParamCounts-style QuaffCounts sum, yLogLike, new sort order).  The returned counts are
     still in QuaffCounts layout (m2m,m2i,m2d,m2e,...); param_counts() converts.
     skip_pathless: under -force (use_null False) the running yLogLike starts at -inf, so a reference without any path (Forward
     = -inf) passes the `>= yLogLike - 20` test (:2252), gets a Backward pass whose counts are NaN, and 0 x NaN (:2259-2261) makes
-    the read's -- and the E-step's -- totals NaN in the reference.  True leaves such references out (what the library does)."""
+    the read's -- and the E-step's -- totals NaN in the reference.  True leaves such references out (what the library does).
+    details: a dict that receives "forward" (the per-reference Forward log-likelihoods) and "counted" (the references that got a
+    Backward pass), for tests that pin WHICH pairs carry weight."""
     rc = ReadCtx(read, sc)
     ynull = null.loglike(read) if use_null else NEG_INF
     ylog = ynull
@@ -601,9 +603,13 @@ def count_read(refs, read, sc, null, cfg, sort_order=None, use_null=True, skip_p
             _, _, cnt = forward_backward(xt, rc, sc, d, cfg.local, want_back=True)
             xyc[nx] = cnt
         ylog = lse(ylog, f)
+    if details is not None:
+        details["forward"] = list(xyll)
+        details["counted"] = [nx for nx in range(len(refs)) if xyc[nx] is not None]
     tot = np.zeros(counts_size(sc.Km, sc.Kg))
     for nx in range(len(refs)):
-        w = math.exp(xyll[nx] - ylog) if xyll[nx] > NEG_INF else 0.0
+        # exp(xyLogLike - yLogLike), src/qmodel.cpp:2259: NaN for -inf - -inf (a read without any path under -force), as there
+        w = 0.0 if (skip_pathless and xyll[nx] == NEG_INF) else math.exp(xyll[nx] - ylog) if not (math.isinf(xyll[nx]) and math.isinf(ylog)) else float("nan")
         if xyc[nx] is not None:
             tot += w * param_counts(xyc[nx], sc.Km, sc.Kg)
     asc = sorted(range(len(refs)), key=lambda a: xyll[a])

@@ -125,7 +125,7 @@ EXPORTS = ["qf_ctx_create", "qf_ctx_destroy", "qf_last_error", "qf_device_name",
            "qf_fill_class_name", "qf_count_resident", "qf_counts_size", "qf_overlap_resident", "qf_set_params_raw", "qf_set_null_raw", "qf_set_memory_budget", "qf_set_pipeline_chunks",
            "qf_device_count", "qf_set_score_threshold", "qf_comm_unique_id", "qf_comm_init_rank", "qf_comm_init_all",
            "qf_comm_size", "qf_comm_destroy", "qf_allreduce_counts", "qf_overlap_rows", "qf_overlap_rows_pairs",
-           "qf_exact_add", "qf_exact_to_double", "qf_exact_from_double", "qf_allreduce_counts_exact"]
+           "qf_exact_add", "qf_exact_to_double", "qf_exact_from_double", "qf_allreduce_counts_exact", "qf_device_bus_id"]
 
 
 def load_library():
@@ -358,6 +358,12 @@ class Context:
     def device_name(self):
         b = C.create_string_buffer(256)
         self._chk(self.L.qf_device_name(self.h, b, 256))
+        return b.value.decode()
+
+    def device_bus_id(self):
+        b = C.create_string_buffer(64)
+        self.L.qf_device_bus_id.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self._chk(self.L.qf_device_bus_id(self.h, b, 64))
         return b.value.decode()
 
     def set_params_json(self, text=None):

@@ -250,6 +250,8 @@ struct qf_ctx : Slot {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_size = 1;
   DevBuf d_comm;
+  HostBuf<uint64_t> h_comm;       // pinned staging of the all-reduce (doubles or limbs)
+  hipEvent_t ev_comm = nullptr;   // recorded behind the collective: the deadline wait polls it
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -378,6 +380,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   if (c->sort_temp) (void)hipFree(c->sort_temp);
   if (c->ev_tok) (void)hipEventDestroy(c->ev_tok);
   if (c->ev_nll) (void)hipEventDestroy(c->ev_nll);
+  if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
   if (c->second_ready) {
     (void)hipStreamSynchronize(c->second.stream);
     c->second.destroy();
@@ -392,6 +395,11 @@ int qf_device_name(const qf_ctx* c, char* buf, size_t cap) {
   if (!c || !buf || !cap) return QF_ERR_ARG;
   snprintf(buf, cap, "%s", c->devname.c_str());
   return QF_OK;
+}
+
+int qf_device_bus_id(const qf_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap < 16) return QF_ERR_ARG;
+  return hipDeviceGetPCIBusId(buf, (int)cap, c->device) == hipSuccess ? QF_OK : QF_ERR_DEVICE;
 }
 
 // ---------------------------------------------------------------------------------- model
@@ -2647,7 +2655,8 @@ int qf_comm_init_rank(qf_ctx* c, const uint8_t* id, int rank, int n_ranks) {
   }
   qf_comm_destroy(c);
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, c->d_comm.reserve(((size_t)qf_counts_size(c) + 64) * 8));   // the staging buffer now: nothing to allocate between the ranks' collectives
+  HIPCHK(c, c->d_comm.reserve((((size_t)qf_counts_size(c) + 1) * 5 + 64) * 8));   // the staging buffers now (five words per value on the exact path): nothing to allocate between the ranks' collectives
+  c->h_comm.reserve(((size_t)qf_counts_size(c) + 1) * 5 + 64);
   ncclUniqueId u;
   memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
   // ncclCommInitRank returns only when all n_ranks have called it, and a rank whose peer died before getting here would wait
@@ -2694,7 +2703,8 @@ int qf_comm_init_all(qf_ctx* const* ctxs, int n) {
   for (int k = 0; k < n; ++k) qf_comm_destroy(ctxs[k]);
   for (int k = 0; k < n; ++k) {     // staging buffers before the communicators exist: a failed allocation fails the call, not one rank of a collective
     HIPCHK(ctxs[k], hipSetDevice(ctxs[k]->device));
-    HIPCHK(ctxs[k], ctxs[k]->d_comm.reserve(((size_t)qf_counts_size(ctxs[k]) + 64) * 8));
+    HIPCHK(ctxs[k], ctxs[k]->d_comm.reserve((((size_t)qf_counts_size(ctxs[k]) + 1) * 5 + 64) * 8));
+    ctxs[k]->h_comm.reserve(((size_t)qf_counts_size(ctxs[k]) + 1) * 5 + 64);
   }
   std::vector<ncclComm_t> comms(n, nullptr);
   const ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, dev.data());
@@ -2719,30 +2729,28 @@ void qf_comm_destroy(qf_ctx* c) {
 // Every exit that is not success aborts the communicator: a rank that fails before or inside the collective must not leave its
 // peers blocked in it (they then time out of their own wait below, or see RCCL's error), and the communicator is unusable after a
 // failed collective anyway.
-int qf_allreduce_counts(qf_ctx* c, double* counts, uint32_t n, double* loglike) {
-  if (!c || (n && !counts)) return QF_ERR_ARG;
-  if (!c->comm) return fail(c, QF_ERR_STATE, "no communicator (qf_comm_init_rank / qf_comm_init_all)");
-  const size_t m = (size_t)n + (loglike ? 1 : 0);
-  if (!m) return QF_OK;
+// One all-reduce of `words` 8-byte values held in c->h_comm (pinned, owned by the context), in place: up, ncclAllReduce, wait
+// with a deadline, down.  The wait polls an event recorded behind the collective -- a collective finishes only when every rank
+// has entered it -- and the download is queued only after the event has fired: a rank whose peer never arrives returns a status
+// with nothing of its own still in flight into host memory (the staging buffer outlives the call anyway).
+static int comm_allreduce_staged(qf_ctx* c, size_t words, ncclDataType_t type) {
   auto bail = [&](const std::string& what) {
     (void)hipGetLastError();
     comm_abort(c);
     return fail(c, QF_ERR_DEVICE, what + " (communicator aborted)");
   };
   if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice");
-  if (c->d_comm.reserve(m * 8) != hipSuccess) return bail("cannot allocate the all-reduce staging buffer");
-  double* d = c->d_comm.as<double>();
-  if (n && hipMemcpyAsync(d, counts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the counts");
-  if (loglike && hipMemcpyAsync(d + n, loglike, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the log-likelihood");
-  const double limit = comm_timeout_s();
-  const ncclResult_t r = g_rccl.AllReduce(d, d, m, ncclDouble, ncclSum, c->comm, c->stream);
+  if (c->d_comm.reserve(words * 8) != hipSuccess) return bail("cannot allocate the all-reduce staging buffer");
+  if (!c->ev_comm && hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+  uint64_t* d = c->d_comm.as<uint64_t>();
+  if (hipMemcpyAsync(d, c->h_comm.data(), words * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the counts");
+  const ncclResult_t r = g_rccl.AllReduce(d, d, words, type, ncclSum, c->comm, c->stream);
   if (r != ncclSuccess) return bail(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
-  if (n && hipMemcpyAsync(counts, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the counts");
-  if (loglike && hipMemcpyAsync(loglike, d + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the log-likelihood");
-  // the collective finishes when every rank has entered it: wait with a deadline, not with hipStreamSynchronize
+  if (hipEventRecord(c->ev_comm, c->stream) != hipSuccess) return bail("hipEventRecord");
+  const double limit = comm_timeout_s();
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
-    const hipError_t q = hipStreamQuery(c->stream);
+    const hipError_t q = hipEventQuery(c->ev_comm);
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) return bail(std::string("all-reduce stream: ") + hipGetErrorString(q));
     if (g_rccl.CommGetAsyncError) {
@@ -2754,6 +2762,22 @@ int qf_allreduce_counts(qf_ctx* c, double* counts, uint32_t n, double* loglike) 
       return bail("the all-reduce did not complete within " + std::to_string((int)limit) + " s: a peer rank is missing");
     std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
+  if (hipMemcpyAsync(c->h_comm.data(), d, words * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the counts");
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return bail("download of the counts");
+  return QF_OK;
+}
+
+int qf_allreduce_counts(qf_ctx* c, double* counts, uint32_t n, double* loglike) {
+  if (!c || (n && !counts)) return QF_ERR_ARG;
+  if (!c->comm) return fail(c, QF_ERR_STATE, "no communicator (qf_comm_init_rank / qf_comm_init_all)");
+  const size_t m = (size_t)n + (loglike ? 1 : 0);
+  if (!m) return QF_OK;
+  c->h_comm.resize(m);
+  if (n) memcpy(c->h_comm.data(), counts, (size_t)n * 8);
+  if (loglike) memcpy(c->h_comm.data() + n, loglike, 8);
+  if (int rc = comm_allreduce_staged(c, m, ncclDouble)) return rc;
+  if (n) memcpy(counts, c->h_comm.data(), (size_t)n * 8);
+  if (loglike) memcpy(loglike, c->h_comm.data() + n, 8);
   return QF_OK;
 }
 
@@ -2807,7 +2831,8 @@ int qf_allreduce_counts_exact(qf_ctx* c, uint64_t* fx, uint32_t n) {
   if (!c->comm) return fail(c, QF_ERR_STATE, "no communicator (qf_comm_init_rank / qf_comm_init_all)");
   if (!n) return QF_OK;
   // a marker (non-finite sum) travels as a count in a fifth word per value
-  std::vector<uint64_t> limbs((size_t)n * 5);
+  c->h_comm.resize((size_t)n * 5);
+  uint64_t* limbs = c->h_comm.data();
   for (uint32_t k = 0; k < n; ++k) {
     const uint64_t lo = fx[2 * (size_t)k], hi = fx[2 * (size_t)k + 1];
     const bool mark = exact_is_marker(fx + 2 * (size_t)k);
@@ -2815,29 +2840,8 @@ int qf_allreduce_counts_exact(qf_ctx* c, uint64_t* fx, uint32_t n) {
     L[0] = mark ? 0 : (lo & 0xFFFFFFFFull); L[1] = mark ? 0 : (lo >> 32); L[2] = mark ? 0 : (hi & 0xFFFFFFFFull); L[3] = mark ? 0 : (hi >> 32);
     L[4] = mark ? 1 : 0;
   }
-  const size_t m = limbs.size();
-  auto bail = [&](const std::string& what) {
-    (void)hipGetLastError();
-    comm_abort(c);
-    return fail(c, QF_ERR_DEVICE, what + " (communicator aborted)");
-  };
-  if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice");
-  if (c->d_comm.reserve(m * 8) != hipSuccess) return bail("cannot allocate the all-reduce staging buffer");
-  uint64_t* d = c->d_comm.as<uint64_t>();
-  if (hipMemcpyAsync(d, limbs.data(), m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail("upload of the counts");
-  const ncclResult_t r = g_rccl.AllReduce(d, d, m, ncclUint64, ncclSum, c->comm, c->stream);
-  if (r != ncclSuccess) return bail(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
-  if (hipMemcpyAsync(limbs.data(), d, m * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return bail("download of the counts");
-  const double limit = comm_timeout_s();
-  const auto t0 = std::chrono::steady_clock::now();
-  for (;;) {
-    const hipError_t q = hipStreamQuery(c->stream);
-    if (q == hipSuccess) break;
-    if (q != hipErrorNotReady) return bail(std::string("all-reduce stream: ") + hipGetErrorString(q));
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-      return bail("the all-reduce did not complete within " + std::to_string((int)limit) + " s: a peer rank is missing");
-    std::this_thread::sleep_for(std::chrono::microseconds(50));
-  }
+  if (int rc = comm_allreduce_staged(c, (size_t)n * 5, ncclUint64)) return rc;
+  limbs = c->h_comm.data();
   for (uint32_t k = 0; k < n; ++k) {
     const uint64_t* L = &limbs[(size_t)k * 5];
     if (L[4]) { fx[2 * (size_t)k] = 0; fx[2 * (size_t)k + 1] = kExactInfHigh; continue; }

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_overlap_cols(const uint32_t* __restrict
 #define QF_SR_SUB 8
 #endif
 #ifndef QF_SR_WAVES
-#define QF_SR_WAVES 3
+#define QF_SR_WAVES 4
 #endif
 constexpr int kRowsSub = QF_SR_SUB;            // columns per staged block
 template <int P> constexpr uint32_t single_rows_lds() { return 2u * kRowsSub * P * 8u + 64u; }

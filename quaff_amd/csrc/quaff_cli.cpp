@@ -22,6 +22,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "../../include/quaff_hip.h"
 #include "qf_em.hpp"
@@ -194,13 +199,25 @@ static void writeStockholm(ostream& out, const Hit& h) {
   size_t tag = 0;
   for (const auto& l : lines) tag = max(tag, l.first.size());
   const size_t perBlock = max(tag, 79 - tag);
-  out << "# STOCKHOLM 1.0" << endl << "#=GF Score " << fmt6(h.score) << endl;
-  for (int k = 0; k < 2; ++k) if (h.note[k].size()) out << "#=GS CC " << h.label[k] << ' ' << h.note[k] << endl;
+  // the record is composed in memory and written in one piece (a line at a time with std::endl the writer flushed 24 M times
+  // for 57 k overlaps of 2 kb reads: 17 of the command's 20 s)
+  string buf;
+  buf.reserve(lines.size() * (xs.size() + (xs.size() / perBlock + 1) * (tag + 2)) + 256);
+  buf += "# STOCKHOLM 1.0\n#=GF Score ";
+  buf += fmt6(h.score);
+  buf += '\n';
+  for (int k = 0; k < 2; ++k) if (h.note[k].size()) { buf += "#=GS CC "; buf += h.label[k]; buf += ' '; buf += h.note[k]; buf += '\n'; }
   for (size_t c = 0; c < xs.size(); c += perBlock) {
-    if (c) out << endl;
-    for (const auto& l : lines) out << l.first << string(tag - l.first.size(), ' ') << ' ' << l.second.substr(c, perBlock) << endl;
+    if (c) buf += '\n';
+    for (const auto& l : lines) {
+      buf += l.first;
+      buf.append(tag - l.first.size() + 1, ' ');
+      buf.append(l.second, c, perBlock);
+      buf += '\n';
+    }
   }
-  out << "//" << endl;
+  buf += "//\n";
+  out.write(buf.data(), (std::streamsize)buf.size());
 }
 
 // SAM record (writeSam, src/qmodel.cpp:608-616).  An alignment against a reverse-complemented reference is reported on
@@ -212,7 +229,7 @@ static void writeSam(ostream& out, const Hit& h) {
   const bool readRev = h.origin[1].rev != flip;
   const unsigned pos = flip ? h.origin[0].end - (unsigned)h.columns() + 1 : h.origin[0].start;
   out << h.origin[1].name << '\t' << (readRev ? 16 : 0) << '\t' << h.origin[0].name << '\t' << pos << "\t0\t"
-      << h.cigar(flip) << "\t*\t0\t0\t*\t*\tAS:i:" << ((int)round(h.score)) << endl;
+      << h.cigar(flip) << "\t*\t0\t0\t*\t*\tAS:i:" << ((int)round(h.score)) << '\n';
 }
 
 struct Printer {  // QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600
@@ -403,6 +420,24 @@ static void onDevices(size_t n, F&& fn) {
   for (const auto& e : err) if (e.size()) Fail(e);
 }
 
+// QUAFF_HIP_TIMING=1: one JSON line on stderr when a command ends -- wall seconds of its phases (tools/cli_bench.py reads it).
+struct PhaseClock {
+  std::map<string, double> sec;
+  std::mutex mu;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void add(const string& k, double dt) { std::lock_guard<std::mutex> lk(mu); sec[k] += dt; }
+  template <class F> void time(const string& k, F&& f) { const double a = now(); f(); add(k, now() - a); }
+  void report(const char* cmd) {
+    if (!getenv("QUAFF_HIP_TIMING")) return;
+    std::ostringstream o;
+    o << "{\"quaff_hip_timing\": \"" << cmd << "\", \"wall_s\": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (const auto& kv : sec) o << ", \"" << kv.first << "_s\": " << kv.second;
+    o << "}";
+    std::cerr << o.str() << std::endl;
+  }
+};
+
 static void packSeqs(const vector<FastSeq>& v, size_t lo, size_t hi, string& seq, string& qual, vector<uint64_t>& off, bool& allQual) {
   seq.clear(); qual.clear(); off.assign(1, 0);
   allQual = true;
@@ -521,39 +556,59 @@ static int cmdAlign(Opts& o) {
          [&] { if (!o.av.empty() && o.av[0] == "-noquals") { o.noquals = true; o.av.pop_front(); return true; } return false; }() ||
          o.parseUnknown()) {}
   o.finishConfig();
+  PhaseClock clk;
   SeqSet reads, refs;
-  reads.load(o.readFiles, "read", "-read", !o.noquals, false, true);
-  refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, true);
+  clk.time("parse", [&] {
+    reads.load(o.readFiles, "read", "-read", !o.noquals, false, true);
+    refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, true);
+  });
   Session s(o);
   s.loadParams(o);
-  s.loadNull(o, reads.seqs);
+  clk.time("null_model", [&] { s.loadNull(o, reads.seqs); });
   s.setRefs(refs.seqs);
   s.setThreshold(pr.threshold);
   pr.header(cout, refs.seqs, false);
-  // contiguous blocks of reads, one per device at a time; printed in read order whatever the device count
+  // contiguous blocks of reads, one per device at a time; printed in read order whatever the device count.  A round's
+  // alignments are written by a thread of their own while the next round is on the devices (the reference's printer is one
+  // mutex-guarded stream too, src/qmodel.cpp:2570-2600, fed by its worker threads).
   const size_t G = s.devices(), n = reads.seqs.size();
   const size_t perCall = max<size_t>(1, ((size_t)1 << 28) / max<size_t>(1, refs.seqs.size()));   // the library takes 2^28 pairs per call
-  const size_t batch = max<size_t>(1, min<size_t>({(size_t)65536, perCall, (n + G - 1) / G}));
+  const size_t batch = max<size_t>(1, min<size_t>({(size_t)(n > 4 * 65536 * G ? 65536 : 16384), perCall, (n + G - 1) / G}));
+  std::future<void> writer;
   for (size_t lo0 = 0; lo0 < n; lo0 += batch * G) {
     const size_t nrun = min(G, (n - lo0 + batch - 1) / batch);
-    vector<vector<Hit>> got(nrun);
+    auto got = std::make_shared<vector<vector<Hit>>>(nrun);
     onDevices(nrun, [&](size_t k) {
       const size_t lo = lo0 + k * batch, hi = min(n, lo + batch);
       qf_ctx* c = s.ctxs[k];
       string seq, qual;
       vector<uint64_t> off;
       bool allQual;
+      double t = PhaseClock::now();
       packSeqs(reads.seqs, lo, hi, seq, qual, off, allQual);
+      if (!k) clk.add("pack", PhaseClock::now() - t);
       qf_align_result res;
+      t = PhaseClock::now();
       QFT(c, qf_align_batch(c, &o.cfg, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)(hi - lo),
                             printAll ? QF_ALIGN_ALL : QF_ALIGN_BEST, &res));
+      if (!k) { clk.add("device_call", PhaseClock::now() - t); clk.add("device_ms_reported", res.ms_total * 1e-3); }
+      t = PhaseClock::now();
       for (uint32_t a = 0; a < res.n_alignments; ++a) {
         const qf_alignment& al = res.alignments[a];
-        got[k].push_back(makeAlignment(refs.seqs[al.ref], reads.seqs[lo + al.read], al, res.cigar_runs + al.run_offset, o.cfg.local));
+        (*got)[k].push_back(makeAlignment(refs.seqs[al.ref], reads.seqs[lo + al.read], al, res.cigar_runs + al.run_offset, o.cfg.local));
       }
+      if (!k) clk.add("collect", PhaseClock::now() - t);
     });
-    for (const auto& block : got) for (const Hit& h : block) pr.write(cout, h);
+    if (writer.valid()) writer.get();
+    writer = std::async(std::launch::async, [&pr, &clk, got] {
+      const double t = PhaseClock::now();
+      for (const auto& block : *got) for (const Hit& h : block) pr.write(cout, h);
+      clk.add("write", PhaseClock::now() - t);
+    });
   }
+  if (writer.valid()) writer.get();
+  cout.flush();
+  clk.report("align");
   return EXIT_SUCCESS;
 }
 
@@ -782,23 +837,26 @@ static int cmdOverlap(Opts& o) {
          [&] { if (!o.av.empty() && o.av[0] == "-noquals") { o.noquals = true; o.av.pop_front(); return true; } return false; }() ||
          o.parseUnknown()) {}
   o.finishConfig();
+  PhaseClock clk;
   SeqSet reads;
-  reads.load(o.readFiles, "read", "-read", !o.noquals, !o.fwdstrand, true);
+  clk.time("parse", [&] { reads.load(o.readFiles, "read", "-read", !o.noquals, !o.fwdstrand, true); });
   Session s(o);
   s.loadParams(o);
-  s.loadNull(o, reads.seqs);
+  clk.time("null_model", [&] { s.loadNull(o, reads.seqs); });
   s.setThreshold(pr.threshold);
   pr.header(cout, reads.seqs, true);
   string seq, qual;
   vector<uint64_t> off;
   bool allQual;
-  packSeqs(reads.seqs, 0, reads.seqs.size(), seq, qual, off, allQual);
-  for (qf_ctx* c : s.ctxs) QF(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
+  clk.time("pack", [&] { packSeqs(reads.seqs, 0, reads.seqs.size(), seq, qual, off, allQual); });
+  clk.time("upload", [&] {
+    for (qf_ctx* c : s.ctxs) QF(c, qf_upload_reads(c, seq.data(), allQual ? qual.data() : nullptr, off.data(), (uint32_t)reads.seqs.size()));
+  });
   // QuaffOverlapScheduler's enumeration (src/qoverlap.cpp:475-480,528-547: nx = 0 ... nOriginals - 2, ny = nx + 1 ... over the
   // originals and then their reverse complements) happens on the device: qf_overlap_rows takes a block of rows, generates its
   // (nx, ny, yComplemented) triples, applies the printer's threshold and returns the alignments that pass, in the
   // scheduler's order.  Every device holds all reads; consecutive row blocks go to the devices in turn and are printed in
-  // block order.
+  // block order, by a thread of their own while the next blocks are on the devices.
   const size_t N = reads.nOriginals, total = reads.seqs.size(), G = s.devices();
   size_t chunk = (size_t)1 << 26;   // pairs per device call (the library cuts a call into blocks that fit its tables)
   if (const char* e = getenv("QUAFF_HIP_OVERLAP_CHUNK")) chunk = max<size_t>(1, (size_t)atol(e));   // tests: many small blocks
@@ -808,13 +866,17 @@ static int cmdOverlap(Opts& o) {
     acc += total - 1 - nx;
     if (acc >= chunk || nx + 2 == N) { blocks.push_back({(uint32_t)b0, (uint32_t)(nx + 1)}); b0 = nx + 1; acc = 0; }
   }
+  std::future<void> writer;
   for (size_t r0 = 0; r0 < blocks.size(); r0 += G) {
     const size_t nrun = min(G, blocks.size() - r0);
-    vector<vector<Hit>> got(nrun);
+    auto got = std::make_shared<vector<vector<Hit>>>(nrun);
     onDevices(nrun, [&](size_t k) {
       qf_ctx* c = s.ctxs[k];
       qf_overlap_rows_result res;
+      double t = PhaseClock::now();
       QFT(c, qf_overlap_rows(c, &o.cfg, (uint32_t)N, blocks[r0 + k].x0, blocks[r0 + k].x1, &res));
+      if (!k) { clk.add("device_call", PhaseClock::now() - t); clk.add("device_ms_reported", res.ms_total * 1e-3); }
+      t = PhaseClock::now();
       for (uint32_t a = 0; a < res.n_hits; ++a) {
         const qf_overlap_hit& h = res.hits[a];
         qf_overlap_alignment al;
@@ -822,11 +884,20 @@ static int cmdOverlap(Opts& o) {
         al.viterbi = h.viterbi; al.score = h.score;
         al.x_start = h.x_start; al.x_end = h.x_end; al.y_start = h.y_start; al.y_end = h.y_end;
         al.n_columns = h.n_columns; al.n_runs = h.n_runs; al.run_offset = h.run_offset;
-        got[k].push_back(makeOverlapAlignment(reads.seqs[h.x], reads.seqs[h.y], al, res.state_runs + h.run_offset));
+        (*got)[k].push_back(makeOverlapAlignment(reads.seqs[h.x], reads.seqs[h.y], al, res.state_runs + h.run_offset));
       }
+      if (!k) clk.add("collect", PhaseClock::now() - t);
     });
-    for (const auto& block : got) for (const Hit& h : block) pr.write(cout, h);
+    if (writer.valid()) writer.get();
+    writer = std::async(std::launch::async, [&pr, &clk, got] {
+      const double t = PhaseClock::now();
+      for (const auto& block : *got) for (const Hit& h : block) pr.write(cout, h);
+      clk.add("write", PhaseClock::now() - t);
+    });
   }
+  if (writer.valid()) writer.get();
+  cout.flush();
+  clk.report("overlap");
   return EXIT_SUCCESS;
 }
 

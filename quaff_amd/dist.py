@@ -105,6 +105,33 @@ def attach_rccl(ctx):
     return True
 
 
+def rccl_report(ctx, single_device=False):
+    """What the ranks of this job really were: every rank's (host, PCI bus id of its context's device) gathered over the process
+    group, and -- under the nccl backend -- a library communicator (qf_comm_init_rank) brought up on the context and exercised with
+    one all-reduce of a 1 per rank, so that the printed rank count is RCCL's own.  Returns a dict on every rank; raises on rank 0 if
+    the ranks do not sit on `world` distinct devices (unless single_device: the one-GPU rehearsal)."""
+    import socket
+    import torch.distributed as dist
+    rank, world, _ = env_rank()
+    me = (socket.gethostname(), ctx.device_bus_id())
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ranks": 1, "distinct_devices": 1, "backend": None, "devices": ["%s/%s" % me]}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, me)
+    rep = {"ranks": dist.get_world_size(), "distinct_devices": len(set(everyone)), "backend": dist.get_backend(),
+           "devices": sorted("%s/%s" % d for d in set(everyone))}
+    if dist.get_backend() == "nccl":
+        if ctx.comm_size() <= 1 and world > 1:
+            attach_rccl(ctx)
+        if ctx.comm_size() > 0:
+            ones, _ = ctx.allreduce_counts(np.ones(1), 0.0)
+            rep["library_comm_size"] = ctx.comm_size()
+            rep["library_allreduce_of_ones"] = float(ones[0])
+    if rank == 0 and not single_device and rep["distinct_devices"] != rep["ranks"]:
+        raise RuntimeError("%d ranks on %d distinct devices: %s" % (rep["ranks"], rep["distinct_devices"], rep["devices"]))
+    return rep
+
+
 def estep_allreduce(counts, loglike, ctx=None):
     """The train E-step exchange (QuaffCountingScheduler::finalCounts / finalLogLike, src/qmodel.cpp:2416-2422): returns
     (global counts, global log-likelihood).  Through the library's qf_allreduce_counts when the context carries a

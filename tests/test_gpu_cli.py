@@ -121,15 +121,21 @@ def _layout(text):
     return re.sub(r"-?\d+\.?\d*(?:e[-+]?\d+)?", "#", text).split()
 
 
-@pytest.mark.parametrize("order", [0, 1])
-def test_train_files_and_stopping_iteration_match_the_oracles_em_loop(tmp_path, order):
+@pytest.mark.parametrize("flags", [("-order", 0), ("-order", 1), ("-order", 2), ("-suborder", 2, "-gaporder", 0), ("-suborder", 0, "-gaporder", 2)],
+                         ids=["order0", "order1", "order2", "sub2gap0", "sub0gap2"])
+def test_train_files_and_stopping_iteration_match_the_oracles_em_loop(tmp_path, flags):
     """SURVEY 8(f) #2 end to end: `quaff train -maxiter 3 -saveprior -savecounts -savecountswithprior -saveparams` on 40 reads
     against the oracle's own EM loop (QuaffTrainer::fitUnlimited, src/qmodel.cpp:2186-2231) driving the oracle's own E-step:
     the auto-prior (initCounts(9, 9, 5, 1, null), incl. the `i == j` quirk for -order 1) byte for byte; the last E-step's
     counts and counts + prior at 1e-4 relative; the fitted parameters (6 s.f. text; q, r come out of a Newton iteration that
     stops at a relative 1e-4 step); log-likelihood and log-prior of every iteration; and `-mininc` stops both at the same
-    iteration."""
-    rng = np.random.default_rng(57 + order)
+    iteration.  -order k = match contexts of k + 1 bases, gap contexts of k (t/quaff.cpp:441-450: config 4 trains at -order 2, 64
+    match prefixes and 24 508 counts); -suborder / -gaporder set them separately (:452-468), so that the emission and the
+    transition tables have different context lengths."""
+    opt = dict(zip(flags[::2], flags[1::2]))
+    order = opt.get("-order", 0)
+    ml, gl = 1 + opt.get("-suborder", order), opt.get("-gaporder", order)
+    rng = np.random.default_rng(57 + 10 * ml + gl)
     ref = rand_seq(rng, 3000)
     reads = make_reads(rng, ref, 40, 250)
     fa, fq = tmp_path / "ref.fa", tmp_path / "reads.fq"
@@ -137,14 +143,13 @@ def test_train_files_and_stopping_iteration_match_the_oracles_em_loop(tmp_path, 
     fq.write_text("".join("@%s\n%s\n+\n%s\n" % (r.name, r.seq, r.qual) for r in reads))
     null_path = os.path.join(GOLDEN, "testquaffnullparams.json")
     null = O.NullParams.from_json(open(null_path).read())
-    ml, gl = 1 + order, order
     x = O.FastSeq("ref", ref)
     refs = [x, x.revcomp()]
     prior = O.init_counts(ml, gl, 9, 9, 5, 1, null)
     seed = O.m_step(prior, ml, gl)                          # requireParamsOrUsePrior, t/quaff.cpp:370-376
     cfg = O.DPConfig()
     files = {k: tmp_path / (k + ".json") for k in ("prior", "counts", "withprior", "params")}
-    extra = ["-order", str(order)] if order else []
+    extra = [str(f) for f in flags] if (ml, gl) != (1, 0) else []
     out = subprocess.run([QUAFF, "train", str(fa), str(fq), "-null", null_path, "-maxiter", "3", "-mininc", "0", "-saveprior", str(files["prior"]),
                           "-savecounts", str(files["counts"]), "-savecountswithprior", str(files["withprior"]),
                           "-saveparams", str(files["params"])] + extra, capture_output=True, text=True, timeout=600)

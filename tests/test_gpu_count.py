@@ -33,13 +33,16 @@ def oracle_estep(refs, reads, sc, null, cfg, orders=None, use_null=True):
     tot = np.zeros(O.counts_size(sc.Km, sc.Kg))
     ylogs, new_orders, fwd = [], [], []
     for r, read in enumerate(reads):
-        c, yl, no = O.count_read(refs, read, sc, null, cfg, None if orders is None else orders[r], use_null, skip_pathless=not use_null)
+        d = {}
+        c, yl, no = O.count_read(refs, read, sc, null, cfg, None if orders is None else orders[r], use_null, skip_pathless=not use_null, details=d)
+        fwd.append(d)
         if np.isfinite(yl):
             tot += c
         else:
             assert not use_null
         ylogs.append(yl)
         new_orders.append(no)
+    oracle_estep.details = fwd      # per read: the oracle's per-reference Forward values and which references it gave a Backward pass
     return tot, np.array(ylogs), new_orders
 
 
@@ -65,6 +68,18 @@ def run_case(ctx, refs, reads, sc, null, cfg_kw=None, orders=None, force=False):
     want, ylogs, new_orders = oracle_estep(refs, reads, sc, null, ocfg, orders, use_null=not force)
     fin = np.isfinite(ylogs)
     assert np.array_equal(np.isfinite(res["read_loglike"]), fin)
+    # WHICH pairs carry no weight is pinned, not only the totals: a pair is pathless here exactly where the oracle finds no path,
+    # and has posterior weight exactly where the oracle ran a Backward pass over it (and the read has a likelihood at all)
+    for r, d in enumerate(oracle_estep.details):
+        order = list(range(len(refs))) if orders is None else list(orders[r])
+        pathless = np.array([d["forward"][x] == -np.inf for x in range(len(refs))])
+        seen = np.zeros(len(refs), bool)
+        seen[order] = True
+        assert np.array_equal(np.isneginf(res["forward"][r])[seen], pathless[seen]), (r, res["forward"][r], d["forward"])
+        weighted = set(int(x) for x in np.flatnonzero(res["weight"][r] > 0))
+        counted = set(d["counted"]) if fin[r] else set()
+        must = set(x for x in counted if np.exp(d["forward"][x] - ylogs[r]) > 1e-290)   # (a weight may underflow to 0 on either side)
+        assert must <= weighted <= counted, (r, weighted, d["counted"])
     np.testing.assert_allclose(res["read_loglike"][fin], ylogs[fin], rtol=RTOL)
     assert res["loglike"] == ylogs.sum() or abs(res["loglike"] - ylogs.sum()) <= RTOL * abs(ylogs.sum())
     assert_counts_close(res["counts"], want, "counts")

@@ -179,3 +179,55 @@ def test_missing_peer_returns_a_status_instead_of_hanging(tmp_path):
         assert p.returncode == 3, (rank, p.returncode, out[-500:], err[-1500:])
         status = [l for l in out.splitlines() if l.startswith("STATUS")][0].split(None, 3)
         assert int(status[1]) == -1 and 3.0 <= float(status[2]) < 60.0 and "waiting for the other ranks" in status[3]
+
+
+SKIPPER = textwrap.dedent("""
+    import sys, time
+    sys.path.insert(0, %r)
+    import numpy as np
+    import quaff_amd as Q
+    from quaff_amd.api import QuaffHipError
+    rank, uid_hex = int(sys.argv[1]), sys.argv[2]
+    ctx = Q.Context(rank)                        # one rank per GPU
+    ctx.set_params_json(None)
+    if uid_hex == "-":
+        print("UID", Q.Context.comm_unique_id().hex()); sys.stdout.flush()
+        uid_hex = sys.stdin.readline().strip()
+    ctx.comm_init_rank(bytes.fromhex(uid_hex), rank, 2)
+    print("JOINED"); sys.stdout.flush()
+    if rank == 1:
+        time.sleep(20)                           # never enters the collective
+        sys.exit(0)
+    t0 = time.time()
+    try:
+        ctx.allreduce_counts_exact(np.zeros((8, 2), np.uint64))
+    except QuaffHipError as e:
+        print("STATUS", e.code, "%%.1f" %% (time.time() - t0), str(e))
+        sys.exit(3)
+    print("REDUCED")
+""") % ROOT
+
+
+def test_all_reduce_with_a_peer_that_skips_it_returns_a_status(tmp_path):
+    """The all-reduce deadline (qf_allreduce_counts_exact, src/qmodel.cpp:2416-2422): two ranks form a communicator, rank 1 never
+    enters the collective; rank 0 must come back with QF_ERR_DEVICE after QUAFF_HIP_COMM_TIMEOUT, with nothing of its own still in
+    flight (the staging buffer belongs to the context).  Needs two devices: on the one-GPU boxes of this pool it is skipped."""
+    from quaff_amd import api
+    if api.load_library().qf_device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL takes one rank per device)")
+    script = tmp_path / "skipper.py"
+    script.write_text(SKIPPER)
+    env = dict(os.environ, QUAFF_HIP_COMM_TIMEOUT="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p0 = subprocess.Popen([sys.executable, str(script), "0", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    uid = p0.stdout.readline().split()[1]
+    p1 = subprocess.Popen([sys.executable, str(script), "1", uid], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    p0.stdin.write(uid + "\n"); p0.stdin.flush()
+    try:
+        out, err = p0.communicate(timeout=120)
+    except subprocess.TimeoutExpired:
+        p0.kill(); p1.kill()
+        pytest.fail("rank 0 was still inside the all-reduce after 120 s")
+    p1.communicate(timeout=60)
+    assert p0.returncode == 3, (p0.returncode, out[-500:], err[-1500:])
+    status = [l for l in out.splitlines() if l.startswith("STATUS")][0].split(None, 3)
+    assert int(status[1]) == -1 and 3.0 <= float(status[2]) < 60.0 and "did not complete" in status[3]
