@@ -1474,6 +1474,7 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
         s.read_off = d_roff;
         s.cell_size = 48;
         s.storage_mode = 1;
+        s.fb_use_32x3 = (c->debug & QF_DEBUG_FB32) != 0;
         s.pair_skip = d_skip;
       }, max_units, sa, bc))
     return rc;

@@ -42,7 +42,9 @@ __device__ __forceinline__ double dpp_from_above(double v) {  // lane l+1's valu
 template <int G>
 __device__ __forceinline__ float dpp_f32_from_above(float v) {  // lane l+1's value; 0 in the group's last lane
   constexpr int ctrl = G == 16 ? 0x101 : 0x130;              // row_shl:1 / wave_shl:1
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true));
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true);
+  if (G == 32 && dpp_lane() == 31) r = 0;                    // (the first group's last lane would see the second group's first)
+  return __int_as_float(r);
 }
 
 }  // namespace qf

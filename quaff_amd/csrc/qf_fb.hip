@@ -18,6 +18,12 @@ namespace qf {
 struct __attribute__((packed, aligned(4))) U32x4f { uint32_t v[4]; };   // 16-byte load from a 4-byte aligned address
 
 #define QF_NEG_INF (-__builtin_huge_val())
+#ifndef QF_FWD32_WAVES
+#define QF_FWD32_WAVES 4    // (32, 3): Forward's three diagonals per lane fit 128 registers
+#endif
+#ifndef QF_BWD32_WAVES
+#define QF_BWD32_WAVES 2    // Backward's do not (208 bytes of scratch at four wavefronts per SIMD, 64 at three)
+#endif
 #ifndef QF_BWD_WAVES
 #define QF_BWD_WAVES 2
 #endif
@@ -125,7 +131,7 @@ __device__ __forceinline__ double lseh(const double* hs, double a, double b) {
 #define QF_FWD_WAVES 3
 #endif
 template <int G, int B, bool GAPCTX, bool EMLDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF_FWD_WAVES : B <= 8 ? 2 : 1))) void k_forward_fill(FbArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? QF_FWD32_WAVES : B <= 5 ? QF_FWD_WAVES : B <= 8 ? 2 : 1))) void k_forward_fill(FbArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_fb[];
   const uint32_t Kg = a.dp.Kg;
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
@@ -495,7 +501,7 @@ __global__ void k_count_plan(CountPlanArgs a) {
 //    step and accumulated in fp64; the pair's posterior weight multiplies at the flush, not per term.
 // ------------------------------------------------------------------------------------------------
 template <int G, int B, bool GAPCTX, bool EMLDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF_BWD_WAVES : 1, B <= 5 ? 8 : 1))) void k_backward_fill(FbArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? QF_BWD32_WAVES : B <= 5 ? QF_BWD_WAVES : 1, B <= 5 ? 8 : 1))) void k_backward_fill(FbArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_fb[];
   const uint32_t Kg = a.dp.Kg, Km = a.Km;
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
@@ -600,14 +606,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
   constexpr int NF = fw_row_floats(B);
   const float4* __restrict__ fwrow = (const float4*)(a.fw + fw_off);
   auto rowptr = [&](int j) -> const float4* { return fwrow + ((uint64_t)(j - 1 + l) * (NF / 4)) * G + l; };
-  const float4 ninf4 = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+  // (component by component: a whole-vector select of the 12-float row of B = 3 went through scratch memory)
+  auto sel4 = [](bool ok, const float4& v) -> float4 {
+    const float ni = -__builtin_huge_valf();
+    return make_float4(ok ? v.x : ni, ok ? v.y : ni, ok ? v.z : ni, ok ? v.w : ni);
+  };
   float4 Fq[NF / 4];
   {
     const int j = yLen + rl;
     const bool ok = active && bmax >= 0 && j <= yLen;
     const float4* src = ok ? rowptr(j) : fwrow;
 #pragma unroll
-    for (int c = 0; c < NF / 4; ++c) { const float4 v = src[(uint64_t)c * G]; Fq[c] = ok ? v : ninf4; }
+    for (int c = 0; c < NF / 4; ++c) { const float4 v = src[(uint64_t)c * G]; Fq[c] = sel4(ok, v); }
   }
   double e[B], insE = eins[0];   // emissions of the destination column j+1: none before the first step (the Backward values there are -inf)
 #pragma unroll
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B <= 5 ? QF
         const int hiK = fw_float_index(B, b, 2), prevHiK = b == B - 1 ? 0 : fw_float_index(B, b + 1, 2);
         const bool freed = 4 * c + 3 <= hiK && 4 * c + 3 > prevHiK;
         const bool tail = b == 0 && 4 * c + 3 > hiK;
-        if (freed || tail) { const float4 v = nsrc[(uint64_t)c * G]; Fq[c] = moreF ? v : ninf4; }
+        if (freed || tail) { const float4 v = nsrc[(uint64_t)c * G]; Fq[c] = sel4(moreF, v); }
       }
     };
     // (i+1, j) for the top slot: lane l+1's slot 0 at column j, finished in the previous step
@@ -1182,6 +1192,7 @@ static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
     case 10: FN<64, 8>(a, s); break;               \
     case 11: FN<64, 12>(a, s); break;              \
     case 12: FN<64, 16>(a, s); break;              \
+    case 14: FN<32, 3>(a, s); break;               \
   }
 void launch_forward_fill(int cls, const FbArgs& a, hipStream_t s) {
   if (!a.n_cls_units) return;

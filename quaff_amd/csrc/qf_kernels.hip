@@ -1178,6 +1178,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_units(SeedArgs a, uint32_t 
       cls = classify_width(dhi - dlo + 1);
       if (a.storage_mode == 2 && cls > 10) cls = kRowClass;    // overlap kernels take up to 8 diagonals per lane
       if (a.storage_mode == 2 && a.ov_use_32x3 && dhi - dlo + 1 > 64 && dhi - dlo + 1 <= 96) cls = kOv32Class;   // (qf_device.hpp)
+      if (a.storage_mode == 1 && dhi - dlo + 1 > (a.fb_use_32x3 ? 64 : 80) && dhi - dlo + 1 <= 96) cls = kOv32Class;   // E-step: (32, 3) instead of (16, 6) [-kmatchband 80: Backward 23.8 -> 20.7 ms per 20 k reads] -- and, as an A/B, of (16, 5) [15.0 -> 20.0]
       // overlap bands of 97 .. 128 diagonals are few (a hundred per thousand x rows) and each is a chain of 2 000 steps: on 64
       // lanes x 3 diagonals a step is three dependent look-ups deep instead of eight on 16 lanes x 8
       if (a.storage_mode == 2 && cls == 6 && !a.ov_wide_on_16x8) cls = 7;

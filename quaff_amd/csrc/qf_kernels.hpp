@@ -102,6 +102,7 @@ struct SeedArgs {
   uint32_t* slot_list;         // optional, ~0u-initialised
   uint32_t slot_x0, slot_rows;
   int ov_use_32x3;             // overlap: bands of 65 .. 96 diagonals go to class kOv32Class (32 lanes x 3) instead of (16, 5) / (16, 6)
+  int fb_use_32x3;             // E-step A/B: also bands of 65 .. 80 diagonals go to class kOv32Class (32 lanes x 3 diagonals), not only 81 .. 96
   int ov_wide_on_16x8;         // A/B: overlap bands of 97 .. 128 diagonals stay on class (16, 8) instead of (64, 3)
   int storage_mode;            // 0: packed traceback words (Viterbi); 1: Forward matrix doubles
   int force_block_kernel;      // use the workgroup-per-pair kernel even in threshold mode (tests run both)
