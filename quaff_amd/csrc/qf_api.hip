@@ -231,7 +231,8 @@ struct qf_ctx : Slot {
   bool row_lds = false, row_e16 = false;
   uint64_t row_max_entries = 0;
   DevBuf d_row_sorted, d_row_pieces;
-  uint32_t row_pieces_n = 0;
+  uint32_t row_pieces_n = 0, row_tri_x0 = 0;
+  bool row_tri = false;          // the pieces are (first row, rows, chunk) of the scheduler's triangle, not pieces of d_row_sorted
   HostBuf<double> h_ov_result, h_ov_score;
   std::vector<uint32_t> h_ov_slot;
   std::vector<qf_overlap_alignment> h_ov_align;
@@ -1870,7 +1871,38 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     const int cl = c->chunk_log2;
     const bool cached = c->row_items_epoch == c->prep_epoch && c->row_items_lo == lo && c->row_items_hi == hi && c->row_items_cl == cl && c->row_items_lds == c->row_lds && c->row_items_rows.size() == c->ov_rows.size() &&
                         !memcmp(c->row_items_rows.data(), c->ov_rows.data(), c->ov_rows.size() * sizeof(qf_ctx::PairRow));
-    if (!cached) {
+    // The scheduler's triangle (whole rows x0, x0 + 1, ..., each x against x + 1 ... n_seqs - 1) with the LDS prefilter: no item
+    // list at all -- a piece is (first row, rows, chunk) and k_seed_rows_lds forms its items itself.
+    bool tri = c->row_lds && !c->ov_rows.empty() && lo == 0;
+    if (tri) {
+      uint64_t p = 0;
+      for (size_t q = 0; q < c->ov_rows.size() && tri; ++q) {
+        const auto& r = c->ov_rows[q];
+        tri = r.x == c->ov_rows[0].x + q && r.y0 == r.x + 1 && r.n == c->n_reads - 1 - r.x && r.p0 == p;
+        p += r.n;
+      }
+      tri = tri && p == hi;
+    }
+    if (tri && !cached) {
+      constexpr uint32_t kPiece = 64;
+      const uint32_t X0 = c->ov_rows[0].x, X1 = X0 + (uint32_t)c->ov_rows.size(), n_chunks = (c->n_reads + (1u << cl) - 1) >> cl;
+      std::vector<uint4> pieces;
+      for (uint32_t ch = (X0 + 1) >> cl; ch < n_chunks; ++ch) {
+        const uint32_t xend = std::min<uint64_t>(X1, (((uint64_t)ch + 1) << cl) - 1);   // rows x with x + 1 < (ch + 1) << cl have pairs in the chunk
+        for (uint32_t x = X0; x < xend; x += kPiece) pieces.push_back(make_uint4(x, std::min(kPiece, xend - x), ch, 0u));
+      }
+      c->row_pieces_n = (uint32_t)pieces.size();
+      c->row_tri = true;
+      c->row_tri_x0 = X0;
+      c->row_items_n = 1;   // (nothing of the plain list is used)
+      if (!pieces.empty()) {
+        HIPCHK(c, c->d_row_pieces.reserve(pieces.size() * sizeof(uint4)));
+        HIPCHK(c, hipMemcpyAsync(c->d_row_pieces.p, pieces.data(), pieces.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // stack-lifetime host buffer
+      }
+      c->row_items_rows = c->ov_rows;
+      c->row_items_lo = lo; c->row_items_hi = hi; c->row_items_cl = cl; c->row_items_lds = c->row_lds; c->row_items_epoch = c->prep_epoch;
+    } else if (!cached) {
       const uint32_t n_chunks = (c->n_reads + (1u << cl) - 1) >> cl;
       std::vector<uint32_t> first(n_chunks + 1, 0);
       auto clip = [&](const qf_ctx::PairRow& r, uint32_t& y, uint32_t& yend, uint32_t& p) {
@@ -1894,20 +1926,21 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       if (c->row_lds) {   // k_seed_rows_lds: the chunk-major list itself, with x's offset and length, in pieces of one chunk each
         constexpr uint32_t kPiece = 64;
         std::vector<RowItemL> sl(sorted.size());
-        std::vector<uint2> pieces;
+        std::vector<uint4> pieces;
         for (size_t q = 0; q < sorted.size(); ++q) {
           const RowItem& r = sorted[q];
           const uint64_t xb = c->read_off[r.x];
           sl[q] = {r.x, r.ylo, r.yhi, r.pbase, (uint32_t)(c->read_off[r.x + 1] - xb), (uint32_t)xb, (uint32_t)(xb >> 32), r.chunk};
-          if (pieces.empty() || sorted[pieces.back().x].chunk != r.chunk || pieces.back().y == kPiece) pieces.push_back(make_uint2((uint32_t)q, 0u));
+          if (pieces.empty() || sorted[pieces.back().x].chunk != r.chunk || pieces.back().y == kPiece) pieces.push_back(make_uint4((uint32_t)q, 0u, 0u, 0u));
           ++pieces.back().y;
         }
         c->row_pieces_n = (uint32_t)pieces.size();
+        c->row_tri = false;
         if (!sl.empty()) {
           HIPCHK(c, c->d_row_sorted.reserve(sl.size() * sizeof(RowItemL)));
-          HIPCHK(c, c->d_row_pieces.reserve(pieces.size() * sizeof(uint2)));
+          HIPCHK(c, c->d_row_pieces.reserve(pieces.size() * sizeof(uint4)));
           HIPCHK(c, hipMemcpyAsync(c->d_row_sorted.p, sl.data(), sl.size() * sizeof(RowItemL), hipMemcpyHostToDevice, c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->d_row_pieces.p, pieces.data(), pieces.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->d_row_pieces.p, pieces.data(), pieces.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));   // stack-lifetime host buffers
         }
       }
@@ -1971,8 +2004,9 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
           s.chunk_estride = c->chunk_estride;
           s.row_skip = c->d_row_skip.as<uint8_t>();
           if (c->row_lds && c->row_pieces_n) {
-            s.row_sorted = c->d_row_sorted.p;
-            s.row_pieces = c->d_row_pieces.as<uint2>();
+            s.row_sorted = c->row_tri ? nullptr : c->d_row_sorted.p;
+            s.tri_x0 = c->row_tri_x0;
+            s.row_pieces4 = c->d_row_pieces.as<uint4>();
             s.n_row_pieces = c->row_pieces_n;
             s.row_n_seqs = c->n_reads;
             s.row_max_entries = c->row_max_entries;

@@ -948,10 +948,30 @@ template <int CB, typename ET>
 __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows_lds(SeedArgs a, uint32_t stride) {
   extern __shared__ uint32_t cnt[];   // [2^cl][stride] counters | dummy zone | bucket starts [nbuckets + 1] | sequence lengths [2^cl] | entries
   static_assert(CB >= 2, "an entry carries its position in units of 2^(CB-2) diagonals");
-  const uint2 piece = a.row_pieces[blockIdx.x];
-  const RowItemL* __restrict__ items = (const RowItemL*)a.row_sorted + piece.x;
+  // a piece: up to kSeedRowPiece consecutive x rows against one chunk.  Either items of the chunk-major list (row_sorted), or --
+  // the scheduler's triangle (row x = pairs (x, x + 1 ... n_seqs - 1), src/qoverlap.cpp:475-480), where the items are a function
+  // of (x, chunk) -- just (chunk, first row, rows) and the items are formed here (a 2^24-pair block has a million of them: built and
+  // uploaded by the host they cost more than this kernel)
+  const uint4 pd = a.row_pieces4[blockIdx.x];
+  const bool tri = a.row_sorted == nullptr;
+  const RowItemL* __restrict__ items = tri ? nullptr : (const RowItemL*)a.row_sorted + pd.x;
+  const uint32_t n_items = pd.y;
   const int cl = a.chunk_log2, k = a.kmer_len;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, csize = 1u << cl, nb1 = a.nbuckets + 1, chunk = items[0].chunk, y0 = chunk << cl;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, csize = 1u << cl, nb1 = a.nbuckets + 1, chunk = tri ? pd.z : items[0].chunk, y0 = chunk << cl;
+  auto item_at = [&](uint32_t q) -> RowItemL {
+    if (!tri) return items[q];
+    const uint32_t x = pd.x + q, r = x - a.tri_x0;
+    const uint64_t xb = a.read_off[x];
+    RowItemL it;
+    it.x = x;
+    it.ylo = max(x + 1, y0);
+    it.yhi = min(a.row_n_seqs, y0 + csize);
+    it.pbase = (uint32_t)((uint64_t)r * (a.row_n_seqs - 1 - a.tri_x0) - (uint64_t)r * (r - 1) / 2) + (it.ylo - (x + 1));
+    it.xlen = (uint32_t)(a.read_off[x + 1] - xb);
+    it.xb_lo = (uint32_t)xb; it.xb_hi = (uint32_t)(xb >> 32);
+    it.chunk = chunk;
+    return it;
+  };
   uint32_t* st = cnt + csize * stride + seed_rows_dummy_bytes(a.max_read_len, CB) / 4;
   uint32_t* ylen = st + nb1;
   ET* ents = (ET*)(ylen + csize);
@@ -1009,11 +1029,11 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows_lds(SeedArgs a, u
       }
     }
   };
-  RowItemL cur = items[0], prev = cur;
+  RowItemL cur = item_at(0), prev = cur;
   uint32_t kmc[R];
   load_km(cur, kmc);
-  for (uint32_t itn = 0; itn < piece.y; ++itn) {
-    const RowItemL nxt = items[min(itn + 1, piece.y - 1)];
+  for (uint32_t itn = 0; itn < n_items; ++itn) {
+    const RowItemL nxt = item_at(min(itn + 1, n_items - 1));
     uint32_t kmn[R];
     load_km(nxt, kmn);
     const int xLen = (int)cur.xlen, nkx = xLen - k + 1;
@@ -1108,7 +1128,7 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows_lds(SeedArgs a, u
 #pragma unroll
     for (int r = 0; r < R; ++r) kmc[r] = kmn[r];
   }
-  settle(prev, (piece.y - 1) & 1u);
+  settle(prev, (n_items - 1) & 1u);
 }
 
 __global__ void k_chunk_kmer_count(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k, uint32_t nbuckets,
@@ -2377,7 +2397,7 @@ void with_seed_variant(bool wide, int cb, F&& f) {   // f(std::bool_constant<WID
 int launch_seed(const SeedArgs& a_in, uint32_t n_pairs, bool mem, hipStream_t s) {
   if (!n_pairs) return 0;
   SeedArgs a = a_in;
-  if (a.row_pieces && a.n_row_pieces && !mem) {   // the same with the chunk's index in LDS, one workgroup per chunk and piece of x rows
+  if (a.row_pieces4 && a.n_row_pieces && !mem) {   // the same with the chunk's index in LDS, one workgroup per chunk and piece of x rows
     const size_t stride = seed_rows_lds_stride_bytes(a);
     const size_t lds = seed_rows_lds_bytes(a, stride, a.chunk_log2, a.row_max_entries, a.row_e16 != 0);
     if (stride && lds <= kSeedRowLdsBig) {

@@ -92,9 +92,9 @@ struct SeedArgs {
   uint8_t* row_skip;           // [n_pairs], zero-initialised: set for the pairs the prefilter settled
   // the prefilter with the chunk's index in LDS (k_seed_rows_lds): the items chunk-major with x's offset / length (RowItemL),
   // cut into pieces (first item, count) of one chunk each; LDS sizing: most k-mer positions of a chunk, 16-bit entries or not
-  const void* row_sorted;
-  const uint2* row_pieces;
-  uint32_t n_row_pieces, row_n_seqs;
+  const void* row_sorted;      // null: the scheduler's triangle, pieces = (first row, rows, chunk, -) and the items are formed on the device
+  const uint4* row_pieces4;    // (first item, items, -, -) of row_sorted, or (first row, rows, chunk, -)
+  uint32_t n_row_pieces, row_n_seqs, tri_x0;
   uint64_t row_max_entries;
   int row_e16;
   // slotted single-diagonal list (overlap, x-major lists with consecutive x): unit of pair (x, y) at

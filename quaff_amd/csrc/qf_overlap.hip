@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF_SR_WAVES
   const uint64_t xb = a.seq_off[x];
   const int xLen = (int)(a.seq_off[x + 1] - xb);
   uint32_t uid[2], comp[2] = {0, 0}, yblocks[2] = {1, 1};
-  int n[2] = {0, 0}, yLen[2] = {0, 0};
+  int yLen[2] = {0, 0};
   const uint4* yp[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -676,7 +676,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF_SR_WAVES
       const uint32_t pair = a.units[uid[k]].pair, y = a.pair_y[pair];   // y = ch * 256 + tid: lane == y % 64
       comp[k] = a.pair_comp[pair] ? 1u : 0u;
       yLen[k] = (int)(a.seq_off[y + 1] - a.seq_off[y]);
-      n[k] = min(xLen, yLen[k]);
       const uint64_t g0 = a.ygoff[y >> 6];
       yblocks[k] = (uint32_t)((a.ygoff[(y >> 6) + 1] - g0) >> 6);
       yp[k] = a.ycolT[comp[k]] + g0 + lane;
@@ -687,7 +686,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF_SR_WAVES
   for (uint32_t cp = 0; cp < 2; ++cp) {                              // the strand flag selects the table: one pass per flag present
     int nn[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) nn[k] = (uid[k] != kNoUnit && comp[k] == cp) ? n[k] : 0;
+    for (int k = 0; k < 2; ++k) nn[k] = (uid[k] != kNoUnit && comp[k] == cp) ? min(xLen, yLen[k]) : 0;   // cells of the band (diagonal 0)
     int gEnd[2] = {(nn[0] - 1) >> 3, (nn[1] - 1) >> 3};              // block of the band's last cell (-1: no band in this pass)
     int T = max(nn[0], nn[1]), gFirst = min(gEnd[0] < 0 ? 0x7FFFFFFF : gEnd[0], gEnd[1] < 0 ? 0x7FFFFFFF : gEnd[1]);
 #pragma unroll
@@ -746,35 +745,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF_SR_WAVES
 #pragma unroll
         for (int c = 0; c < kRowsSub; ++c) ad[k][c] = (c & 1) ? wd[c >> 1] >> 16 : wd[c >> 1] & 0xFFFFu;
       }
-      double e[2][kRowsSub];
+      const bool general = g == 0 || (g >= gFirst && __any(gEnd[0] == g || gEnd[1] == g));
+      // the block's sixteen emissions in two halves of eight (all sixteen at once cost the registers of a fourth wavefront per SIMD)
+      constexpr int H = kRowsSub / 2;
+      double e[2][H];
+      auto fetch = [&](int h) {
 #pragma unroll
-      for (int c = 0; c < kRowsSub; ++c)
+        for (int c = 0; c < H; ++c)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) e[k][c] = *(const double*)(s_crow + BUF * kBufBytes + c * (P * 8u) + ad[k][c]);
+          for (int k = 0; k < 2; ++k) e[k][c] = *(const double*)(s_crow + BUF * kBufBytes + (h * H + c) * (P * 8u) + ad[k][h * H + c]);
+      };
+      auto chain = [&](int h) {
+        if (!general) {
+#pragma unroll
+          for (int c = 0; c < H; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) M[k] = (M[k] + g0) + e[k][c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < H; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              double m = (M[k] + g0) + e[k][c];
+              if (g == 0 && h == 0 && c == 0) {                     // the diagonal's first cell: Start -> Match beats -inf + ... (src/qoverlap.cpp:141)
+                m = e[k][c];
+                flag[k] = e[k][c] > QF_NEG_INF ? 3u : 0u;
+              }
+              M[k] = m;
+              if (kRowsSub * g + h * H + c + 1 == nn[k]) res[k] = m;   // the band's last cell, its only end cell
+            }
+        }
+      };
+      fetch(0);
       if (g + 1 < nBlocks) stage(roNext, BUF ^ 1u);
       roNext = row_offsets(g + 2);
 #pragma unroll
       for (int k = 0; k < 2; ++k) yr[BUF][k] = yp[k][(size_t)min((uint32_t)g + 2, yblocks[k] - 1) * 64];
-      const bool general = g == 0 || (g >= gFirst && __any(gEnd[0] == g || gEnd[1] == g));
-      if (!general) {
-#pragma unroll
-        for (int c = 0; c < kRowsSub; ++c)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) M[k] = (M[k] + g0) + e[k][c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < kRowsSub; ++c)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            double m = (M[k] + g0) + e[k][c];
-            if (g == 0 && c == 0) {                                 // the diagonal's first cell: Start -> Match beats -inf + ... (src/qoverlap.cpp:141)
-              m = e[k][c];
-              flag[k] = e[k][c] > QF_NEG_INF ? 3u : 0u;
-            }
-            M[k] = m;
-            if (kRowsSub * g + c + 1 == nn[k]) res[k] = m;          // the band's last cell, its only end cell
-          }
-      }
+      chain(0);
+      fetch(1);
+      chain(1);
     };
     for (int g = 0; g < nBlocks; g += 2) {
       block(std::integral_constant<uint32_t, 0>(), g);

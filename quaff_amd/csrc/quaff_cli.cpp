@@ -262,9 +262,29 @@ struct Printer {  // QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600
       for (const auto& s : refs) if (s.source.isNull()) o << "@SQ\tSN:" << s.name << "\tLN:" << s.seq.size() << endl;
     }
   }
-  void write(ostream& out, const Hit& h) {  // writeAlignment :2566-2600
-    if (!(h.score >= threshold)) return;
+  // A batch of alignments: the records are composed by a few threads side by side (1.9 GB of Stockholm text for the overlaps of
+  // 5 000 reads is the command's longest phase) and written in order.
+  void writeAll(ostream& out, const vector<vector<Hit>>& blocks) {
+    vector<const Hit*> all;
+    for (const auto& b : blocks) for (const Hit& h : b) all.push_back(&h);
+    const size_t T = std::min<size_t>(8, std::max<size_t>(1, all.size() / 64));
+    vector<string> text(T);
+    vector<std::thread> th;
+    auto work = [&](size_t k) {
+      std::ostringstream os;
+      const size_t lo = all.size() * k / T, hi = all.size() * (k + 1) / T;
+      for (size_t a = lo; a < hi; ++a) emit(os, *all[a]);
+      text[k] = os.str();
+    };
+    for (size_t k = 1; k < T; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& t : th) t.join();
     ostream& o = stream(out);
+    for (const string& t : text) o.write(t.data(), (std::streamsize)t.size());
+  }
+  void write(ostream& out, const Hit& h) { emit(stream(out), h); }
+  void emit(ostream& o, const Hit& h) {  // writeAlignment :2566-2600
+    if (!(h.score >= threshold)) return;
     auto fasta = [&](const string& name, const string& comment, const string& text) {
       o << '>' << name;
       if (comment.size()) o << ' ' << comment;
@@ -273,7 +293,7 @@ struct Printer {  // QuaffAlignmentPrinter, src/qmodel.cpp:2480-2600
     switch (format) {
       case Fasta:
         for (int k = 0; k < 2; ++k) fasta(h.label[k], h.note[k], h.laidOut(k, false, '-'));
-        out << endl;
+        o << endl;
         break;
       case Stockholm: writeStockholm(o, h); break;
       case Sam: writeSam(o, h); break;
@@ -602,7 +622,7 @@ static int cmdAlign(Opts& o) {
     if (writer.valid()) writer.get();
     writer = std::async(std::launch::async, [&pr, &clk, got] {
       const double t = PhaseClock::now();
-      for (const auto& block : *got) for (const Hit& h : block) pr.write(cout, h);
+      pr.writeAll(cout, *got);
       clk.add("write", PhaseClock::now() - t);
     });
   }
@@ -891,7 +911,7 @@ static int cmdOverlap(Opts& o) {
     if (writer.valid()) writer.get();
     writer = std::async(std::launch::async, [&pr, &clk, got] {
       const double t = PhaseClock::now();
-      for (const auto& block : *got) for (const Hit& h : block) pr.write(cout, h);
+      pr.writeAll(cout, *got);
       clk.add("write", PhaseClock::now() - t);
     });
   }
