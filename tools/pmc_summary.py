@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 passes of one workload (tools/profile.sh) into profiles/r<NN>_pmc_<workload>.json (replayed, labelled, by
 bench.py as `roofline.traffic` / `roofline.replayed_counters` while `source_hash` still matches the device code) and
-profiles/r<NN>_<workload>_kernel_stats.csv.  ROUND=r03 (default) names the files.
+profiles/r<NN>_<workload>_kernel_stats.csv.  ROUND=r04 (default) names the files.
 
 Passes (separate runs, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC passes carry
 --kernel-trace only), each `rocprofv3 ... --output-format csv -d <dir> -- python3 bench.py --workload W --steps 2 --warmup 1 --cpu-sample 0`:
@@ -100,7 +100,7 @@ def main():
     sys.path.insert(0, root)
     from quaff_amd import api
     import subprocess
-    rnd = os.environ.get("ROUND", "r03")
+    rnd = os.environ.get("ROUND", "r04")
     try:
         head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:

@@ -6,7 +6,7 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-export ROUND=${ROUND:-r03}
+export ROUND=${ROUND:-r04}
 summ() {  # workload: kernel=cells pairs from the stats pass's bench line, then the summary
   python3 - "$1" <<'PY' > gpurun_out/prof_$1/cells.txt
 import json, sys
@@ -31,14 +31,21 @@ PY
   python3 tools/pmc_summary.py gpurun_out/prof_$1 $1 $(cat gpurun_out/prof_$1/cells.txt) > gpurun_out/prof_$1/summary.txt
   cp gpurun_out/prof_$1/bench_line.json profiles/${ROUND}_$1_profiled_bench.json
 }
+# (a gpurun call is at most 20 minutes: `bash tools/profile_all.sh a` = align + train, `... b` = overlap + fulldp, no argument = both)
+PART=${1:-ab}
+if [[ $PART == *a* ]]; then
 bash tools/profile.sh align && summ align
 bash tools/profile.sh train && summ train
-bash tools/profile.sh overlap --overlap-rows 680 --inflight 1 --serial-classes && summ overlap
-bash tools/profile.sh fulldp --reads 512 && summ fulldp
-echo "profiles done"
 python3 bench.py > profiles/${ROUND}_align_bench.json 2> gpurun_out/bench_align.err && echo "align line"
 python3 bench.py --workload train > profiles/${ROUND}_train_bench.json 2> gpurun_out/bench_train.err && echo "train line"
+python3 bench.py --workload train --band 80 > profiles/${ROUND}_train_band80_bench.json 2> gpurun_out/bench_train80.err && echo "train band-80 line"
+fi
+if [[ $PART == *b* ]]; then
+bash tools/profile.sh overlap --overlap-rows 680 --inflight 1 --serial-classes && summ overlap
+bash tools/profile.sh fulldp --reads 512 && summ fulldp
 python3 bench.py --workload fulldp > profiles/${ROUND}_fulldp_bench.json 2> gpurun_out/bench_fulldp.err && echo "fulldp line"
 python3 bench.py --workload overlap > profiles/${ROUND}_overlap_bench.json 2> gpurun_out/bench_overlap.err && echo "overlap line"
 python3 bench.py --workload overlap --reads 1500 > profiles/${ROUND}_overlap_dense_bench.json 2> gpurun_out/bench_dense.err && echo "dense line"
+fi
+echo "profiles done"
 mkdir -p gpurun_out/profiles_${ROUND} && cp profiles/${ROUND}_* gpurun_out/profiles_${ROUND}/
