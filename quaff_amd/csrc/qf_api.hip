@@ -1967,7 +1967,10 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   // Slotted single-diagonal list: x rows x0, x0 + 1, ... (the scheduler's order), at most one single-diagonal band per pair
   // (bands are at least 2 wide otherwise) and the staging kernel applies.
   uint32_t slot_rows = 0, slot_x0 = 0, slot_ychunks = 0;
-  if (c->ov_use_rows && cfg->band_size >= 2 && overlap_single_stages_rows(sc.Km) && !c->ov_slot_collision &&
+  // (k_overlap_single_rows: compact rows of up to 512 entries, context-free gap scores; else k_overlap_single_lds while whole rows fit)
+  const bool single_rows = c->ov_pitch && c->ov_cols_epoch == c->prep_epoch && sc.Kg == 1 && !(c->debug & QF_DEBUG_OLD_SINGLE_ROWS) &&
+                           (!need[0] || c->ov_mmic_epoch[0] == c->prep_epoch) && (!need[1] || c->ov_mmic_epoch[1] == c->prep_epoch);
+  if (c->ov_use_rows && cfg->band_size >= 2 && (single_rows || overlap_single_stages_rows(sc.Km)) && !c->ov_slot_collision &&
       !(c->debug & (QF_DEBUG_GLOBAL_OVERLAP_ROWS | QF_DEBUG_PAIR_ORDER_SINGLES))) {
     bool ok = true;
     uint32_t xa = 0, xb = 0, first = 1;
@@ -2073,8 +2076,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   if (!need[1]) { oa.mmi[1] = oa.mmi[0]; oa.gap[1] = oa.gap[0]; }
   if (slot_rows) {
     oa.slot_list = c->d_slot_list.as<uint32_t>(); oa.slot_rows = slot_rows; oa.slot_ychunks = slot_ychunks; oa.slot_x0 = slot_x0;
-    if (c->ov_pitch && c->ov_cols_epoch == c->prep_epoch && !(c->debug & QF_DEBUG_OLD_SINGLE_ROWS) &&
-        (!need[0] || c->ov_mmic_epoch[0] == c->prep_epoch) && (!need[1] || c->ov_mmic_epoch[1] == c->prep_epoch)) {
+    if (single_rows) {
       oa.mmic_pitch = c->ov_pitch;
       oa.mmic_cpr = c->ov_cpr;
       oa.mmic[0] = c->d_mmic0.as<double>();

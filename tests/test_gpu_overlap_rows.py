@@ -161,3 +161,98 @@ def test_rows_argument_errors(ctx):
     assert e.value.code == -2 and "reserved" in str(e.value)
     assert ctx.overlap_rows(6, 0, 5, cfg)["n_pairs"] == 11 + 10 + 9 + 8 + 7
     assert ctx.overlap_rows(12, 0, 11, cfg)["n_pairs"] == 66          # the same 12 sequences taken as 12 originals, no complements
+
+
+def _oracle_rows(rows, seqs, n_orig, params_json, cfg_kw, limit=400):
+    """every returned hit (at most `limit`, evenly spread) against the oracle with =="""
+    p = O.Params.from_json(params_json)
+    sc = O.Scores(p)
+    null = O.NullParams.from_json(NULL_JSON)
+    osc = {False: O.OverlapScores(p, sc, False), True: O.OverlapScores(p, sc, True)}
+    ocfg = O.DPConfig(kmer_len=cfg_kw.get("kmer_len", 6), kmer_threshold=cfg_kw.get("kmer_threshold", 14), band=cfg_kw.get("band_size", 64))
+    hits = rows["hits"]
+    pick = range(len(hits)) if len(hits) <= limit else np.linspace(0, len(hits) - 1, limit).astype(int)
+    for k in pick:
+        h = hits[int(k)]
+        nx, ny = int(h["x"]), int(h["y"])
+        comp = ny >= n_orig
+        want = O.overlap_pair(seqs[nx], seqs[ny], comp, osc[comp], sc, null, ocfg)
+        assert want is not None and (h["viterbi"], h["score"]) == (want["result"], want["score"]), (nx, ny)
+        assert (int(h["x_start"]), int(h["x_end"]), int(h["y_start"]), int(h["y_end"])) == (want["xStart"], want["xEnd"], want["yStart"], want["yEnd"])
+
+
+@pytest.mark.parametrize("case", ["wide_qualities", "two_base_match_context", "no_qualities"])
+def test_single_diagonal_rows_kernel_row_pitches(case):
+    """k_overlap_single_rows keeps the pair-emission rows of the quality values in use, Km x nq entries, at a row pitch of 128,
+    256 or 512 doubles: Phred 0..60 with one-base contexts takes 256 (244 entries), two-base match contexts with context-free
+    gaps (-suborder 1 -gaporder 0) 512 (336 entries); reads without qualities have one quality row per context (4 entries).
+    Rows vs the pair-list entry point (which runs the plain-list kernels) and vs the oracle."""
+    import quaff_amd as Q
+    from tests.helpers import mutate, rand_seq, rand_qual
+    from tests.test_gpu_align import synth_params_json
+    rng = np.random.default_rng({"wide_qualities": 311, "two_base_match_context": 312, "no_qualities": 313}[case])
+    pj = synth_params_json(rng, 2, 0) if case == "two_base_match_context" else DEFAULT_JSON
+    g = rand_seq(rng, 4000)
+    reads = []
+    for k in range(40):
+        L = int(rng.integers(150, 330))
+        s = int(rng.integers(0, len(g) - L))
+        src = g[s:s + L] if k % 3 else O.revcomp_str(g[s:s + L])
+        seq = mutate(rng, src, sub=0.04, ins=0.02, dele=0.02)
+        qual = "" if case == "no_qualities" else (rand_qual(rng, len(seq), 0, 60) if case == "wide_qualities" else rand_qual(rng, len(seq)))
+        reads.append(O.FastSeq("r%d" % k, seq, qual))
+    seqs = reads + [r.revcomp() for r in reads]
+    c = Q.Context(0)
+    try:
+        c.set_params_json(None if pj is DEFAULT_JSON else pj)
+        c.set_null_json(NULL_JSON)
+        c.upload_reads([s.seq for s in seqs], None if case == "no_qualities" else [s.qual for s in seqs])
+        cfg = Q.DPConfig(kmer_threshold=14)
+        rows, lst, pairs = compare_with_pair_list(c, 40, 80, 0, 39, cfg, float("-inf"))
+        assert rows["n_finite"] == len(pairs)
+        _oracle_rows(rows, seqs, 40, pj, {})
+    finally:
+        c.close()
+
+
+def test_single_diagonal_rows_kernel_many_chunks_and_a_strand_boundary_inside_a_wavefront():
+    """4 500 originals + their reverse complements = 9 000 resident sequences: 36 y chunks of 256 (both bands of a lane, several chunk
+    sets per XCD), the first reverse complement (index 4 500) in the middle of a group of 64 -- a wavefront whose lanes read two
+    strand tables, taken in two passes -- ragged lengths inside every group of 64 (blocks where some lanes' diagonals have ended),
+    and the rows the triangle's chunks run out on.  All hits of rows 0..2, rows around the strand boundary and the last rows
+    against the oracle; the totals of a row range against the pair-list entry point."""
+    import quaff_amd as Q
+    from tests.helpers import mutate, rand_seq, rand_qual
+    rng = np.random.default_rng(314)
+    n = 4500
+    g = rand_seq(rng, 30000)
+    reads = []
+    for k in range(n):
+        L = int(rng.integers(60, 200))
+        s = int(rng.integers(0, len(g) - L))
+        src = g[s:s + L] if k % 2 else O.revcomp_str(g[s:s + L])
+        seq = mutate(rng, src, sub=0.03, ins=0.01, dele=0.01)
+        reads.append(O.FastSeq("r%d" % k, seq, rand_qual(rng, len(seq))))
+    seqs = reads + [r.revcomp() for r in reads]
+    c = Q.Context(0)
+    try:
+        c.set_params_json(None)
+        c.set_null_json(NULL_JSON)
+        c.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+        cfg = Q.DPConfig(kmer_threshold=14)
+        c.set_score_threshold(0.0)
+        for x0, x1 in ((0, 3), (2240, 2243), (n - 4, n - 1)):
+            rows = c.overlap_rows(n, x0, x1, cfg)
+            assert rows["n_pairs"] == sum(2 * n - 1 - x for x in range(x0, x1)) == rows["n_finite"]
+            assert len(rows["hits"]) > 0
+            _oracle_rows(rows, seqs, n, DEFAULT_JSON, {}, limit=150)
+        rows, lst, pairs = compare_with_pair_list(c, n, 2 * n, n - 3, n - 1, cfg, 0.0)
+        # several rows in one block and one at a time: the same totals
+        c.set_score_threshold(float("-inf"))
+        whole = c.overlap_rows(n, 10, 14, cfg)
+        one = [c.overlap_rows(n, x, x + 1, cfg) for x in range(10, 14)]
+        for k in ("n_pairs", "n_finite", "total_cells", "total_diagonals"):
+            assert sum(o[k] for o in one) == whole[k], k
+        assert sum(o["result_checksum"] for o in one) & MASK == whole["result_checksum"]
+    finally:
+        c.close()
