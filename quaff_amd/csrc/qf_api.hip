@@ -350,6 +350,7 @@ int qf_ctx_create(int device_id, qf_ctx** out) {
   qf_ctx* c = new qf_ctx();
   c->device = device_id;
   if (const char* e = getenv("QUAFF_HIP_CHUNKS")) c->pipeline_chunks = (uint32_t)atoi(e);  // tuning aid; 0 = automatic
+  if (const char* e = getenv("QUAFF_HIP_DEBUG_FLAGS")) c->debug = (uint32_t)strtoul(e, nullptr, 0);   // developer A/B (qf_internal.h)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
   if (c->create()) {
@@ -1245,9 +1246,14 @@ int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_ali
   return QF_OK;
 }
 
+// QUAFF_HIP_DEBUG_FLAGS: switches OR-ed into every context's (developer A/B: a whole test run on a kernel variant)
+static uint32_t env_debug_flags() {
+  const char* e = getenv("QUAFF_HIP_DEBUG_FLAGS");
+  return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+}
 int qf_debug_set_flags(qf_ctx* c, uint32_t flags) {
   if (!c) return QF_ERR_ARG;
-  c->debug = flags;
+  c->debug = flags | env_debug_flags();
   return QF_OK;
 }
 
