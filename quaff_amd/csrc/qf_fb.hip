@@ -75,6 +75,16 @@ __device__ __forceinline__ void fx_add(unsigned long long* acc, double v) {
   fx_add_words(acc, w0, w1);
   if (big) fx_add_words(acc, w0, w1);
 }
+// A band's running totals (the context-free transition counts: sums over all the band's cells; -global full DP against a
+// reference of millions of bases pushes the expected delete count past fx_add's 2^20): integer part and fraction separately,
+// exact for any finite term below 2^31.
+__device__ __forceinline__ void fx_add_total(unsigned long long* acc, double v) {
+  if (!(v > 0.0)) return;
+  if (v < 262144.0) { fx_add(acc, v); return; }
+  const double ip = floor(v);
+  fx_add(acc, v - ip);                                              // (exact: v < 2^53)
+  fx_add_words(acc, 0ull, (unsigned long long)ip << 32);
+}
 
 // (context k-mer, quality) of a match-emission row number as the context words carry it (FbArgs::em_qmajor)
 __device__ __forceinline__ void em_row_decode(const FbArgs& a, uint32_t er, uint32_t& mk, uint32_t& q) {
@@ -803,16 +813,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
     __builtin_amdgcn_wave_barrier();
     for (uint32_t c = lane; c < 3 * Kg; c += 64) fx_add_words(cnt + 2 * (cTr + c), s_tr[2 * c], s_tr[2 * c + 1]);
   } else if (active && l == 0) {
-    fx_add(cnt + 2 * (cTr + 0), wgt * acc_m2m);
-    fx_add(cnt + 2 * (cTr + 1), wgt * acc_m2i);
-    fx_add(cnt + 2 * (cTr + 2), wgt * acc_m2d);
+    fx_add_total(cnt + 2 * (cTr + 0), wgt * acc_m2m);
+    fx_add_total(cnt + 2 * (cTr + 1), wgt * acc_m2i);
+    fx_add_total(cnt + 2 * (cTr + 2), wgt * acc_m2d);
   }
   if (active && l == 0) {
-    fx_add(cnt + 2 * (cTr + 3 * Kg + gkEnd), wgt * acc_m2e);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 0), wgt * acc_d2d);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 1), wgt * acc_d2m);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 2), wgt * acc_i2i);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 3), wgt * acc_i2m);
+    fx_add_total(cnt + 2 * (cTr + 3 * Kg + gkEnd), wgt * acc_m2e);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 0), wgt * acc_d2d);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 1), wgt * acc_d2m);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 2), wgt * acc_i2i);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 3), wgt * acc_i2m);
     a.units[uid].end_val = startv;  // Backward result of this band (diagnostic: should equal Forward's)
   }
 }
@@ -1127,11 +1137,11 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
   __builtin_amdgcn_wave_barrier();
   for (uint32_t c = l; c < 3 * Kg; c += 64) fx_add_words(cnt + 2 * (cTr + c), s_tr[2 * c], s_tr[2 * c + 1]);
   if (l == 0) {
-    fx_add(cnt + 2 * (cTr + 3 * Kg + gkEnd), acc_m2e);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 0), acc_d2d);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 1), acc_d2m);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 2), acc_i2i);
-    fx_add(cnt + 2 * (cTr + 4 * Kg + 3), acc_i2m);
+    fx_add_total(cnt + 2 * (cTr + 3 * Kg + gkEnd), acc_m2e);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 0), acc_d2d);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 1), acc_d2m);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 2), acc_i2i);
+    fx_add_total(cnt + 2 * (cTr + 4 * Kg + 3), acc_i2m);
     a.units[uid].end_val = startv;
   }
 }

@@ -95,35 +95,42 @@ static vector<FastSeq> readFastSeqs(const string& filename) {
   while ((n = gzread(fp, buf, sizeof buf)) > 0) data.append(buf, n);
   gzclose(fp);
   vector<FastSeq> seqs;
-  size_t p = 0;
-  auto line = [&](string& out) -> bool {
+  // lines are (begin, end) ranges of `data`: nothing is copied but the fields themselves (a 200 MB FASTQ of 100 k reads parsed
+  // at 0.5 GB/s with a string per line and a character at a time; config 2's device call takes 40 ms)
+  size_t p = 0, lb = 0, le = 0;
+  auto line = [&]() -> bool {
     if (p >= data.size()) return false;
-    size_t e = data.find('\n', p);
-    if (e == string::npos) e = data.size();
-    out.assign(data, p, e - p);
-    if (!out.empty() && out.back() == '\r') out.pop_back();
+    const char* nl = (const char*)memchr(data.data() + p, '\n', data.size() - p);
+    size_t e = nl ? (size_t)(nl - data.data()) : data.size();
+    lb = p;
+    le = e;
+    if (le > lb && data[le - 1] == '\r') --le;
     p = e + 1;
     return true;
   };
-  string l;
-  bool have = line(l);
+  auto first = [&]() -> char { return le > lb ? data[lb] : '\0'; };
+  bool have = line();
   while (have) {
-    if (l.empty() || (l[0] != '>' && l[0] != '@')) { have = line(l); continue; }
+    if (first() != '>' && first() != '@') { have = line(); continue; }
     FastSeq s;
-    const size_t sp = l.find_first_of(" \t");
-    s.name = l.substr(1, sp == string::npos ? string::npos : sp - 1);
-    if (sp != string::npos) s.comment = l.substr(sp + 1);
-    have = line(l);
-    while (have && !(l.size() && (l[0] == '>' || l[0] == '@' || l[0] == '+'))) {
-      for (char c : l) if (!isspace((unsigned char)c)) s.seq += c;
-      have = line(l);
+    size_t sp = lb + 1;
+    while (sp < le && data[sp] != ' ' && data[sp] != '\t') ++sp;
+    s.name.assign(data, lb + 1, sp - lb - 1);
+    if (sp < le) s.comment.assign(data, sp + 1, le - sp - 1);
+    have = line();
+    while (have && !(first() == '>' || first() == '@' || first() == '+')) {
+      bool blank = false;
+      for (size_t q = lb; q < le && !blank; ++q) blank = isspace((unsigned char)data[q]) != 0;
+      if (!blank) s.seq.append(data, lb, le - lb);
+      else for (size_t q = lb; q < le; ++q) if (!isspace((unsigned char)data[q])) s.seq += data[q];
+      have = line();
     }
-    if (have && l.size() && l[0] == '+') {
-      have = line(l);
-      while (have && s.qual.size() < s.seq.size()) { s.qual += l; have = line(l); }
+    if (have && first() == '+') {
+      have = line();
+      while (have && s.qual.size() < s.seq.size()) { s.qual.append(data, lb, le - lb); have = line(); }
       if (s.qual.size() != s.seq.size()) s.qual.clear();
     }
-    seqs.push_back(s);
+    seqs.push_back(std::move(s));
   }
   if (seqs.empty()) cerr << "Warning: Couldn't read any sequences from " << filename << endl;
   return seqs;
@@ -405,7 +412,7 @@ struct SeqSet {  // SeqList::loadSequences, t/quaff.cpp:610-636
       for (auto& fs : readFastSeqs(f)) {
         if (wantQual) Require(fs.hasQual(), "Sequence " + fs.name + " in file " + f + " does not have quality scores");
         else fs.qual.clear();
-        if (fs.seq.size()) seqs.push_back(fs);
+        if (fs.seq.size()) seqs.push_back(std::move(fs));
       }
     nOriginals = seqs.size();
     if (wantRevcomps) for (size_t n = 0; n < nOriginals; ++n) seqs.push_back(revcomp(seqs[n]));
