@@ -2100,6 +2100,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   oa.min_score = c->min_score;
   oa.per_pair = c->ov_per_pair ? 1 : 0;
   oa.no_lds_rows = (c->debug & QF_DEBUG_GLOBAL_OVERLAP_ROWS) != 0;
+  oa.no_fast_steps = (c->debug & QF_DEBUG_OV_NO_FAST) != 0;
   oa.Km = sc.Km;
   oa.Kg = sc.Kg;
   oa.pair_head = c->d_pair_head.as<uint32_t>();

@@ -47,4 +47,12 @@ __device__ __forceinline__ float dpp_f32_from_above(float v) {  // lane l+1's va
   return __int_as_float(r);
 }
 
+// acc = 2 * acc + (x > y): the compare's lane mask goes straight into an add-with-carry (no select / shift / or)
+__device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y) {
+  const unsigned long long mask = __builtin_amdgcn_fcmp(x, y, 2 /* ordered > */);
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
+  return acc;
+}
+
 }  // namespace qf

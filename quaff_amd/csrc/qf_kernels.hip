@@ -1316,14 +1316,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_units(SeedArgs a, uint32_t 
 //    reference's M, I, D order) instead of value/flag select chains.
 //  * Lane exchange by DPP row/wave shifts (a -inf "old" value fills the group's edge lane) instead of ds_bpermute.
 // ------------------------------------------------------------------------------------------------
-// acc = 2 * acc + (x > y): the compare's lane mask goes straight into an add-with-carry (no select / shift / or)
-__device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y) {
-  const unsigned long long mask = __builtin_amdgcn_fcmp(x, y, 2 /* ordered > */);
-  unsigned long long carry_out;
-  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
-  return acc;
-}
-
 template <int G, int B, bool GAPCTX, bool EMLDS>
 __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
   // EMLDS: the match-emission table (+ its -inf row) and the insert-emission table are copied to LDS once per workgroup.

@@ -178,6 +178,7 @@ struct OvArgs {  // overlap Viterbi fill / finalize / traceback (qf_overlap.hip)
   uint32_t* tb;
   const double* mmi[2];     // pair-emission tables [plain, yComplemented]
   double min_score;         // alignments scoring below it are neither traced back nor returned (-inf: keep all)
+  int no_fast_steps;        // A/B: the banded overlap fill takes the general step everywhere
   int no_lds_rows;          // A/B: single-diagonal bands gather their emissions from global memory (k_overlap_single)
   int per_pair;             // 1: pair_result / pair_score / pair_end_unit / pair_end_ij for every pair (qf_overlap_resident); 0: only what the kept alignments need
   const double* gap[2];

@@ -234,10 +234,30 @@ void k_overlap_fill(OvArgs a) {
   uint32_t xwN = xword(d0 + B + 1 + j0 - l), xwNN = xword(d0 + B + 2 + j0 - l);   // the words entering at steps 1 and 2
   uint32_t wy = yword(j0 + 1 - l), wyN = yword(j0 + 2 - l), wyNN = yword(j0 + 3 - l);
   uint32_t gkyPrev = yword(j0 - l) >> 24;
-  auto emis = [&](uint32_t wxrow, uint32_t wycol) -> double { return mmi[(size_t)(wxrow & 0x7FFFu) * KQ + (wycol & 0x7FFFu)]; };
+  // (a 32-bit element offset from the table's uniform base: (Km x 95)^2 entries are far below 2^32)
+  auto emis = [&](uint32_t wxrow, uint32_t wycol) -> double { return mmi[(wxrow & 0x7FFFu) * KQ + (wycol & 0x7FFFu)]; };
+  const int bmax = active ? dhi - d0 : -1;                            // slots b > bmax are outside the band
   double e[B];
 #pragma unroll
-  for (int b = 0; b < B; ++b) e[b] = emis(xw[b + 1], wy);
+  for (int b = 0; b < B; ++b) { const double en = emis(xw[b + 1], wy); e[b] = b > bmax ? QF_NEG_INF : en; }
+
+  // FAST steps (wave-uniform range [fastLo, fastHi]): every lane that has a band is on a column >= 2 inside its band's column range
+  // and all its band's slots are on rows 2 ... xLen.  Such a step needs no start candidate and no row / column validity; the
+  // slots above the band's last diagonal are kept at -inf by a -inf emission (match: its sums; insert: by induction, its sources
+  // lie further outside) and one select on the delete state (its source is the band's last diagonal).  Values come from v_max,
+  // the traceback bits straight from the compares (first maximum in the reference's order: bit 0 = second candidate beats the
+  // first, bit 1 = third beats both; "both" reads as 3, which the traceback takes for the third candidate away from row / column 1).
+  int fastLo = 0, fastHi = 0x7FFFFFFF;
+  if (active && bmax >= 0) {
+    const int bt = bmax < B - 1 ? bmax : B - 1;
+    const int jmin = max(max(2, j0 + 1), 2 - d0), jmax = min(jEnd, xLen - d0 - bt);
+    fastLo = jmin - j0 + l - 1;
+    fastHi = jmax - j0 + l - 1;
+  }
+  for (int o = 32; o; o >>= 1) { fastLo = max(fastLo, __shfl_xor(fastLo, o)); fastHi = min(fastHi, __shfl_xor(fastHi, o)); }
+  fastLo = __builtin_amdgcn_readfirstlane(fastLo);
+  fastHi = __builtin_amdgcn_readfirstlane(fastHi);
+  if (a.no_fast_steps) fastHi = -1;
 
   for (int t = 0; t < T; ++t) {
     const int j = j0 + t - l + 1;
@@ -248,6 +268,56 @@ void k_overlap_fill(OvArgs a) {
     double prevM = dpp_from_below<G, false>(pubM), prevI = dpp_from_below<G, false>(pubI), prevD = dpp_from_below<G, false>(pubD);
     double upM = 0, upI = 0, upD = 0;
     uint32_t tbw0 = 0, tbw1 = 0;
+    if (t >= fastLo && t <= fastHi) {
+      uint32_t acc0 = 0, acc1 = 0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const uint32_t wx = xw[b + 1];                       // row i
+        double m2m, m2i, m2d;
+        if (GAPCTX) {
+          const uint32_t gkx = wx >> 24, gkxP = xw[b] >> 24;   // xIndelKmer[i], xIndelKmer[i-1] (i, j >= 2 here)
+          m2m = gap[gkxP * Kg + gkyP];
+          m2i = gap[(size_t)Kg * Kg + gkx * Kg + gkyP];
+          m2d = gap[2ull * Kg * Kg + gkxP * Kg + gky];
+        } else { m2m = c_m2m; m2i = c_m2i; m2d = c_m2d; }
+        const double eb = e[b];
+        {
+          const double en = emis(b + 1 < B ? xw[b + 2] : xwN, wyN);
+          e[b] = b > bmax ? QF_NEG_INF : en;                 // (next step's emission; -inf above the band)
+        }
+        const double tM = (M[b] + m2m) + eb, tI = (I[b] + i2mS) + eb, tD = (D[b] + d2mS) + eb;
+        double m1, nm;
+        asm("v_max_f64 %0, %1, %2" : "=v"(m1) : "v"(tM), "v"(tI));
+        asm("v_max_f64 %0, %1, %2" : "=v"(nm) : "v"(m1), "v"(tD));
+        double sM, sI, sD;
+        if (b + 1 < B) { sM = M[b + 1]; sI = I[b + 1]; sD = D[b + 1]; } else { sM = upM; sI = upI; sD = upD; }
+        const double iM = sM + m2i, iI = sI + i2iS, iD = sD + d2iS;
+        const double ni = max_lse_exact<PACKED>(tab, iI, iD, iM);
+        double mi;
+        asm("v_max_f64 %0, %1, %2" : "=v"(mi) : "v"(iM), "v"(iI));
+        const double dM = prevM + m2d, dD = prevD + d2dS, dIfill = prevI + d2iS, dItb = prevI + i2dS;
+        double ndl = max_lse_exact<PACKED>(tab, dD, dIfill, dM);
+        double md;
+        asm("v_max_f64 %0, %1, %2" : "=v"(md) : "v"(dM), "v"(dItb));
+        if (b > bmax) ndl = QF_NEG_INF;
+        uint32_t& acc = b < 4 ? acc0 : acc1;
+        acc = shift_in_gt(acc, tI, tM);
+        acc = shift_in_gt(acc, tD, m1);
+        acc = shift_in_gt(acc, iI, iM);
+        acc = shift_in_gt(acc, iD, mi);
+        acc = shift_in_gt(acc, dItb, dM);
+        acc = shift_in_gt(acc, dD, md);
+        acc <<= 2;
+        M[b] = nm; I[b] = ni; D[b] = ndl;
+        prevM = nm; prevI = ni; prevD = ndl;
+        if (b == 0) {
+          upM = dpp_from_above<G, false>(nm); upI = dpp_from_above<G, false>(ni); upD = dpp_from_above<G, false>(ndl);
+        }
+        if (!PACKED) __builtin_amdgcn_sched_barrier(0);
+      }
+      tbw0 = __builtin_bitreverse32(acc0) >> (32 - 8 * (B < 4 ? B : 4));
+      if (B > 4) tbw1 = __builtin_bitreverse32(acc1) >> (32 - 8 * (B - 4));
+    } else
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       const int d = d0 + b, i = d + j;
@@ -262,8 +332,12 @@ void k_overlap_fill(OvArgs a) {
         m2d = gap[2ull * Kg * Kg + gkxP * Kg + gky];         // m2dScore(i-1, j)
       } else { m2m = c_m2m; m2i = c_m2i; m2d = c_m2d; }
       const double eb = e[b];
-      // this slot's emission for the next step: row i + 1 (the word above it in the window), column j + 1
-      e[b] = emis(b + 1 < B ? xw[b + 2] : xwN, wyN);
+      // this slot's emission for the next step: row i + 1 (the word above it in the window), column j + 1 (-inf above the band:
+      // the FAST steps rely on it)
+      {
+        const double en = emis(b + 1 < B ? xw[b + 2] : xwN, wyN);
+        e[b] = b > bmax ? QF_NEG_INF : en;
+      }
       // match state; traceback candidate order M, I, D, Start (strict >), src/qoverlap.cpp:204-209
       const double tM = (M[b] + m2m) + eb, tI = (I[b] + i2mS) + eb, tD = (D[b] + d2mS) + eb;
       double nm = tM;
@@ -1078,7 +1152,9 @@ __global__ void k_overlap_traceback(OvArgs a) {
   while (state != 0 && i >= 0 && j >= 0 && (i > 0 || j > 0)) {
     const uint32_t byte = (i >= 1 && j >= 1) ? cellbyte(i, j) : 0u;
     uint32_t op, s;
-    if (state == 1) { op = 0; s = byte & 3u; --i; --j; state = s == 0 ? 1 : s == 1 ? 2 : s == 2 ? 3 : 0; }
+    // (match source 3 = Start on row / column 1, the only place a start candidate exists; elsewhere the FAST steps' raw compare bits
+    // "I > M and D > max(M, I)", i.e. D)
+    if (state == 1) { op = 0; s = byte & 3u; const bool edge = i == 1 || j == 1; --i; --j; state = s == 0 ? 1 : s == 1 ? 2 : (s == 2 || !edge) ? 3 : 0; }
     else if (state == 2) { op = 1; s = (byte >> 2) & 3u; --j; state = s == 0 ? 1 : s == 1 ? 2 : 3; }
     else { op = 2; s = (byte >> 4) & 3u; --i; state = s == 0 ? 1 : s == 1 ? 2 : 3; }
     ++ncol;
