@@ -225,7 +225,9 @@ struct qf_ctx : Slot {
   uint64_t rows_settled = 0;    // QF_DEBUG_COUNT_SETTLED: pairs the prefilter settled during the last qf_overlap_resident
   uint64_t chunk_epoch = 0;
   int chunk_k = -1, chunk_log2 = 0;
+  uint32_t chunk_span = 0;       // seed_row_entry_span the index entries were built with
   uint64_t chunk_estride = 0;    // > 0: the chunk index is the padded one of k_seed_rows_lds
+  int chunk_pb = 0;              // > 0: 16-bit index entries, sequence << chunk_pb | position
   // k_seed_rows_lds (the prefilter with the chunk's index in LDS): whether the current chunk size was chosen for it, 16-bit entries,
   // the most k-mer positions a chunk holds; its chunk-major items (RowItemL) and pieces
   bool row_lds = false, row_e16 = false;
@@ -2011,6 +2013,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
           s.chunk_entries = c->d_centries.as<uint32_t>();
           s.chunk_log2 = c->chunk_log2;
           s.chunk_estride = c->chunk_estride;
+          s.chunk_pb = c->chunk_pb;
           s.row_skip = c->d_row_skip.as<uint8_t>();
           if (c->row_lds && c->row_pieces_n) {
             s.row_sorted = c->row_tri ? nullptr : c->d_row_sorted.p;
@@ -2348,11 +2351,21 @@ static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], u
         }
       }
     }
-    if (!c->row_lds)
+    // Second: 16-bit index entries, sequence << pb | position with 2^pb > the longest sequence -- the prefilter is bound by its
+    // gathers and these halve them -- when at least 8 sequences' counters (2^(pb + 1) diagonals each) fit the workgroup's LDS.
+    int pb = 0;
+    if (stride && !c->row_lds && !(c->debug & QF_DEBUG_ROW_INDEX_32)) {
+      int bits = 1;
+      while ((1ull << bits) < c->read_maxlen) ++bits;
+      int tcl = std::min(6, 16 - bits);
+      while (tcl >= 3 && (seed_row_stride_bytes_e16(bits, seed_row_bits_of(t)) << tcl) > kSeedRowLdsMax) --tcl;
+      if (tcl >= 3) { pb = bits; cl = tcl; }
+    }
+    if (!c->row_lds && !pb)
       while (stride && cl > 3 && (stride << cl) > kSeedRowLdsMax) --cl;   // two workgroups' counters per CU
-    if (stride && (c->row_lds || (stride << cl) <= kSeedRowLdsMax)) {
+    if (stride && (c->row_lds || pb || (stride << cl) <= kSeedRowLdsMax)) {
       const uint64_t estride = c->row_lds ? ((c->row_max_entries + (1ull << (2 * cfg->kmer_len)) + 16 + 15) & ~15ull) : 0;   // padded index: entries per chunk
-      if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl || c->chunk_estride != estride) {
+      if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl || c->chunk_estride != estride || c->chunk_span != seed_row_entry_span(t) || c->chunk_pb != pb) {
         const uint32_t nb = 1u << (2 * cfg->kmer_len), n_chunks = (n_seqs + (1u << cl) - 1) >> cl;
         const size_t bytes = (size_t)n_chunks * (nb + 1) * 4;
         const size_t ebytes = estride ? (size_t)n_chunks * estride * 4 : (c->read_total + 16) * 4;
@@ -2363,12 +2376,14 @@ static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], u
         HIPCHK(c, hipMemsetAsync(c->d_ccursor.p, 0, bytes, c->stream));
         if (estride) HIPCHK(c, hipMemsetAsync(c->d_centries.p, 0xFF, ebytes, c->stream));   // pad entries
         launch_chunk_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len, nb, cl,
-                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), estride, c->stream);
+                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), estride, seed_row_entry_span(t), pb, c->stream);
         HIPCHK(c, hipGetLastError());
         c->chunk_epoch = c->prep_epoch;
         c->chunk_k = cfg->kmer_len;
         c->chunk_log2 = cl;
         c->chunk_estride = estride;
+        c->chunk_span = seed_row_entry_span(t);
+        c->chunk_pb = pb;
       }
       c->ov_use_rows = true;
     }

@@ -854,7 +854,14 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_
 // Sixteen wavefronts per workgroup: a position's three dependent loads (its k-mer, the bucket, the bucket's entries four at a
 // time) are all the latency there is to hide, and the counters take 64 KB of LDS whatever the workgroup's size.
 constexpr int kSeedRowThreads = 1024;
-template <int CB>
+struct __attribute__((packed, aligned(4))) W2a { uint32_t v[2]; };
+// E16: the index entries are 16 bits, (sequence in chunk) << pb | (len - 1 - j) with 2^pb > the longest sequence, and a sequence's
+// counters span 2^(pb + 1) diagonals, so that an entry e names the counter position L = e + (e & ~(2^pb - 1)) = sequence << (pb + 1) |
+// position without a multiply.  What bounds this kernel is not arithmetic but the texture addresser: every look-up is a 64-lane
+// gather (`TA_BUSY` 74 %, 4.7 G cache accesses per launch in round 3's form: per x position two 4-byte bucket bounds and four
+// 16-byte entry loads, each lane on its own line).  16-bit entries halve the entry loads (a 16-byte load holds 8), the two bucket
+// bounds come as one 8-byte load: 6.25 -> 3.25 accesses per position.
+template <int CB, bool E16>
 __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint32_t stride) {
   extern __shared__ uint32_t cnt[];   // [2^cl][stride]: two 16-bit coarse counters per word
   const RowItem it = a.row_items[blockIdx.x];
@@ -866,42 +873,129 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
   const uint64_t xb = a.ref_off[it.x];
   const int xLen = (int)(a.ref_off[it.x + 1] - xb), nkx = xLen - k + 1;
   const uint32_t* __restrict__ cs = a.chunk_start + (uint64_t)it.chunk * (a.nbuckets + 1);
-  const uint32_t* __restrict__ ce = a.chunk_entries + a.read_off[(uint64_t)it.chunk << cl];
+  const uint32_t* __restrict__ ce = a.chunk_entries + (E16 ? 0 : a.read_off[(uint64_t)it.chunk << cl]);
+  const uint16_t* __restrict__ ce16 = (const uint16_t*)a.chunk_entries + (E16 ? a.read_off[(uint64_t)it.chunk << cl] : 0);
   const uint32_t* __restrict__ xk = a.skmer + xb;
   const uint32_t y0 = it.chunk << cl, yylo = it.ylo - y0, yyhi = it.yhi - y0;
   const bool whole = yylo == 0 && yyhi == csize;            // the item takes every sequence of the chunk (all but a row's two end chunks)
-  auto count = [&](uint32_t i, uint32_t ent) {
-    const uint32_t yy = ent >> 26;
-    if (!whole && (yy < yylo || yy >= yyhi)) return;
-    const uint32_t cbin = (i + (ent & 0x3FFFFFFu)) >> CB;   // bin = i - j + yLen - 1 (diagenv.cpp:33-40)
-    atomicAdd(&cnt[yy * stride + (cbin >> 1)], 1u << (16 * (cbin & 1)));
+  // A 32-bit index entry is L = (sequence in chunk) x Wd + (len - 1 - j), Wd = the diagonals a sequence's counters span (stride x 2
+  // bins of 2^CB: launch_chunk_index): the 16-bit counter of a match of x position i is number (L + i) >> CB of the whole array,
+  // i.e. word ((L + i) >> (CB + 1)), half (L + i) >> CB & 1 -- bin = i - j + yLen - 1 (diagenv.cpp:33-40) -- with no per-sequence
+  // multiply.  (Round 3 kept (sequence << 26 | position) and spent ~15 instructions per match unpacking it.)
+  const uint32_t Wd = (stride * 2u) << CB, Llo = yylo * Wd, Lhi = yyhi * Wd;
+  const uint32_t himask = E16 ? (0xFFFFu & ~((1u << a.chunk_pb) - 1u)) : 0u;
+  auto count = [&](uint32_t i, uint32_t L) {
+    if (E16) L += L & himask;
+    if (!whole && (L < Llo || L >= Lhi)) return;
+    const uint32_t t = L + i;
+    atomicAdd(&cnt[t >> (CB + 1)], 1u << (16 * ((t >> CB) & 1u)));
   };
-  // two positions per thread and round, their buckets' first kRowBatch x 4 entries fetched as one batch of independent loads
-  constexpr int kRowPos = 2, kRowBatch = 5;
+  const uint32_t cnt_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt;   // LDS address of the counters
+  // two positions per thread and round, their buckets' first entries fetched as one batch of independent 16-byte loads
+  constexpr int kRowPos = 2, kRowBatch = E16 ? 3 : 5, kPerLoad = E16 ? 8 : 4;
   for (int i0 = (int)tid; i0 < nkx; i0 += kRowPos * kSeedRowThreads) {
     uint32_t km[kRowPos], sq[kRowPos], eq[kRowPos];
 #pragma unroll
     for (int c = 0; c < kRowPos; ++c) km[c] = i0 + c * kSeedRowThreads < nkx ? xk[i0 + c * kSeedRowThreads] : 0u;
 #pragma unroll
     for (int c = 0; c < kRowPos; ++c) {
-      sq[c] = cs[km[c]];
-      eq[c] = i0 + c * kSeedRowThreads < nkx ? cs[km[c] + 1] : sq[c];
+      const W2a se = *(const W2a*)(cs + km[c]);            // the bucket's bounds as one 8-byte load
+      sq[c] = se.v[0];
+      eq[c] = i0 + c * kSeedRowThreads < nkx ? se.v[1] : sq[c];
     }
     W4a v[kRowPos][kRowBatch];
+    auto odd16 = [&](int c) { return (uint32_t)(((uintptr_t)(ce16 + sq[c]) >> 1) & 1u); };   // the bucket's first 16-bit entry sits in the upper half of its dword
 #pragma unroll
     for (int c = 0; c < kRowPos; ++c)
 #pragma unroll
-      for (int b = 0; b < kRowBatch; ++b)
-        if (sq[c] + 4 * b < eq[c]) v[c][b] = *(const W4a*)(ce + sq[c] + 4 * b);   // (the entry array has 16 words of slack)
+      for (int b = 0; b < kRowBatch; ++b) {
+        // (the entry array has 16 words of slack; a lane whose bucket ends earlier holds zeros it never counts; 16-bit entries are
+        // fetched from the even element at or below the bucket's first, so that the load is 4-byte aligned)
+        // (-1 for the first bucket of a chunk whose entries start at an odd element: the chunk before's last entry, never counted)
+        const int32_t first = (int32_t)(E16 ? sq[c] - odd16(c) : sq[c]);
+        if (first + kPerLoad * b < (int32_t)eq[c]) v[c][b] = E16 ? *(const W4a*)(ce16 + first + kPerLoad * b) : *(const W4a*)(ce + first + kPerLoad * b);
+        else v[c][b] = W4a{{0u, 0u, 0u, 0u}};
+      }
 #pragma unroll
     for (int c = 0; c < kRowPos; ++c) {
       const uint32_t i = (uint32_t)(i0 + c * kSeedRowThreads);
+      const uint32_t ip = i + (cnt_base << (CB - 1)), nrem = eq[c] - sq[c];
+      if (whole && !E16) {
+        // Four entries at a time, written out: per entry the sum L + i (the counters' LDS address rides in i, shifted up by the
+        // CB - 1 bits the word address drops), the word address, the increment 1 << 16 x (bin parity), and the count under an execution mask
+        // set by the compare itself (lanes whose bucket still has this entry) and put back by a scalar move: seven vector
+        // instructions and no branch per match.
 #pragma unroll
-      for (int b = 0; b < kRowBatch; ++b)
+        for (int b = 0; b < kRowBatch; ++b) {
+          uint32_t t0, t1, t2, t3, a0, a1, a2, a3;
+          unsigned long long sv;
+          asm volatile(
+              "v_add_u32 %[t0], %[e0], %[ip]\n v_add_u32 %[t1], %[e1], %[ip]\n v_add_u32 %[t2], %[e2], %[ip]\n v_add_u32 %[t3], %[e3], %[ip]\n"
+              "v_lshrrev_b32 %[a0], %[shw], %[t0]\n v_lshrrev_b32 %[a1], %[shw], %[t1]\n v_lshrrev_b32 %[a2], %[shw], %[t2]\n v_lshrrev_b32 %[a3], %[shw], %[t3]\n"
+              "v_and_b32 %[a0], -4, %[a0]\n v_and_b32 %[a1], -4, %[a1]\n v_and_b32 %[a2], -4, %[a2]\n v_and_b32 %[a3], -4, %[a3]\n"
+              "v_bfe_u32 %[t0], %[t0], %[cb], 1\n v_bfe_u32 %[t1], %[t1], %[cb], 1\n v_bfe_u32 %[t2], %[t2], %[cb], 1\n v_bfe_u32 %[t3], %[t3], %[cb], 1\n"
+              "v_lshlrev_b32 %[t0], 4, %[t0]\n v_lshlrev_b32 %[t1], 4, %[t1]\n v_lshlrev_b32 %[t2], 4, %[t2]\n v_lshlrev_b32 %[t3], 4, %[t3]\n"
+              "v_lshlrev_b32_e64 %[t0], %[t0], 1\n v_lshlrev_b32_e64 %[t1], %[t1], 1\n v_lshlrev_b32_e64 %[t2], %[t2], 1\n v_lshlrev_b32_e64 %[t3], %[t3], 1\n"
+              "s_mov_b64 %[sv], exec\n"
+              "v_cmpx_lt_u32 vcc, %[k0], %[n]\n ds_add_u32 %[a0], %[t0]\n s_mov_b64 exec, %[sv]\n"
+              "v_cmpx_lt_u32 vcc, %[k1], %[n]\n ds_add_u32 %[a1], %[t1]\n s_mov_b64 exec, %[sv]\n"
+              "v_cmpx_lt_u32 vcc, %[k2], %[n]\n ds_add_u32 %[a2], %[t2]\n s_mov_b64 exec, %[sv]\n"
+              "v_cmpx_lt_u32 vcc, %[k3], %[n]\n ds_add_u32 %[a3], %[t3]\n s_mov_b64 exec, %[sv]\n"
+              : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
+                [sv] "=&s"(sv)
+              : [e0] "v"(v[c][b].v[0]), [e1] "v"(v[c][b].v[1]), [e2] "v"(v[c][b].v[2]), [e3] "v"(v[c][b].v[3]), [ip] "v"(ip), [n] "v"(nrem),
+                [shw] "n"(CB - 1), [cb] "n"(CB), [k0] "n"(4 * b), [k1] "n"(4 * b + 1), [k2] "n"(4 * b + 2), [k3] "n"(4 * b + 3)
+              : "vcc", "memory");
+        }
+      } else if (whole && E16) {
+        // The same for 16-bit entries, a dword = two entries at a time: entry e -> L = e + (e & himask); entry number q of the
+        // load (from the even entry at or below the bucket's first) is the bucket's entry q - (first & 1): counted while that is
+        // below the bucket's length (unsigned: the entry before the bucket wraps to a large number).
+        const uint32_t odd = odd16(c);
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-          if (sq[c] + 4 * b + w < eq[c]) count(i, v[c][b].v[w]);
-      for (uint32_t q = sq[c] + 4 * kRowBatch; q < eq[c]; ++q) count(i, ce[q]);   // longer buckets: rare
+        for (int b = 0; b < kRowBatch; ++b)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            uint32_t e0, e1, t0, t1, a0, a1, q0, q1;
+            unsigned long long sv;
+            asm volatile(
+                "v_and_b32 %[e0], 0xffff, %[wd]\n v_lshrrev_b32 %[e1], 16, %[wd]\n"
+                "v_and_b32 %[t0], %[hm], %[e0]\n v_and_b32 %[t1], %[hm], %[e1]\n"
+                "v_add3_u32 %[t0], %[e0], %[t0], %[ip]\n v_add3_u32 %[t1], %[e1], %[t1], %[ip]\n"
+                "v_lshrrev_b32 %[a0], %[shw], %[t0]\n v_lshrrev_b32 %[a1], %[shw], %[t1]\n"
+                "v_and_b32 %[a0], -4, %[a0]\n v_and_b32 %[a1], -4, %[a1]\n"
+                "v_bfe_u32 %[t0], %[t0], %[cb], 1\n v_bfe_u32 %[t1], %[t1], %[cb], 1\n"
+                "v_lshlrev_b32 %[t0], 4, %[t0]\n v_lshlrev_b32 %[t1], 4, %[t1]\n"
+                "v_lshlrev_b32_e64 %[t0], %[t0], 1\n v_lshlrev_b32_e64 %[t1], %[t1], 1\n"
+                "v_sub_u32 %[q0], %[k0], %[odd]\n v_sub_u32 %[q1], %[k1], %[odd]\n"
+                "s_mov_b64 %[sv], exec\n"
+                "v_cmpx_lt_u32 vcc, %[q0], %[n]\n ds_add_u32 %[a0], %[t0]\n s_mov_b64 exec, %[sv]\n"
+                "v_cmpx_lt_u32 vcc, %[q1], %[n]\n ds_add_u32 %[a1], %[t1]\n s_mov_b64 exec, %[sv]\n"
+                : [e0] "=&v"(e0), [e1] "=&v"(e1), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "=&v"(a0), [a1] "=&v"(a1), [q0] "=&v"(q0), [q1] "=&v"(q1),
+                  [sv] "=&s"(sv)
+                : [wd] "v"(v[c][b].v[w]), [hm] "v"(himask), [ip] "v"(ip), [n] "v"(nrem), [odd] "v"(odd), [shw] "n"(CB - 1), [cb] "n"(CB),
+                  [k0] "n"(8 * b + 2 * w), [k1] "n"(8 * b + 2 * w + 1)
+                : "vcc", "memory");
+          }
+      } else if (E16) {
+        const uint32_t odd = odd16(c);
+#pragma unroll
+        for (int b = 0; b < kRowBatch; ++b)
+#pragma unroll
+          for (int w = 0; w < 8; ++w) {
+            const uint32_t q = (uint32_t)(8 * b + w) - odd;
+            if (q < nrem) count(i, (v[c][b].v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu);
+          }
+      } else {
+#pragma unroll
+        for (int b = 0; b < kRowBatch; ++b)
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            if (sq[c] + 4 * b + w < eq[c]) count(i, v[c][b].v[w]);
+      }
+      // longer buckets: rare
+      if (E16) for (uint32_t q = sq[c] - odd16(c) + kPerLoad * kRowBatch; q < eq[c]; ++q) count(i, ce16[q]);
+      else for (uint32_t q = sq[c] + kPerLoad * kRowBatch; q < eq[c]; ++q) count(i, ce[q]);
     }
   }
   __syncthreads();
@@ -1143,7 +1237,7 @@ __global__ void k_chunk_kmer_count(const uint8_t* __restrict__ tok, const uint64
 }
 __global__ void k_chunk_kmer_scatter(const uint8_t* __restrict__ tok, const uint64_t* __restrict__ off, uint32_t k, uint32_t nbuckets,
                                      int cl, const uint32_t* __restrict__ starts, uint32_t* __restrict__ cursor,
-                                     uint32_t* __restrict__ entries, uint64_t estride) {
+                                     uint32_t* __restrict__ entries, uint64_t estride, uint32_t wd, int pb) {
   const uint32_t x = blockIdx.y;
   const uint64_t b = off[x], len = off[x + 1] - b;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1154,7 +1248,9 @@ __global__ void k_chunk_kmer_scatter(const uint8_t* __restrict__ tok, const uint
   const uint32_t slot = starts[bi] + atomicAdd(&cursor[bi], 1u);
   // a chunk's entries: behind those of the chunks before it, or (padded index) `estride` entries per chunk
   const uint64_t cbase = estride ? (uint64_t)(x >> cl) * estride : off[(uint64_t)(x >> cl) << cl];
-  entries[cbase + slot] = ((x & ((1u << cl) - 1)) << 26) | (uint32_t)(len - 1 - i);
+  // (k_seed_rows: sequence x wd + position, wd = the diagonals a sequence's counters span; k_seed_rows_lds re-packs (sequence, position) itself)
+  if (pb) ((uint16_t*)entries)[cbase + slot] = (uint16_t)(((x & ((1u << cl) - 1)) << pb) | (uint32_t)(len - 1 - i));   // k_seed_rows<., true>
+  else entries[cbase + slot] = wd ? (x & ((1u << cl) - 1)) * wd + (uint32_t)(len - 1 - i) : ((x & ((1u << cl) - 1)) << 26) | (uint32_t)(len - 1 - i);
 }
 
 // Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
@@ -2296,12 +2392,12 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
 // estride = 0: a chunk's entries follow the chunks before it; > 0 (k_seed_rows_lds): buckets padded to even length (the pad
 // entry stays 0xFFFFFFFF: the caller fills the array with it first), `estride` entries per chunk
 void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
-                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, hipStream_t s) {
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, uint32_t wd, int pb, hipStream_t s) {
   const dim3 grid((uint32_t)((max_len + 255) / 256), n_seqs);
   const uint32_t n_chunks = (n_seqs + (1u << chunk_log2) - 1) >> chunk_log2;
   hipLaunchKernelGGL(k_chunk_kmer_count, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts);
   hipLaunchKernelGGL(k_bucket_scan, dim3(n_chunks), dim3(1024), 0, s, starts, nbuckets, estride ? 2u : 1u);
-  hipLaunchKernelGGL(k_chunk_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts, cursor, entries, estride);
+  hipLaunchKernelGGL(k_chunk_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts, cursor, entries, estride, estride ? 0u : wd, estride ? 0 : pb);
 }
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;
@@ -2340,6 +2436,11 @@ static uint32_t seed_wave_words(const SeedArgs& a, int cb, bool& wide) {
 // The prefilter's coarse bins are half as wide as the per-pair kernel's: k-mer matches come in runs (a chance 8-mer is three
 // of them on one diagonal), and with bins of 8 diagonals 17 % of unrelated 2 kb read pairs still had a bin at the threshold.
 static int seed_row_bits(const SeedArgs& a) { return seed_coarse_bits(a) - 1; }
+// k_seed_rows<., E16>: bytes of 16-bit counters per sequence when a sequence's counters span 2^(pb + 1) diagonals
+size_t seed_row_stride_bytes_e16(int pb, int cb) { return ((size_t)2 << (pb + 1)) >> cb; }
+int seed_row_bits_of(const SeedArgs& a) { return seed_row_bits(a); }
+// diagonals the counters of one sequence of a chunk span in k_seed_rows (its index entries are sequence x this + position)
+uint32_t seed_row_entry_span(const SeedArgs& a) { return (uint32_t)(seed_row_stride_bytes(a) / 4 * 2) << seed_row_bits(a); }
 size_t seed_row_stride_bytes(const SeedArgs& a) {
   if (!a.sparse || a.threshold < 0 || !a.nbuckets || a.ref_skeys || a.dump_cover || a.force_block_kernel || seed_needs_deep_counters(a)) return 0;
   const int cb = seed_row_bits(a);
@@ -2404,13 +2505,16 @@ int launch_seed(const SeedArgs& a_in, uint32_t n_pairs, bool mem, hipStream_t s)
       a.pair_skip = a.row_skip;
     }
   } else if (a.row_items && a.n_row_items && !mem) {   // settle the pairs with nothing but the forced diagonal a chunk of y at a time
-    const size_t stride = seed_row_stride_bytes(a);
+    const int cb = seed_row_bits(a);
+    const size_t stride = a.chunk_pb ? seed_row_stride_bytes_e16(a.chunk_pb, cb) : seed_row_stride_bytes(a);
     const size_t lds = stride << a.chunk_log2;
-    if (stride && lds <= kSeedRowLdsMax) {
-      const int cb = seed_row_bits(a);
-      auto fn = cb == 4 ? k_seed_rows<4> : cb == 3 ? k_seed_rows<3> : k_seed_rows<2>;
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(fn, dim3(a.n_row_items), dim3(kSeedRowThreads), lds, s, a, (uint32_t)(stride / 4));
+    if (seed_row_stride_bytes(a) && lds <= kSeedRowLdsMax) {
+      auto go = [&](auto fn) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(fn, dim3(a.n_row_items), dim3(kSeedRowThreads), lds, s, a, (uint32_t)(stride / 4));
+      };
+      if (a.chunk_pb) { if (cb == 4) go(k_seed_rows<4, true>); else if (cb == 3) go(k_seed_rows<3, true>); else go(k_seed_rows<2, true>); }
+      else { if (cb == 4) go(k_seed_rows<4, false>); else if (cb == 3) go(k_seed_rows<3, false>); else go(k_seed_rows<2, false>); }
       a.pair_skip = a.row_skip;
     }
   }
