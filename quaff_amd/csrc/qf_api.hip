@@ -1881,7 +1881,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
                         !memcmp(c->row_items_rows.data(), c->ov_rows.data(), c->ov_rows.size() * sizeof(qf_ctx::PairRow));
     // The scheduler's triangle (whole rows x0, x0 + 1, ..., each x against x + 1 ... n_seqs - 1) with the LDS prefilter: no item
     // list at all -- a piece is (first row, rows, chunk) and k_seed_rows_lds forms its items itself.
-    bool tri = c->row_lds && !c->ov_rows.empty() && lo == 0;
+    bool tri = !c->ov_rows.empty() && lo == 0 && !(c->debug & QF_DEBUG_HOST_ROW_ITEMS);
     if (tri) {
       uint64_t p = 0;
       for (size_t q = 0; q < c->ov_rows.size() && tri; ++q) {
@@ -1891,7 +1891,15 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       }
       tri = tri && p == hi;
     }
-    if (tri && !cached) {
+    if (tri && !c->row_lds) {
+      // ... and with the plain prefilter the list is formed by a kernel (k_row_items_tri), not built and copied by the host
+      const uint32_t X0 = c->ov_rows[0].x, R = (uint32_t)c->ov_rows.size();
+      const uint32_t n = launch_row_items_tri(X0, R, c->n_reads, cl, nullptr, 0, c->stream);
+      HIPCHK(c, c->d_row_items.reserve((size_t)n * sizeof(RowItem)));
+      c->row_items_n = launch_row_items_tri(X0, R, c->n_reads, cl, c->d_row_items.as<RowItem>(), n, c->stream);
+      HIPCHK(c, hipGetLastError());
+      c->row_items_epoch = 0;   // (d_row_items no longer holds a cached host-built list)
+    } else if (tri && !cached) {
       constexpr uint32_t kPiece = 64;
       const uint32_t X0 = c->ov_rows[0].x, X1 = X0 + (uint32_t)c->ov_rows.size(), n_chunks = (c->n_reads + (1u << cl) - 1) >> cl;
       std::vector<uint4> pieces;
@@ -1953,7 +1961,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         }
       }
       // deal: segments of kSeg consecutive items go to XCD 0, 1, ... 7, 0, ...; workgroup b sits on XCD b % 8
-      constexpr uint32_t kSeg = 32, kXcd = 8;
+      constexpr uint32_t kSeg = kRowSeg, kXcd = kRowXcd;
       const uint32_t n_items = (uint32_t)sorted.size(), n_seg = (n_items + kSeg - 1) / kSeg, seg_rounds = (n_seg + kXcd - 1) / kXcd;
       std::vector<RowItem> items((size_t)seg_rounds * kXcd * kSeg, RowItem{~0u, 0, 0, 0, 0});
       for (uint32_t k = 0; k < n_items; ++k) {
@@ -2535,7 +2543,15 @@ int qf_overlap_rows(qf_ctx* c, const qf_dp_config* cfg, uint32_t n_originals, ui
   c->ov_tot = qf_ctx::OvTotals();
   c->h_hits.clear();
   c->h_hit_runs.clear();
-  const uint64_t want = c->ov_block_pairs ? c->ov_block_pairs : (1ull << 24);
+  // Blocks of about 2^24 pairs, of EQUAL size: a call's rows cut at exactly 2^24 leave a small last block, and a block costs
+  // ~10 ms however few pairs it has (one banded unit's 2000 dependent steps, the traceback's, the host's turnarounds).
+  uint64_t want = c->ov_block_pairs ? c->ov_block_pairs : (1ull << 24);
+  if (!c->ov_block_pairs) {
+    uint64_t total = 0;
+    for (uint32_t x = x0; x < x1; ++x) total += n_seqs - 1 - x;
+    const uint64_t nb = std::max<uint64_t>(1, (total + want / 2) / want);
+    want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want + want / 2);   // (+ a row: the cut falls on a row boundary)
+  }
   std::vector<uint64_t> row_start;
   for (uint32_t b0 = x0; b0 < x1;) {
     // rows of this block: as many as stay under the pair target (at least one; a row has fewer than 2^28 pairs by the

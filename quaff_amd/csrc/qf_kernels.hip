@@ -854,6 +854,48 @@ __global__ __launch_bounds__(512) void k_seed_wave_lds_pairs(SeedArgs a, uint32_
 // Sixteen wavefronts per workgroup: a position's three dependent loads (its k-mer, the bucket, the bucket's entries four at a
 // time) are all the latency there is to hide, and the counters take 64 KB of LDS whatever the workgroup's size.
 constexpr int kSeedRowThreads = 1024;
+// The row prefilter's item list for the scheduler's triangle -- whole rows X0 .. X0 + R - 1, each x against x + 1 ... n_seqs - 1
+// (src/qoverlap.cpp:528-547) -- formed on the device: chunk-major (every row of one chunk of y before the next chunk), then dealt
+// out in segments of kRowSeg items to XCD 0, 1, ... 7 like the host's list for arbitrary runs (overlap_chunk).  A row block of
+// 2^24 pairs against 100 k sequences is 1.1 M items: built and copied by the host that was 2 - 3 ms of idle GPU per block.
+// Chunk ch0 + c holds rows X0 .. min(X0 + R, ((ch0 + c + 1) << cl) - 1) - 1: A + c x 2^cl of them while that is below R (the
+// first nPart chunks, firstFull items in all), R from there on.
+__global__ void k_row_items_tri(uint32_t X0, uint32_t R, uint32_t n_seqs, int cl, uint32_t ch0, uint32_t A, uint32_t nPart, uint32_t firstFull,
+                                uint32_t n_items, uint32_t n_padded, RowItem* __restrict__ items) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n_padded) return;
+  const uint32_t xcd = d % kRowXcd, t = d / kRowXcd, pos = t % kRowSeg, seg = (t / kRowSeg) * kRowXcd + xcd, k = seg * kRowSeg + pos;
+  RowItem it{~0u, 0u, 0u, 0u, 0u};
+  if (k < n_items) {
+    uint32_t c, r;
+    if (k >= firstFull) { c = nPart + (k - firstFull) / R; r = (k - firstFull) % R; }
+    else {
+      uint32_t first = 0, cnt = A;
+      for (c = 0; first + cnt <= k; ++c) { first += cnt; cnt += 1u << cl; }
+      r = k - first;
+    }
+    const uint32_t x = X0 + r, chunk = ch0 + c;
+    const uint32_t ylo = max(x + 1, chunk << cl), yhi = (uint32_t)min((uint64_t)n_seqs, ((uint64_t)chunk + 1) << cl);
+    const uint64_t p0 = (uint64_t)r * (n_seqs - 1 - X0) - (uint64_t)r * (r ? r - 1 : 0) / 2;   // pairs of the rows before x
+    it = RowItem{x, chunk, ylo, yhi, (uint32_t)(p0 + (ylo - (x + 1)))};
+  }
+  items[d] = it;
+}
+uint32_t launch_row_items_tri(uint32_t X0, uint32_t R, uint32_t n_seqs, int cl, RowItem* items, size_t capacity, hipStream_t s) {
+  const uint32_t ch0 = (X0 + 1) >> cl, n_chunks = (uint32_t)(((uint64_t)n_seqs + (1u << cl) - 1) >> cl);
+  const uint32_t A = ((ch0 + 1) << cl) - 1 - X0;
+  uint64_t firstFull = 0;
+  uint32_t nPart = 0;
+  for (uint64_t cnt = A; cnt < R && ch0 + nPart < n_chunks; cnt += 1u << cl) { firstFull += cnt; ++nPart; }
+  const uint64_t n_items = firstFull + (uint64_t)(n_chunks - (ch0 + nPart)) * R;
+  const uint64_t n_seg = (n_items + kRowSeg - 1) / kRowSeg, n_padded = (n_seg + kRowXcd - 1) / kRowXcd * kRowXcd * kRowSeg;
+  if (!items) return (uint32_t)std::min<uint64_t>(n_padded, 0xFFFFFFFFull);   // (size query)
+  if (!n_items || n_padded > capacity) return 0;
+  hipLaunchKernelGGL(k_row_items_tri, dim3((uint32_t)((n_padded + 255) / 256)), dim3(256), 0, s, X0, R, n_seqs, cl, ch0, A, nPart, (uint32_t)firstFull,
+                     (uint32_t)n_items, (uint32_t)n_padded, items);
+  return (uint32_t)n_padded;
+}
+
 struct __attribute__((packed, aligned(4))) W2a { uint32_t v[2]; };
 // E16: the index entries are 16 bits, (sequence in chunk) << pb | (len - 1 - j) with 2^pb > the longest sequence, and a sequence's
 // counters span 2^(pb + 1) diagonals, so that an entry e names the counter position L = e + (e & ~(2^pb - 1)) = sequence << (pb + 1) |

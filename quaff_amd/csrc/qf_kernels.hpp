@@ -46,6 +46,9 @@ size_t seed_rows_lds_fit(const struct SeedArgs& a, int cl, uint64_t max_entries,
 size_t seed_rows_lds_bytes(const struct SeedArgs& a, size_t stride, int cl, uint64_t max_entries, bool e16);
 constexpr size_t kSeedRowLdsMax = 76 * 1024;   // LDS of one row-prefilter workgroup (per-y coarse counters of a chunk): two fit a CU
 struct RowItem { uint32_t x, chunk, ylo, yhi, pbase; };   // pairs (x, y) for y in [ylo, yhi), all inside one chunk; pair index of ylo
+constexpr uint32_t kRowSeg = 32, kRowXcd = 8;   // the item list is dealt out in segments of kRowSeg to the XCDs (overlap_chunk)
+// triangle rows X0 .. X0 + R - 1: the dealt-out item list formed on the device; returns its length (items == nullptr: only that)
+uint32_t launch_row_items_tri(uint32_t X0, uint32_t R, uint32_t n_seqs, int cl, RowItem* items, size_t capacity, hipStream_t s);
 
 struct SeedArgs {
   uint32_t pair_base, n_refs;
