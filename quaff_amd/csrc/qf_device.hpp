@@ -32,7 +32,7 @@ struct Unit {
   uint32_t cls;       // fill-kernel class
   double end2_val;    // overlap only: max of mat over the band's cells in the last REFERENCE row (i == xLen)
   uint32_t end2_j;    // its read column (largest column on ties)
-  uint32_t pad_;
+  uint32_t staged;    // E-step: k_backward_fill ran on this band and left its column sums for k_count_flush
 };
 
 // Fill-kernel classes: class 0 = single diagonal (one lane per unit); class c>0 = G lanes x B

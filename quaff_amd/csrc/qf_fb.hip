@@ -517,11 +517,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
   const uint32_t n_em = a.dp.ematch_ninf_off / 8 + 4;
   double* s_trans = lds_fb + kLseDoubles;
   double* s_acc_all = s_trans + ((4 * Kg + 1) & ~1u);             // [4 waves][4][64 lanes] i2m, d2m, i2i, d2d counts of each lane
-  unsigned long long* s_tr_all = (unsigned long long*)(s_acc_all + 4 * 4 * 64);   // [4 waves][3 Kg][2] context-dependent transition counts (fixed point: fx_add)
-  double* s_em = (double*)s_tr_all + (GAPCTX ? 4 * 3 * Kg * 2 : 0u);
+  double* s_em = s_acc_all + 4 * 4 * 64;
   lseh_load(lds_fb, a.lse_h, threadIdx.x, 256);
   for (uint32_t k = threadIdx.x; k < 4 * Kg; k += 256) s_trans[k] = a.dp.trans[k];
-  if (GAPCTX) for (uint32_t k = threadIdx.x; k < 4 * 3 * Kg * 2; k += 256) s_tr_all[k] = 0ull;
   for (uint32_t k = threadIdx.x; k < 4 * 4 * 64; k += 256) s_acc_all[k] = 0.0;
   if (EMLDS) {
     for (uint32_t k = threadIdx.x; k < n_em; k += 256) s_em[k] = a.dp.ematch[k];
@@ -535,7 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int grp = lane / G, l = lane % G, rl = G - 1 - l;
   const uint32_t uidx = wave * UPW + grp;
-  bool active = uidx < a.n_cls_units;
+  const bool exists = uidx < a.n_cls_units;
+  bool active = exists;
   uint32_t uid = 0;
   int dlo = 0, dhi = -1, xLen = 0, yLen = 0;
   uint64_t xb = 0, yb = 0, fw_off = 0;
@@ -555,16 +554,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
     // band (typically the lone diagonal 0 beside the seeded band) contributes exactly nothing.
     if (!a.no_band_shortcuts && u.end_val - Fres < -110.0) active = false;
   }
+  if (exists && l == 0) a.units[uid].staged = active ? 1u : 0u;   // k_count_flush: this band's rows hold column sums
   int T = active ? yLen + G - 1 : 0;
   for (int o = 32; o; o >>= 1) T = max(T, __shfl_xor(T, o));
   if (T == 0) return;
-  // Context-dependent transition counts of the wavefront's bands: fixed-point words in LDS like the global accumulators (fx_add:
-  // two ds_add_u64 without return per term), flushed word for word at the end.  (A cheaper-looking scheme -- fp64 ds_add_f64 of
-  // terms rounded to a multiple of one quantum, whose sums are exact whatever the order -- is order-free only for a FIXED
-  // quantum; one sized from the wavefront's own longest band makes a term's rounding depend on which bands share the wavefront,
-  // i.e. on how the batch was cut: tests/soak_count_overlap.py found totals differing in the 14th digit between a call and the
-  // same call in pieces.  A fixed quantum safe for 1 M-base reads is 2^-29: too coarse for the rare contexts' small counts.)
-  unsigned long long* s_tr = s_tr_all + (size_t)wv * 3 * Kg * 2;
   const int d0 = dlo + l * B;
   const int bmax = active ? dhi - d0 : -1;
   const double i2m = a.dp.i2m, d2m = a.dp.d2m, i2i = a.dp.i2i, d2d = a.dp.d2d;
@@ -576,7 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
   const uint8_t* __restrict__ xt = a.ref_tok + xb;
   const uint32_t* __restrict__ ctx = a.ctx + yb;
   unsigned long long* __restrict__ cnt = a.counts + 2 * (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;   // (lo, hi) per entry; contention: see kCountReplicas
-  const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
+  const uint64_t cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
 
   double Bm[B], Bi[B], Bd[B];   // Backward values of this lane's diagonals at the column of its previous step
 #pragma unroll
@@ -584,8 +577,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
   double pubD = QF_NEG_INF;     // slot 0's del after this lane's latest step (for lane l-1)
   double acc_m2e = 0, startv = QF_NEG_INF;
   double acc_m2m = 0, acc_m2i = 0, acc_m2d = 0;   // !GAPCTX only
-  // running match-by-token[4] / insert sums of the column this lane is on: at most G x B terms each, fp32 like the partials
-  float colsum[5] = {0, 0, 0, 0, 0};
+  // running match-by-token[4] / insert / (GAPCTX) m2m, m2i, m2d sums of the column this lane is on: at most G x B terms each,
+  // fp32 like the partials
+  constexpr int NCOL = GAPCTX ? 8 : 5;
+  float colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t gkEnd = 0;
 
   // tokens of rows i+1 of the lane's B slots as a sliding 2-bit window (the rows move up by one per step)
@@ -607,7 +602,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
   // context words: the lane's column falls by one per step; the word of column j is ctx[j - 1], loaded a step ahead
   auto ctxword = [&](int t) -> uint32_t { return ctx[max(yLen - 1 - t + rl, -100)]; };
   uint32_t wA = ctxword(0);
-  uint32_t wNext = 0;            // context word of column j+1 (this lane's previous step)
   // Fq[c], e[b]: this step's operands, fetched during the previous step.  Fq = the cell row of the Forward storage (packed
   // fp32: anchor, then (mat, ins, del) offsets of slot B-1 .. 0, NF / 4 sixteen-byte chunks); a chunk is reloaded for the
   // next step as soon as the slot loop (which runs from slot B-1 down) has used its last value: one buffer, a whole step of
@@ -755,19 +749,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
 #pragma unroll
     for (int c = 0; c < 4; ++c) unsafeAtomicAdd(&s_acc[c * 64], (double)pa[c]);
     // ---- per-column partials travel with the column: lane l+1 was on column j one step ago and hands its running sums
-    // to lane l; the unit's lane 0 is the last on every column and flushes the complete sums (no LDS, no barriers)
+    // to lane l; the unit's lane 0 is the last on every column and holds the complete sums (no LDS, no barriers)
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < NCOL; ++c) {
       const float in = dpp_f32_from_above<G>(colsum[c]);
       colsum[c] = colvalid ? in + pf[c] : 0.f;
     }
     if (colvalid) {
       if (!GAPCTX) { acc_m2m += (double)pf[5]; acc_m2i += (double)pf[6]; acc_m2d += (double)pf[7]; }
-      else {
-        fx_add(s_tr + 2 * gk, wgt * (double)pf[5]);
-        fx_add(s_tr + 2 * (Kg + gk), wgt * (double)pf[6]);
-        fx_add(s_tr + 2 * (2 * Kg + gk), wgt * (double)pf[7]);
-      }
       if (startStep && j == 1) {  // start -> mat(i,1): emission counts of column 1, once per lane
         const uint32_t er = w & 0x7FFFu;
         uint32_t mk, q;
@@ -779,22 +768,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
         }
       }
     }
-    if (colvalid && l == 0 && j < yLen) {
-      // the unit's lane 0 holds the complete sums of its column; emission rows belong to the destination column j+1 (context
-      // word index j); column yLen has no destination.  (Handing the five terms to five lanes by DPP so that they convert and add
-      // side by side measured the same: 17.4 vs 17.3 ms.)
-      const uint32_t er = wNext & 0x7FFFu;
-        uint32_t mk, q;
-        em_row_decode(a, er, mk, q);
-      const uint32_t ytok = ((wNext >> 15) & 0x1FFu) / (kNQualDev + 1);
-      if (q < (uint32_t)kNQualDev) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          fx_add(cnt + 2 * (cMat + ((uint64_t)c * Km + mk) * kNQualDev + q), wgt * (double)colsum[c]);
-        fx_add(cnt + 2 * (cIns + (uint64_t)ytok * kNQualDev + q), wgt * (double)colsum[4]);
-      }
+    // The column's sums do not go to the accumulators from here: that was ten global atomics and ~120 instructions per step
+    // issued for one lane in sixteen, 3.8 of this kernel's 15.4 ms (and three more fixed-point adds per LANE and step for the
+    // context-dependent transition counts, 0.8 ms).  Lane 0 leaves them in the Forward row of this step instead -- every lane of
+    // the band has just consumed it (a row is one step's cells, fetched a step ahead), and chunks 0 and 1 of it are lane 0's
+    // own -- as two 16-byte stores, and k_count_flush adds them up afterwards with every lane busy and an LDS table in front
+    // of the global accumulators.
+    if (colvalid && l == 0) {
+      float4* dst = (float4*)rowptr(j);
+      dst[0] = make_float4(colsum[0], colsum[1], colsum[2], colsum[3]);
+      dst[G] = make_float4(colsum[4], colsum[5], colsum[6], colsum[7]);
     }
-    wNext = w;
   }
   // context-free transitions, m2e and the Backward result (start), reduced over the unit's lanes
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -808,11 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 32 ? Q
     startv = lseh(hs, startv, __shfl_xor(startv, o, G));
     gkEnd = max(gkEnd, (uint32_t)__shfl_xor((int)gkEnd, o, G));
   }
-  if (GAPCTX) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t c = lane; c < 3 * Kg; c += 64) fx_add_words(cnt + 2 * (cTr + c), s_tr[2 * c], s_tr[2 * c + 1]);
-  } else if (active && l == 0) {
+  if (!GAPCTX && active && l == 0) {
     fx_add_total(cnt + 2 * (cTr + 0), wgt * acc_m2m);
     fx_add_total(cnt + 2 * (cTr + 1), wgt * acc_m2i);
     fx_add_total(cnt + 2 * (cTr + 2), wgt * acc_m2d);
@@ -1147,13 +1127,142 @@ __global__ __launch_bounds__(64) void k_backward_rows(FbArgs a) {
 }
 
 
-// dynamic LDS of the diagonal-space kernels: lse pieces | transition scores | (Backward, gap contexts) per-wavefront transition
+// ------------------------------------------------------------------------------------------------
+// The column sums k_backward_fill left in the Forward rows (lane 0's chunks 0 and 1 of row j - 1: match counts by reference
+// token[4], insert count, then the m2m, m2i, m2d counts of source column j) -> the count accumulators.  A workgroup takes
+// `upw` bands of the class, a thread per column, and ONE SLICE of the match-emission rows (`rps` rows: what fits its LDS; the
+// order-3 model of the bench has 2 560 rows in use, four slices): the terms of its slice meet in a fixed-point table in LDS,
+// and each entry the workgroup touched goes to the global accumulators once -- a few million global atomics per launch
+// instead of Backward's 173 M.  A column's context word says whose it is, so a record is read by the one workgroup that adds
+// it; slice 0 also takes the insert and context-dependent transition counts.  The terms are the same fixed-point ones as
+// ever (wgt x the fp32 column sum, fx_add): the totals do not depend on the order or on how the batch was cut.
+// rps == 0: straight to the global accumulators (tables too large to slice usefully).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kFlushThreads = 1024;   // the loop is a chain of dependent loads per column (context word -> record): wavefronts hide it, two workgroups fill a CU's 32
+constexpr uint32_t kFlushLdsMax = 46 * 1024, kFlushMaxSlices = 16, kFlushMaxUnits = 128;   // (kFlushMaxUnits: a power of two)
+__global__ __launch_bounds__(kFlushThreads) void k_count_flush(FbArgs a, int G, int row_chunks, int gapctx, uint32_t upw, uint32_t n_slices, uint32_t rps) {
+  extern __shared__ unsigned long long s_tab[];   // [rps x 4 match | 4 x 94 insert | 3 Kg transitions][2 words]
+  const uint32_t Kg = a.dp.Kg, Km = a.Km;
+  const uint32_t nI = 4 * kNQualDev, nT = gapctx ? 3 * Kg : 0;
+  const uint32_t slice = rps ? blockIdx.x % n_slices : 0, grp = rps ? blockIdx.x / n_slices : blockIdx.x;
+  const uint32_t erLo = slice * rps, nE = rps * 4, nAll = nE + (slice == 0 ? nI + nT : 0);
+  const bool tab = rps != 0, rest = slice == 0;   // rest: this workgroup adds the insert / transition counts
+  if (tab) {
+    for (uint32_t k = threadIdx.x; k < 2 * nAll; k += kFlushThreads) s_tab[k] = 0ull;
+    __syncthreads();
+  }
+  unsigned long long* __restrict__ cnt = a.counts + 2 * (size_t)(blockIdx.x % kCountReplicas) * a.counts_stride;
+  const uint64_t cIns = 0, cMat = 4ull * kNQualDev, cTr = (4ull + 4ull * Km) * kNQualDev;
+  // the workgroup's bands: offsets, weights and a prefix of their column counts in LDS, then one flat loop over all the columns
+  // (a loop per band had every thread walk the same chain of dependent loads -- list, unit, offsets, weight -- upw times over)
+  __shared__ uint64_t s_yb[kFlushMaxUnits], s_fw[kFlushMaxUnits];
+  __shared__ double s_wgt[kFlushMaxUnits];
+  __shared__ uint32_t s_pre[kFlushMaxUnits + 1];
+  if (threadIdx.x < upw) {
+    const uint32_t uidx = grp * upw + threadIdx.x;
+    uint32_t cols = 0;
+    if (uidx < a.n_cls_units) {
+      const Unit u = a.units[a.cls_list[uidx]];
+      const uint32_t r = u.pair / a.n_refs;
+      const uint64_t yb = a.read_off[r];
+      s_yb[threadIdx.x] = yb;
+      s_fw[threadIdx.x] = u.tb_off;
+      s_wgt[threadIdx.x] = a.pair_weight[u.pair];
+      if (u.staged) cols = (uint32_t)(a.read_off[r + 1] - yb);   // (not staged: pruned pair or negligible band, Backward did not run)
+    }
+    s_pre[threadIdx.x + 1] = cols;
+  }
+  if (threadIdx.x == 0) s_pre[0] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) for (uint32_t q = 0; q < upw; ++q) s_pre[q + 1] += s_pre[q];
+  __syncthreads();
+  const uint32_t total = s_pre[upw];
+  for (uint32_t cidx = threadIdx.x; cidx < total; cidx += kFlushThreads) {
+    uint32_t q = 0;
+    for (uint32_t step = kFlushMaxUnits / 2; step; step >>= 1)
+      if (q + step < upw && s_pre[q + step] <= cidx) q += step;
+    {
+      const int j = 1 + (int)(cidx - s_pre[q]), yLen = (int)(s_pre[q + 1] - s_pre[q]);
+      const double wgt = s_wgt[q];
+      const float4* __restrict__ fwrow = (const float4*)(a.fw + s_fw[q]);
+      const uint32_t* __restrict__ ctx = a.ctx + s_yb[q];
+      const float4* rec = fwrow + (uint64_t)(j - 1) * row_chunks * G;
+      float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rest) r1 = rec[G];
+      if (rest && gapctx) {
+        const uint32_t gk = ctx[j - 1] >> 24;   // context of source column j
+        if (tab) {
+          fx_add(s_tab + 2 * (nE + nI + gk), wgt * (double)r1.y);
+          fx_add(s_tab + 2 * (nE + nI + Kg + gk), wgt * (double)r1.z);
+          fx_add(s_tab + 2 * (nE + nI + 2 * Kg + gk), wgt * (double)r1.w);
+        } else {
+          fx_add(cnt + 2 * (cTr + gk), wgt * (double)r1.y);
+          fx_add(cnt + 2 * (cTr + Kg + gk), wgt * (double)r1.z);
+          fx_add(cnt + 2 * (cTr + 2 * Kg + gk), wgt * (double)r1.w);
+        }
+      }
+      if (j < yLen) {   // emission rows belong to the destination column j + 1 (context word index j); column yLen has none
+        const uint32_t wN = ctx[j], er = wN & 0x7FFFu;
+        uint32_t mk, qq;
+        em_row_decode(a, er, mk, qq);
+        if (qq < (uint32_t)kNQualDev) {
+          if (!tab || er - erLo < rps) {
+            const float4 r0 = rec[0];
+            const float m[4] = {r0.x, r0.y, r0.z, r0.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (tab) fx_add(s_tab + 2 * ((er - erLo) * 4 + c), wgt * (double)m[c]);
+              else fx_add(cnt + 2 * (cMat + ((uint64_t)c * Km + mk) * kNQualDev + qq), wgt * (double)m[c]);
+            }
+          }
+          if (rest) {
+            const uint32_t ytok = ((wN >> 15) & 0x1FFu) / (kNQualDev + 1);
+            if (tab) fx_add(s_tab + 2 * (nE + ytok * kNQualDev + qq), wgt * (double)r1.x);
+            else fx_add(cnt + 2 * (cIns + (uint64_t)ytok * kNQualDev + qq), wgt * (double)r1.x);
+          }
+        }
+      }
+    }
+  }
+  if (tab) {
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nAll; e += kFlushThreads) {
+      const unsigned long long w0 = s_tab[2 * e], w1 = s_tab[2 * e + 1];
+      if (!(w0 | w1)) continue;
+      uint64_t idx;
+      if (e < nE) {
+        uint32_t mk, qq;
+        em_row_decode(a, erLo + (e >> 2), mk, qq);
+        idx = cMat + ((uint64_t)(e & 3u) * Km + mk) * kNQualDev + qq;
+      } else if (e < nE + nI) idx = cIns + (e - nE);
+      else idx = cTr + (e - nE - nI);
+      fx_add_words(cnt + 2 * idx, w0, w1);
+    }
+  }
+}
+static void launch_count_flush(const FbArgs& a, int G, int B, hipStream_t s) {
+  const int gap = a.dp.Kg > 1;
+  const uint32_t rows = a.dp.ematch_ninf_off / 32, rest = 4 * kNQualDev + (gap ? 3 * a.dp.Kg : 0);
+  // rows per slice: what the LDS budget leaves beside the insert / transition entries (64 bytes per row)
+  uint32_t rps = rest * 16 < kFlushLdsMax ? (kFlushLdsMax - rest * 16) / 64 : 0;
+  rps = std::min(rps, rows);
+  uint32_t n_slices = rps ? (rows + rps - 1) / rps : 1;
+  if (n_slices > kFlushMaxSlices) { rps = 0; n_slices = 1; }
+  else if (rps) rps = (rows + n_slices - 1) / n_slices;   // equal slices
+  // bands per workgroup: what the global accumulators take per second is the bound (~10 G atomics/s measured: a workgroup's table
+  // is ~6 000 of them), so as many bands as still leave one round of workgroups for the chip (two fit a CU)
+  const uint32_t upw = std::max<uint32_t>(4, std::min<uint32_t>(kFlushMaxUnits, (uint32_t)((uint64_t)a.n_cls_units * n_slices / 512)));
+  const uint32_t blocks = (a.n_cls_units + upw - 1) / upw * n_slices;
+  const size_t lds = rps ? ((size_t)rps * 4 + rest) * 16 : 0;
+  hipLaunchKernelGGL(k_count_flush, dim3(blocks), dim3(kFlushThreads), lds, s, a, G, fw_row_floats(B) / 4, gap, upw, n_slices, rps);
+}
+
+// dynamic LDS of the diagonal-space kernels: lse pieces | transition scores | (Backward) the lanes' context-free transition
 // counts | (EMLDS) emission tables.  The emission tables go to LDS when three workgroups still fit a CU (<= 52 KB each).
 static uint32_t fb_lds_bytes(const FbArgs& a, bool backward, bool& emlds) {
   const uint32_t Kg = a.dp.Kg;
   uint32_t d = kLseDoubles + ((4 * Kg + 1) & ~1u);
   if (backward) d += 4 * 4 * 64;
-  if (backward && Kg > 1) d += 4 * 3 * Kg * 2;
   const uint32_t em = a.dp.ematch_ninf_off / 8 + 4 + kInsRows;
   emlds = (d + em) * 8 <= (a.lds_limit ? a.lds_limit : 48u * 1024u);
   return (d + (emlds ? em : 0)) * 8;
@@ -1187,6 +1296,7 @@ static void launch_bwd_gb(const FbArgs& a, hipStream_t s) {
   else if (gap) hipLaunchKernelGGL((k_backward_fill<G, B, true, false>), dim3(blocks), dim3(256), lds, s, a);
   else if (emlds) hipLaunchKernelGGL((k_backward_fill<G, B, false, true>), dim3(blocks), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((k_backward_fill<G, B, false, false>), dim3(blocks), dim3(256), lds, s, a);
+  launch_count_flush(a, G, B, s);
 }
 #define QF_FB_DISPATCH(FN)                         \
   switch (cls) {                                   \

@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_units(SeedArgs a, uint32_t 
   u.cls = (uint32_t)cls;
   u.end2_val = QF_NEG_INF;
   u.end2_j = 0;
-  u.pad_ = 0;
+  u.staged = 0;
   u.next = atomicExch(&a.pair_head[pair], uid);
   a.units[uid] = u;
   atomicAdd(&a.pair_cells[pair], cells);
