@@ -102,6 +102,7 @@ struct Slot {
   hipEvent_t ev[8] = {};   // [6]: pair results final (their copy to the host overlaps selection and traceback); [7]: class lists final
   hipEvent_t cls_ev[kNumClasses] = {}, cls_end[kNumClasses] = {};  // per fill class, on the stream the class runs on
   hipEvent_t cls_ev2[kNumClasses] = {}, cls_end2[kNumClasses] = {};   // E-step: the Backward kernels (cls_ev / cls_end time Forward)
+  hipEvent_t ev_split[2] = {};                                         // E-step: the dominant class's Backward in two parts (count_chunk)
   hipStream_t aux[3] = {};                                         // side streams: fill classes run concurrently
   hipStream_t hi[3] = {};                                          // high priority: classes too small to fill the chip (latency-bound chains)
   DevBuf d_units, d_cls_list, d_pair_head, d_pair_bands, d_pair_nbands, d_ovf, d_pair_ndiag, d_pair_cells, d_pair_score,
@@ -120,6 +121,7 @@ struct Slot {
     for (auto& e : cls_end) (void)hipEventCreate(&e);
     for (auto& e : cls_ev2) (void)hipEventCreate(&e);
     for (auto& e : cls_end2) (void)hipEventCreate(&e);
+    for (auto& e : ev_split) (void)hipEventCreate(&e);
     // side streams at the lowest priority: the small fill classes they carry should fill the gaps of the dominant class
     // (main stream), not compete with it
     int least = 0, greatest = 0;
@@ -140,6 +142,7 @@ struct Slot {
     for (auto& e : cls_end) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_ev2) if (e) (void)hipEventDestroy(e);
     for (auto& e : cls_end2) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_split) if (e) (void)hipEventDestroy(e);
     for (auto& s : aux) if (s) (void)hipStreamDestroy(s);
     for (auto& s : hi) if (s) (void)hipStreamDestroy(s);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1600,11 +1603,29 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
   HIPCHK(S, hipEventRecord(S->ev[4], S->stream));
 
   // ---- Backward + counts
+  // The class with the most cells sets the length of the phase, and what follows its last wavefront is exposed: k_count_flush
+  // over all its bands (1 ms of the bench's 26).  Its first three quarters go to a high-priority stream as a launch of their own:
+  // they are dispatched first and done first, and their flush runs beside the last quarter's Backward, whose own flush is short.
+  int big_cls = -1;
+  for (int cls = 0; cls < kNumClasses; ++cls)
+    if (bc.cls_count[cls] && cls != kRowClass && (big_cls < 0 || bc.cls_cells[cls] > bc.cls_cells[big_cls])) big_cls = cls;
   if (int rc = launch_classes_concurrently(S, bc, serial_classes, [&](int cls, hipStream_t s) {
         FbArgs f2 = fa;
         f2.n_cls_units = bc.cls_count[cls];
         f2.cls_list = S->d_cls_list.as<uint32_t>() + (size_t)cls * max_units;
-        launch_backward_fill(cls, f2, s);
+        const uint32_t tail = cls == big_cls && !serial_classes && f2.n_cls_units >= 8192 && !(c->debug & QF_DEBUG_NO_BACKWARD_SPLIT) ? f2.n_cls_units / 4 : 0;
+        if (tail) {
+          const uint32_t head = f2.n_cls_units - tail;
+          (void)hipEventRecord(S->ev_split[0], s);
+          (void)hipStreamWaitEvent(S->hi[2], S->ev_split[0], 0);
+          f2.n_cls_units = head;
+          launch_backward_fill(cls, f2, S->hi[2]);
+          (void)hipEventRecord(S->ev_split[1], S->hi[2]);
+          f2.cls_list += head;
+          f2.n_cls_units = tail;
+          launch_backward_fill(cls, f2, s);
+          (void)hipStreamWaitEvent(s, S->ev_split[1], 0);
+        } else launch_backward_fill(cls, f2, s);
       }, 0, true, S->cls_ev2, S->cls_end2))
     return rc;
   HIPCHK(S, hipGetLastError());
