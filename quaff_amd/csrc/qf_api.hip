@@ -2570,8 +2570,8 @@ int qf_overlap_rows(qf_ctx* c, const qf_dp_config* cfg, uint32_t n_originals, ui
   if (!c->ov_block_pairs) {
     uint64_t total = 0;
     for (uint32_t x = x0; x < x1; ++x) total += n_seqs - 1 - x;
-    const uint64_t nb = std::max<uint64_t>(1, (total + want / 2) / want);
-    want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want + want / 2);   // (+ a row: the cut falls on a row boundary)
+    const uint64_t nb = (total + want - 1) / want;                       // (never above 2^24: the buffers of a block are sized for that)
+    if (nb > 1) want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want);   // (+ a row: the cut falls on a row boundary)
   }
   std::vector<uint64_t> row_start;
   for (uint32_t b0 = x0; b0 < x1;) {

@@ -4,6 +4,9 @@
 // formats (Stockholm, gapped FASTA, SAM, refseq; params / counts JSON), so that it is a drop-in for the hot path.
 // All DP runs on the GPU through the C ABI (include/quaff_hip.h); this file is host plumbing only.  Not provided:
 // remote/ssh/EC2/qsub execution, logging levels (-v* are accepted and ignored); -threads only divides -kmatchmax's memory.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -20,6 +23,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <string_view>
+#include <iterator>
 #include <thread>
 #include <vector>
 #include <chrono>
@@ -35,8 +40,13 @@
 using namespace std;
 using namespace qf;
 
+// (EarlySession below: the device contexts come up on a thread of their own while the input is parsed; the process must not run
+// its exit handlers under that thread's feet)
+static std::shared_future<void>* g_background = nullptr;
+static thread_local bool t_in_background = false;
 [[noreturn]] static void Fail(const string& msg) {  // Fail(), src/util.cpp:89-98
   cerr << msg << endl;
+  if (g_background && g_background->valid() && !t_in_background) g_background->wait();
   exit(EXIT_FAILURE);
 }
 #define Require(cond, msg) do { if (!(cond)) Fail(msg); } while (0)
@@ -57,8 +67,42 @@ struct Coords {  // SeqIntervalCoords, src/fastseq.h:29-39
     return c;
   }
 };
+// A sequence or quality string: its own storage, or a view of the input file as it lies mapped in memory (`keep` holds the
+// mapping).  A FASTQ record whose sequence and quality sit on one line each -- every record of a sequencer's file -- is never
+// copied: building 200 000 strings for the 100 k reads of config 2 was 0.2 s of page faults, five device calls' worth.
+class Text {
+  const char* p_ = nullptr;
+  size_t n_ = 0;
+  bool owned_ = false;
+  string own_;
+  std::shared_ptr<const void> keep_;
+  void fix() { if (owned_) { p_ = own_.data(); n_ = own_.size(); } }
+ public:
+  Text() = default;
+  Text(const Text& o) : p_(o.p_), n_(o.n_), owned_(o.owned_), own_(o.own_), keep_(o.keep_) { fix(); }
+  Text(Text&& o) noexcept : p_(o.p_), n_(o.n_), owned_(o.owned_), own_(std::move(o.own_)), keep_(std::move(o.keep_)) { fix(); o.clear(); }
+  Text& operator=(const Text& o) { if (this != &o) { p_ = o.p_; n_ = o.n_; owned_ = o.owned_; own_ = o.own_; keep_ = o.keep_; fix(); } return *this; }
+  Text& operator=(Text&& o) noexcept {
+    if (this != &o) { p_ = o.p_; n_ = o.n_; owned_ = o.owned_; own_ = std::move(o.own_); keep_ = std::move(o.keep_); fix(); o.clear(); }
+    return *this;
+  }
+  Text& operator=(string t) { own_ = std::move(t); owned_ = true; keep_.reset(); fix(); return *this; }
+  void view(const char* p, size_t n, std::shared_ptr<const void> keep) { own_.clear(); owned_ = false; p_ = p; n_ = n; keep_ = std::move(keep); }
+  void clear() { own_.clear(); owned_ = false; p_ = nullptr; n_ = 0; keep_.reset(); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  const char* data() const { return p_; }
+  const char* begin() const { return p_; }
+  const char* end() const { return p_ + n_; }
+  char operator[](size_t i) const { return p_[i]; }
+  operator std::string_view() const { return std::string_view(p_, n_); }
+  string str() const { return string(p_, n_); }
+  string substr(size_t pos, size_t len) const { return pos >= n_ ? string() : string(p_ + pos, std::min(len, n_ - pos)); }
+};
+static ostream& operator<<(ostream& o, const Text& t) { return o.write(t.data(), (std::streamsize)t.size()); }
 struct FastSeq {
-  string name, comment, seq, qual;
+  string name, comment;
+  Text seq, qual;
   Coords source;
   bool hasQual() const { return qual.size() == seq.size(); }
 };
@@ -70,9 +114,10 @@ static FastSeq revcomp(const FastSeq& s) {  // FastSeq::revcomp, src/fastseq.cpp
   FastSeq r;
   r.name = "revcomp(" + s.name + ")";
   r.comment = s.comment;
-  r.seq.resize(s.seq.size());
-  for (size_t i = 0; i < s.seq.size(); ++i) r.seq[s.seq.size() - 1 - i] = complementChar(s.seq[i]);
-  r.qual = string(s.qual.rbegin(), s.qual.rend());
+  string rs(s.seq.size(), ' ');
+  for (size_t i = 0; i < s.seq.size(); ++i) rs[s.seq.size() - 1 - i] = complementChar(s.seq[i]);
+  r.seq = std::move(rs);
+  r.qual = string(std::make_reverse_iterator(s.qual.end()), std::make_reverse_iterator(s.qual.begin()));
   Coords c;
   c.name = s.name; c.start = 1; c.end = (unsigned)s.seq.size(); c.rev = true;
   r.source = c.compose(s.source);
@@ -86,52 +131,133 @@ static void writeFasta(ostream& out, const FastSeq& s) {
 
 // FASTA / FASTQ reader with kseq's conventions (kseq/kseq.h, src/fastseq.cpp:133-171): name up to the first blank,
 // rest of the header line is the comment, multi-line sequence, quality kept only when as long as the sequence.
+// Three passes over the file in memory (config 2's device call takes 40 ms; a 200 MB FASTQ of 100 k reads parsed by one
+// thread with a string per field took 430): (1) the lines, by memchr; (2) the records -- which line is a header, which lines
+// are its sequence and its quality: the one sequential decision, and it reads only first characters and lengths; (3) the
+// strings, built by up to eight threads, a block of records each.
 static vector<FastSeq> readFastSeqs(const string& filename) {
-  gzFile fp = gzopen(filename.c_str(), "r");
-  Require(fp != Z_NULL, "Couldn't open " + filename);
-  string data;
-  char buf[1 << 16];
-  int n;
-  while ((n = gzread(fp, buf, sizeof buf)) > 0) data.append(buf, n);
-  gzclose(fp);
-  vector<FastSeq> seqs;
-  // lines are (begin, end) ranges of `data`: nothing is copied but the fields themselves (a 200 MB FASTQ of 100 k reads parsed
-  // at 0.5 GB/s with a string per line and a character at a time; config 2's device call takes 40 ms)
-  size_t p = 0, lb = 0, le = 0;
-  auto line = [&]() -> bool {
-    if (p >= data.size()) return false;
-    const char* nl = (const char*)memchr(data.data() + p, '\n', data.size() - p);
-    size_t e = nl ? (size_t)(nl - data.data()) : data.size();
-    lb = p;
-    le = e;
-    if (le > lb && data[le - 1] == '\r') --le;
-    p = e + 1;
-    return true;
+  // the bytes: the file mapped as it lies in the page cache, or inflated by zlib when it is gzipped (or cannot be mapped)
+  struct Mapping {
+    void* p = MAP_FAILED;
+    size_t n = 0;
+    string inflated;
+    ~Mapping() { if (p != MAP_FAILED) munmap(p, n); }
   };
-  auto first = [&]() -> char { return le > lb ? data[lb] : '\0'; };
-  bool have = line();
-  while (have) {
-    if (first() != '>' && first() != '@') { have = line(); continue; }
-    FastSeq s;
-    size_t sp = lb + 1;
-    while (sp < le && data[sp] != ' ' && data[sp] != '\t') ++sp;
-    s.name.assign(data, lb + 1, sp - lb - 1);
-    if (sp < le) s.comment.assign(data, sp + 1, le - sp - 1);
-    have = line();
-    while (have && !(first() == '>' || first() == '@' || first() == '+')) {
-      bool blank = false;
-      for (size_t q = lb; q < le && !blank; ++q) blank = isspace((unsigned char)data[q]) != 0;
-      if (!blank) s.seq.append(data, lb, le - lb);
-      else for (size_t q = lb; q < le; ++q) if (!isspace((unsigned char)data[q])) s.seq += data[q];
-      have = line();
+  const auto keep = std::make_shared<Mapping>();   // lives as long as a record still views it
+  Mapping& map = *keep;
+  string& inflated = map.inflated;
+  const char* d = nullptr;
+  size_t n = 0;
+  {
+    const int fd = open(filename.c_str(), O_RDONLY);
+    Require(fd >= 0, "Couldn't open " + filename);
+    unsigned char magic[2] = {0, 0};
+    const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    struct stat st;
+    if (!gz && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      map.p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+      if (map.p != MAP_FAILED) { map.n = n = (size_t)st.st_size; d = (const char*)map.p; }
     }
-    if (have && first() == '+') {
-      have = line();
-      while (have && s.qual.size() < s.seq.size()) { s.qual.append(data, lb, le - lb); have = line(); }
-      if (s.qual.size() != s.seq.size()) s.qual.clear();
+    close(fd);
+    if (!d) {
+      gzFile fp = gzopen(filename.c_str(), "r");
+      Require(fp != Z_NULL, "Couldn't open " + filename);
+      (void)gzbuffer(fp, 1 << 20);
+      vector<char> buf(1 << 20);
+      int m;
+      while ((m = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) inflated.append(buf.data(), m);
+      gzclose(fp);
+      d = inflated.data();
+      n = inflated.size();
     }
-    seqs.push_back(std::move(s));
   }
+  // (1) lines: [begin, end) without the newline and a trailing carriage return
+  vector<std::pair<size_t, size_t>> lines;
+  lines.reserve(n / 64 + 16);
+  for (size_t p = 0; p < n;) {
+    const char* nl = (const char*)memchr(d + p, '\n', n - p);
+    const size_t e = nl ? (size_t)(nl - d) : n;
+    size_t le = e;
+    if (le > p && d[le - 1] == '\r') --le;
+    lines.push_back({p, le});
+    p = e + 1;
+  }
+  // a line's length without white space; every isspace() character is <= ' ', sequence and quality characters are not: eight
+  // bytes at a time, "has a byte below 0x21" = (w - 0x21 x ones) & ~w & (0x80 x ones)
+  auto blanks = [&](size_t k) -> bool {
+    size_t q = lines[k].first;
+    const size_t e = lines[k].second;
+    for (; q + 8 <= e; q += 8) {
+      uint64_t w;
+      memcpy(&w, d + q, 8);
+      if ((w - 0x2121212121212121ull) & ~w & 0x8080808080808080ull) return true;
+    }
+    for (; q < e; ++q) if ((unsigned char)d[q] <= (unsigned char)' ') return true;
+    return false;
+  };
+  auto seqLength = [&](size_t k) -> size_t {
+    if (!blanks(k)) return lines[k].second - lines[k].first;
+    size_t len = 0;
+    for (size_t q = lines[k].first; q < lines[k].second; ++q) len += !isspace((unsigned char)d[q]);
+    return len;
+  };
+  auto first = [&](size_t k) -> char { return lines[k].second > lines[k].first ? d[lines[k].first] : '\0'; };
+  // (2) records
+  struct Rec { size_t name, seq0, seq1, qual0, qual1, seqLen; bool qualOk; };
+  vector<Rec> recs;
+  const size_t nl = lines.size();
+  for (size_t k = 0; k < nl;) {
+    if (first(k) != '>' && first(k) != '@') { ++k; continue; }
+    Rec r{k, k + 1, k + 1, 0, 0, 0, false};
+    ++k;
+    while (k < nl && !(first(k) == '>' || first(k) == '@' || first(k) == '+')) { r.seqLen += seqLength(k); ++k; }
+    r.seq1 = r.qual0 = r.qual1 = k;
+    if (k < nl && first(k) == '+') {
+      ++k;
+      r.qual0 = k;
+      size_t qlen = 0;
+      while (k < nl && qlen < r.seqLen) { qlen += lines[k].second - lines[k].first; ++k; }
+      r.qual1 = k;
+      r.qualOk = qlen == r.seqLen;
+    }
+    recs.push_back(r);
+  }
+  // (3) strings
+  vector<FastSeq> seqs(recs.size());
+  auto build = [&](size_t lo, size_t hi) {
+    for (size_t x = lo; x < hi; ++x) {
+      const Rec& r = recs[x];
+      FastSeq& s = seqs[x];
+      const size_t lb = lines[r.name].first, le = lines[r.name].second;
+      size_t sp = lb + 1;
+      while (sp < le && d[sp] != ' ' && d[sp] != '\t') ++sp;
+      s.name.assign(d + lb + 1, sp - lb - 1);
+      if (sp < le) s.comment.assign(d + sp + 1, le - sp - 1);
+      // one line of sequence without blanks (one line of quality): a view of the file; anything else is put together
+      if (r.seq1 == r.seq0 + 1 && lines[r.seq0].second - lines[r.seq0].first == r.seqLen) s.seq.view(d + lines[r.seq0].first, r.seqLen, keep);
+      else {
+        string t;
+        t.reserve(r.seqLen);
+        for (size_t k = r.seq0; k < r.seq1; ++k) {
+          if (!blanks(k)) t.append(d + lines[k].first, lines[k].second - lines[k].first);
+          else for (size_t q = lines[k].first; q < lines[k].second; ++q) if (!isspace((unsigned char)d[q])) t += d[q];
+        }
+        s.seq = std::move(t);
+      }
+      if (r.qualOk && r.qual1 == r.qual0 + 1) s.qual.view(d + lines[r.qual0].first, r.seqLen, keep);
+      else if (r.qualOk) {
+        string t;
+        t.reserve(r.seqLen);
+        for (size_t k = r.qual0; k < r.qual1; ++k) t.append(d + lines[k].first, lines[k].second - lines[k].first);
+        s.qual = std::move(t);
+      }
+    }
+  };
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), recs.size() / 512 + 1}));
+  vector<std::thread> th;
+  for (size_t t = 1; t < T; ++t) th.emplace_back(build, recs.size() * t / T, recs.size() * (t + 1) / T);
+  build(0, recs.size() / T);
+  for (auto& t : th) t.join();
   if (seqs.empty()) cerr << "Warning: Couldn't read any sequences from " << filename << endl;
   return seqs;
 }
@@ -162,13 +288,13 @@ struct Hit {
   }
   // the side's bases (or quality characters) laid out over the alignment columns, `gap` where the side has none
   string laidOut(int side, bool quality, char gap) const {
-    const string& text = quality ? src[side]->qual : src[side]->seq;
+    const Text& text = quality ? src[side]->qual : src[side]->seq;
     string out;
     out.reserve(columns());
     size_t at = lo[side] - 1;
     for (uint32_t r : runs) {
       const uint32_t len = r >> 2;
-      if (consumes(side, r & 3u)) { out.append(text, at, len); at += len; }
+      if (consumes(side, r & 3u)) { out.append(text.data() + at, len); at += len; }
       else out.append(len, gap);
     }
     return out;
@@ -470,8 +596,8 @@ static void packSeqs(const vector<FastSeq>& v, size_t lo, size_t hi, string& seq
   allQual = true;
   for (size_t n = lo; n < hi; ++n) allQual = allQual && v[n].hasQual() && !v[n].qual.empty();
   for (size_t n = lo; n < hi; ++n) {
-    seq += v[n].seq;
-    if (allQual) qual += v[n].qual;
+    seq.append(v[n].seq.data(), v[n].seq.size());
+    if (allQual) qual.append(v[n].qual.data(), v[n].qual.size());
     off.push_back(seq.size());
   }
 }
@@ -538,7 +664,7 @@ struct Session {
       for (qf_ctx* c : ctxs) QF(c, qf_set_null_json(c, text.c_str()));
     } else {
       vector<string> s, q;
-      for (const auto& r : reads) { s.push_back(r.seq); q.push_back(r.qual); }
+      for (const auto& r : reads) { s.push_back(r.seq.str()); q.push_back(r.qual.str()); }
       null = fit_null(s, q);
       double pqr[12];
       for (int i = 0; i < 4; ++i) { pqr[i * 3] = null.null[i].p; pqr[i * 3 + 1] = null.null[i].q; pqr[i * 3 + 2] = null.null[i].r; }
@@ -549,10 +675,23 @@ struct Session {
   void setRefs(const vector<FastSeq>& x) {
     string s;
     vector<uint64_t> off(1, 0);
-    for (const auto& fs : x) { s += fs.seq; off.push_back(s.size()); }
+    for (const auto& fs : x) { s.append(fs.seq.data(), fs.seq.size()); off.push_back(s.size()); }
     for (qf_ctx* c : ctxs) QF(c, qf_set_refs(c, s.data(), off.data(), (uint32_t)x.size()));
   }
 };
+
+// The device contexts (HIP start-up, streams, the library's tables: ~0.15 s) created while the main thread reads the input.
+struct EarlySession {
+  std::shared_future<void> done;
+  std::unique_ptr<Session> s;
+  explicit EarlySession(const Opts& o) {
+    done = std::async(std::launch::async, [this, &o] { t_in_background = true; s.reset(new Session(o)); }).share();
+    g_background = &done;
+  }
+  Session& get() { done.get(); g_background = nullptr; return *s; }
+  ~EarlySession() { if (done.valid()) done.wait(); g_background = nullptr; }
+};
+
 
 // a read-to-reference alignment as `quaff align` labels it (QuaffViterbiMatrix::alignment, src/qmodel.cpp:1623-1645)
 static Hit makeAlignment(const FastSeq& x, const FastSeq& y, const qf_alignment& al, const uint32_t* runs, bool local) {
@@ -584,12 +723,13 @@ static int cmdAlign(Opts& o) {
          o.parseUnknown()) {}
   o.finishConfig();
   PhaseClock clk;
+  EarlySession early(o);
   SeqSet reads, refs;
   clk.time("parse", [&] {
     reads.load(o.readFiles, "read", "-read", !o.noquals, false, true);
     refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, true);
   });
-  Session s(o);
+  Session& s = early.get();
   s.loadParams(o);
   clk.time("null_model", [&] { s.loadNull(o, reads.seqs); });
   s.setRefs(refs.seqs);
@@ -756,11 +896,12 @@ static int cmdTrainOrCount(Opts& o, bool training) {
   while (o.parseLog() || parseTrainArgs(o, training, maxIter, minInc, maxReadBases, allowNull, rawCounts, countsWithPriorFile, saveParams) ||
          o.parseConfig(true) || o.parseFiles(true) || parsePrior() || o.parseUnknown()) {}
   o.finishConfig();
+  o.wantComm = true;
+  EarlySession early(o);
   SeqSet reads, refs;
   reads.load(o.readFiles, "read", "-read", true, false, false);
   refs.load(o.refFiles, "reference", "-ref", false, !o.fwdstrand, false);
-  o.wantComm = true;
-  Session s(o);
+  Session& s = early.get();
   s.loadNull(o, reads.seqs);
   if (!training) {
     s.loadParams(o);
@@ -865,9 +1006,10 @@ static int cmdOverlap(Opts& o) {
          o.parseUnknown()) {}
   o.finishConfig();
   PhaseClock clk;
+  EarlySession early(o);
   SeqSet reads;
   clk.time("parse", [&] { reads.load(o.readFiles, "read", "-read", !o.noquals, !o.fwdstrand, true); });
-  Session s(o);
+  Session& s = early.get();
   s.loadParams(o);
   clk.time("null_model", [&] { s.loadNull(o, reads.seqs); });
   s.setThreshold(pr.threshold);
@@ -938,7 +1080,11 @@ static int cmdSelfTest(deque<string>& av) {
   auto parsed = [&](const string& file) { Json j; string err; if (!parse_json(slurp(file), j, err)) Fail("Couldn't parse " + file + ": " + err); return j; };
   if (what == "fasta" || what == "fastq") {
     Require(av.size() == 1, "selftest " + what + " <seqs>");
-    for (const FastSeq& fs : readFastSeqs(av[0])) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const vector<FastSeq> all = readFastSeqs(av[0]);
+    if (getenv("QUAFF_HIP_TIMING"))
+      cerr << "{\"quaff_hip_timing\": \"selftest\", \"parse_s\": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "}" << endl;
+    for (const FastSeq& fs : all) {
       if (what == "fasta") writeFasta(cout, fs);
       else {   // FastSeq::writeFastq, src/fastseq.cpp:119-127
         cout << '@' << fs.name;

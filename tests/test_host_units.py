@@ -42,6 +42,80 @@ def test_gzipped_input_reads_like_plain(tmp_path):
     assert selftest("fastq", os.path.join(GOLDEN, "c8f30.fastq.gz")) == selftest("fastq", str(plain)) == plain.read_text()
 
 
+def _kseq_records(text):
+    """kseq's conventions (kseq/kseq.h; src/fastseq.cpp:133-171), restated independently of the C++ reader: a header starts with
+    '>' or '@' (other lines before one are skipped); name = up to the first blank, comment = the rest; sequence lines run to the
+    next line starting with '>', '@' or '+', white space dropped; after '+', quality lines are taken until they hold as many
+    characters as the sequence, and kept only if exactly as many."""
+    lines = [ln[:-1] if ln.endswith("\r") else ln for ln in text.split("\n")]
+    if lines and lines[-1] == "":
+        lines.pop()
+    recs, k = [], 0
+    while k < len(lines):
+        if lines[k][:1] not in (">", "@"):
+            k += 1
+            continue
+        head = lines[k][1:]
+        cut = min([head.index(c) for c in " \t" if c in head] or [len(head)])
+        name, comment = head[:cut], head[cut + 1:]
+        k += 1
+        seq = ""
+        while k < len(lines) and lines[k][:1] not in (">", "@", "+"):
+            seq += "".join(lines[k].split())
+            k += 1
+        qual = ""
+        if k < len(lines) and lines[k][:1] == "+":
+            k += 1
+            while k < len(lines) and len(qual) < len(seq):
+                qual += lines[k]
+                k += 1
+            if len(qual) != len(seq):
+                qual = ""
+        recs.append((name, comment, seq, qual))
+    return recs
+
+
+def test_reader_edge_cases_across_threads(tmp_path):
+    """The reader builds its strings in blocks of records on several threads: 6 000 records of every awkward shape (CR LF, wrapped
+    sequence and quality, blanks inside sequence lines, quality lines that start with '@' or '+', a missing quality, a short
+    quality, FASTA records in between, junk before the first header, no newline at the end) must come out as kseq's rules say."""
+    import random
+    rng = random.Random(11)
+    parts = ["junk before any header\n", "\n"]
+    for r in range(6000):
+        L = rng.choice([0, 1, 7, 60, 61, 200])
+        seq = "".join(rng.choice("ACGTN") for _ in range(L))
+        qual = "".join(chr(rng.randrange(33, 127)) for _ in range(L))
+        if L and r % 5 == 0:
+            qual = "@" + qual[1:]                                  # a quality line that looks like a header
+        if L and r % 7 == 0:
+            qual = "+" + qual[1:]
+        eol = "\r\n" if r % 3 == 0 else "\n"
+        wrap = rng.choice([0, 0, 13, 60])
+        def wrapped(t):
+            return eol.join(t[i:i + wrap] for i in range(0, len(t), wrap)) if wrap and t else t
+        head = "read%d" % r + (rng.choice(["", " a comment", "\ttabbed comment here"]))
+        kind = r % 11
+        if kind == 0:                                              # FASTA
+            parts.append(">" + head + eol + wrapped(seq) + eol)
+        elif kind == 1 and L > 2:                                  # blanks inside a sequence line
+            parts.append("@" + head + eol + seq[:2] + " " + seq[2:] + "\t" + eol + "+" + eol + qual + eol)
+        elif kind == 2 and L > 1:                                  # quality one character short: dropped
+            parts.append("@" + head + eol + seq + eol + "+" + eol + qual[:-1] + eol)
+        elif kind == 3:                                            # '+' line repeats the name
+            parts.append("@" + head + eol + wrapped(seq) + eol + "+read%d" % r + eol + wrapped(qual) + eol)
+        else:
+            parts.append("@" + head + eol + wrapped(seq) + eol + "+" + eol + wrapped(qual) + eol)
+    text = "".join(parts) + "@last\nACGT\n+\nIIII"           # no newline at the end
+    f = tmp_path / "edge.fastq"
+    f.write_bytes(text.encode())
+    got = selftest("fastq", str(f))
+    # an empty sequence "has quality" of equal (zero) length: the writer prints "+" and an empty line for it
+    want = "".join("@" + n + (" " + c if c else "") + "\n" + s + "\n" + ("+\n" + q + "\n" if len(q) == len(s) else "")
+                   for n, c, s, q in _kseq_records(text))
+    assert got == want
+
+
 @pytest.mark.parametrize("what,name", [("params", "testquaffparams.json"), ("params", "defaultparams.json"),   # Makefile:118-119
                                        ("null", "testquaffnullparams.json"), ("counts", "testquaffcounts.json")])  # :122, :125
 def test_json_round_trips(what, name):
