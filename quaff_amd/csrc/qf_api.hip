@@ -30,12 +30,15 @@ using namespace qf;
 namespace {
 std::string g_create_error;
 
+// microseconds this process has spent in hipFree / hipMalloc growing device buffers (qf_debug_alloc_ms: the CLI's timing line)
+static std::atomic<uint64_t> g_alloc_us{0};
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   template <class T> T* as() const { return (T*)p; }
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -46,6 +49,7 @@ struct DevBuf {
       e = hipMalloc(&p, want);
     }
     if (e == hipSuccess) cap = want; else p = nullptr;
+    g_alloc_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     return e;
   }
   void release() {
@@ -1270,6 +1274,7 @@ uint32_t qf_debug_pack_lse_table(uint8_t* out, uint32_t cap) {
   return (uint32_t)pack.size();
 }
 uint64_t qf_debug_rows_settled(const qf_ctx* c) { return c ? c->rows_settled : 0; }
+double qf_debug_alloc_ms(void) { return (double)g_alloc_us.load() * 1e-3; }
 uint32_t qf_debug_lse_pack_bytes(qf_ctx* c) {
   if (!c || hipSetDevice(c->device) != hipSuccess || ensure_lse(c) != QF_OK) return 0;
   return c->lse_pack_bytes;
@@ -2570,8 +2575,11 @@ int qf_overlap_rows(qf_ctx* c, const qf_dp_config* cfg, uint32_t n_originals, ui
   if (!c->ov_block_pairs) {
     uint64_t total = 0;
     for (uint32_t x = x0; x < x1; ++x) total += n_seqs - 1 - x;
-    const uint64_t nb = (total + want - 1) / want;                       // (never above 2^24: the buffers of a block are sized for that)
-    if (nb > 1) want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want);   // (+ a row: the cut falls on a row boundary)
+    // (a block may pass 2^24 pairs by a sixteenth if that saves one: 4.2 x 2^24 pairs are four blocks, not five; never by more --
+    // a block's traceback has to fit the memory budget, and a block cut in two for that loses the triangle's fast paths)
+    uint64_t nb = total / want;
+    if (!nb || (total + nb - 1) / nb > want + want / 16) nb = (total + want - 1) / want;
+    if (nb > 1) want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want + want / 16);   // (+ a row: the cut falls on a row boundary)
   }
   std::vector<uint64_t> row_start;
   for (uint32_t b0 = x0; b0 < x1;) {

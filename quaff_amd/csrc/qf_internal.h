@@ -41,6 +41,7 @@ uint32_t qf_debug_pack_lse_table(uint8_t *out, uint32_t cap);
 uint32_t qf_debug_lse_pack_bytes(qf_ctx *ctx);
 /* Pairs of the last qf_overlap_resident call that the seeding's row prefilter settled (given their single forced diagonal without
  * the per-pair kernel); counted only under QF_DEBUG_COUNT_SETTLED. */
+double qf_debug_alloc_ms(void);   /* milliseconds spent growing device buffers (hipFree + hipMalloc) in this process */
 uint64_t qf_debug_rows_settled(const qf_ctx *ctx);
 
 /* fp64 vector add lane-operations per second this device sustains (a 5 ms microbenchmark: 8 independent v_add_f64 chains per wavefront,

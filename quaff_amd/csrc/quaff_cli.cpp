@@ -34,6 +34,7 @@
 #include <mutex>
 
 #include "../../include/quaff_hip.h"
+extern "C" double qf_debug_alloc_ms(void);   // qf_internal.h: time this process spent growing device buffers
 #include "qf_em.hpp"
 #include "qf_model.hpp"
 
@@ -586,6 +587,7 @@ struct PhaseClock {
     std::ostringstream o;
     o << "{\"quaff_hip_timing\": \"" << cmd << "\", \"wall_s\": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (const auto& kv : sec) o << ", \"" << kv.first << "_s\": " << kv.second;
+    o << ", \"device_alloc_s\": " << qf_debug_alloc_ms() * 1e-3;
     o << "}";
     std::cerr << o.str() << std::endl;
   }
@@ -1044,7 +1046,13 @@ static int cmdOverlap(Opts& o) {
       qf_overlap_rows_result res;
       double t = PhaseClock::now();
       QFT(c, qf_overlap_rows(c, &o.cfg, (uint32_t)N, blocks[r0 + k].x0, blocks[r0 + k].x1, &res));
-      if (!k) { clk.add("device_call", PhaseClock::now() - t); clk.add("device_ms_reported", res.ms_total * 1e-3); }
+      if (!k) {
+        clk.add("device_call", PhaseClock::now() - t);
+        clk.add("device_ms_reported", res.ms_total * 1e-3);
+        clk.add("device_seed", res.ms_seed * 1e-3);
+        clk.add("device_fill", res.ms_fill * 1e-3);
+        clk.add("device_traceback", res.ms_traceback * 1e-3);
+      }
       t = PhaseClock::now();
       for (uint32_t a = 0; a < res.n_hits; ++a) {
         const qf_overlap_hit& h = res.hits[a];
