@@ -2579,7 +2579,7 @@ int qf_overlap_rows(qf_ctx* c, const qf_dp_config* cfg, uint32_t n_originals, ui
     // a block's traceback has to fit the memory budget, and a block cut in two for that loses the triangle's fast paths)
     uint64_t nb = total / want;
     if (!nb || (total + nb - 1) / nb > want + want / 16) nb = (total + want - 1) / want;
-    if (nb > 1) want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want + want / 16);   // (+ a row: the cut falls on a row boundary)
+    want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want + want / 16);   // (+ a row: the cut falls on a row boundary)
   }
   std::vector<uint64_t> row_start;
   for (uint32_t b0 = x0; b0 < x1;) {
