@@ -183,7 +183,7 @@ def roofline_entry(workload, kernel, kind, cells, ms, bound, extra=None):
     if pmc and abs(pmc.get("cells_per_launch", 0) - cells) > 0.01 * cells:
         pmc = None                    # the committed capture is of another problem size (other --reads, another rank count)
         prov = dict(prov, other_problem_size=True)
-    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    traffic = pmc.get("hbm_bytes_per_pass", pmc.get("hbm_bytes_per_launch")) if pmc else None   # (per_pass: a class run as several launches per step)
     out = {"bound": bound, "kernel": kernel, "cells_per_launch": int(cells), "ms_per_launch": round(ms, 4)}
     if bound == "fp64_valu":
         out.update(achieved=round(valu, 3), peak=F64_PEAK_TOPS, unit="TFLOP/s", frac=round(valu / F64_PEAK_TOPS, 4),

@@ -27,6 +27,8 @@ import os
 import sys
 from collections import defaultdict
 
+PROFILED_STEPS = 3   # tools/profile.sh: --steps 2 --warmup 1
+
 
 def find(d, suffix):
     hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)   # (gpurun merges: older runs' files stay)
@@ -87,10 +89,18 @@ def main():
             r["wave_cycles_issue_stalled_frac"] = stall[k].get("SQ_WAIT_INST_ANY", 0.0) / w
             r["wave_cycles_lds_stalled_frac"] = stall[k].get("SQ_WAIT_INST_LDS", 0.0) / w
             r["wave_cycles_issuing_frac"] = stall[k].get("SQ_ACTIVE_INST_ANY", 0.0) / w
+        # train: the cells given are a fill class's per E-step; a class may run as several launches of its kernel per step (the
+        # dominant class's Backward is two: DESIGN.md 4), so per-pass figures = per-launch averages x launches per step
+        lpp = 1
+        if workload == "train" and r["launches"] and r["launches"] % PROFILED_STEPS == 0:
+            lpp = max(1, r["launches"] // PROFILED_STEPS)
+        if lpp > 1:
+            r["launches_per_pass"] = lpp
+            r["hbm_bytes_per_pass"] = r["hbm_bytes_per_launch"] * lpp
         for pat, c in cells.items():
             if pat in k.replace(" ", "") and "SQ_INSTS_VALU" in r:
                 r["cells_per_launch"] = float(c)
-                r["valu_insts_per_cell"] = r["SQ_INSTS_VALU"] * 64 / float(c)
+                r["valu_insts_per_cell"] = r["SQ_INSTS_VALU"] * 64 * lpp / float(c)
         rows.append(r)
     rows.sort(key=lambda r: -(r.get("ms_avg", 0) * max(r["launches"], 1)))
     for r in rows[:14]:
