@@ -1543,6 +1543,7 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
     // on config 4.  Forward runs three on 53 KB each, which the order-2 slice does not fit beside the log-sum-exp pieces: it
     // keeps the table in global memory unless the slice is small (QF_DEBUG_BIG_FORWARD_LDS: two workgroups with the table)
     fa.lds_limit = 78 * 1024;
+  fa.flush_lds = (c->debug & QF_DEBUG_FLUSH_GLOBAL) ? 1u : (c->debug & QF_DEBUG_FLUSH_SLICES) ? 12u * 1024u : 0u;
   }
   fa.dp.eins = c->d_eins.as<double>();
   fa.dp.trans = c->d_trans.as<double>();
@@ -2578,7 +2579,7 @@ int qf_overlap_rows(qf_ctx* c, const qf_dp_config* cfg, uint32_t n_originals, ui
     // (a block may pass 2^24 pairs by a sixteenth if that saves one: 4.2 x 2^24 pairs are four blocks, not five; never by more --
     // a block's traceback has to fit the memory budget, and a block cut in two for that loses the triangle's fast paths)
     uint64_t nb = total / want;
-    if (!nb || (total + nb - 1) / nb > want + want / 16) nb = (total + want - 1) / want;
+    if (!nb || (total + nb - 1) / nb > want + want / 16) nb = std::max<uint64_t>(1, (total + want - 1) / want);   // (an empty range of rows: one empty block)
     want = std::min<uint64_t>((total + nb - 1) / nb + n_seqs, want + want / 16);   // (+ a row: the cut falls on a row boundary)
   }
   std::vector<uint64_t> row_start;

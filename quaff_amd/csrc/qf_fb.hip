@@ -1244,7 +1244,8 @@ static void launch_count_flush(const FbArgs& a, int G, int B, hipStream_t s) {
   const int gap = a.dp.Kg > 1;
   const uint32_t rows = a.dp.ematch_ninf_off / 32, rest = 4 * kNQualDev + (gap ? 3 * a.dp.Kg : 0);
   // rows per slice: what the LDS budget leaves beside the insert / transition entries (64 bytes per row)
-  uint32_t rps = rest * 16 < kFlushLdsMax ? (kFlushLdsMax - rest * 16) / 64 : 0;
+  const uint32_t budget = a.flush_lds ? a.flush_lds : kFlushLdsMax;   // (tests: a small table = many slices; 1 = none)
+  uint32_t rps = rest * 16 < budget ? (budget - rest * 16) / 64 : 0;
   rps = std::min(rps, rows);
   uint32_t n_slices = rps ? (rows + rps - 1) / rps : 1;
   if (n_slices > kFlushMaxSlices) { rps = 0; n_slices = 1; }

@@ -25,6 +25,8 @@ enum qf_debug_flag {
   QF_DEBUG_OLD_SINGLE_ROWS = 8192u,   /* overlap: the slotted single-diagonal bands through k_overlap_single_lds (round 3) instead of k_overlap_single_rows */
   QF_DEBUG_LDS_ROW_INDEX = 16384u,    /* overlap seeding: the row prefilter keeps the chunk's k-mer index in LDS (k_seed_rows_lds: fewer instructions, but LDS-bound and slower; A/B) */
   QF_DEBUG_FB32 = 32768u,             /* E-step: bands of 65 .. 96 diagonals through the (32, 3) Forward / Backward kernels (A/B) */
+  QF_DEBUG_FLUSH_GLOBAL = 1048576u,   /* E-step: k_count_flush adds straight to the global accumulators (the path of tables too large to slice; tests) */
+  QF_DEBUG_FLUSH_SLICES = 2097152u,   /* E-step: k_count_flush with a 12 KB table: many slices of the match-emission rows (tests) */
   QF_DEBUG_NO_BACKWARD_SPLIT = 524288u, /* E-step: the dominant class's Backward as one launch (A/B) */
   QF_DEBUG_HOST_ROW_ITEMS = 262144u,  /* row prefilter: the item list of a triangle block built by the host like any other list's (A/B, tests) */
   QF_DEBUG_ROW_INDEX_32 = 131072u,    /* row prefilter: 32-bit index entries even where 16-bit ones fit (A/B) */

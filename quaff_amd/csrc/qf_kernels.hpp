@@ -151,6 +151,7 @@ struct FbArgs {  // Forward / Backward fills (qf_fb.hip)
   // quality-major emission rows (PrepArgs::em_qmajor_Km): row = (q - em_qmin) << em_kshift | k-mer; em_qmajor = 0: row = k-mer * 95 + q
   uint32_t em_qmajor, em_kshift, em_qmin;
   uint32_t lds_limit;          // bytes of LDS one workgroup of the fill kernels may take (tables go to LDS while they fit)
+  uint32_t flush_lds;          // k_count_flush: bytes of LDS for its table (0 = default; 1 = none: straight to the global accumulators; tests)
 };
 
 struct CountPlanArgs {

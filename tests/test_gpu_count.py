@@ -397,3 +397,44 @@ def test_estep_totals_do_not_depend_on_order_pieces_or_partition(ctx):
         ctx.set_params_json(None)
         ctx.set_pipeline_chunks(0)
         ctx.set_memory_budget(0)
+
+def test_count_flush_paths_and_split_backward_give_the_same_words(ctx):
+    """Backward leaves its per-column count sums in the Forward rows and k_count_flush adds them up: through a table in
+    LDS that holds all the match-emission rows in use, through slices of them (a 12 KB table: QF_DEBUG_FLUSH_SLICES), or straight to
+    the global accumulators (tables too large to slice: QF_DEBUG_FLUSH_GLOBAL); the class with the most cells runs its Backward as
+    two launches once it has 8 192 bands (QF_DEBUG_NO_BACKWARD_SPLIT: one).  The terms are the same fixed-point words on every path,
+    so the totals must be the same 128-bit integers -- and close to the oracle's."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(97)
+    ref = rand_seq(rng, 3000)
+    refs = both_strands(ref)
+    reads = make_reads(rng, ref, 9000, 110)              # 9 000 short reads: one banded unit each on the strand they come from
+    null = O.NullParams.from_json(NULL_JSON)
+    pj = synth_params_json(rng, 2, 1)                    # order-2 match contexts (many emission rows), gap contexts
+
+    def words(res):
+        return np.concatenate([res["counts_exact"], res["loglike_exact"].reshape(1, 2)])
+
+    try:
+        ctx.set_params_json(pj)
+        ctx.set_null_json(NULL_JSON)
+        ctx.set_refs([x.seq for x in refs])
+        ctx.upload_reads([r.seq for r in reads], [r.qual for r in reads])
+        cfg = Q.DPConfig()
+        base = ctx.count_resident(cfg)
+        assert max(c["units"] for c in base["classes"]) >= 8192           # the split applies
+        assert (base["counts"] > 1e-6).sum() > 300
+        for flags, what in ((1048576, "global"), (2097152, "slices"), (524288, "one launch"), (524288 | 2097152, "one launch, slices")):
+            ctx.set_debug_flags(flags)
+            got = ctx.count_resident(cfg)
+            ctx.set_debug_flags(0)
+            assert np.array_equal(words(got), words(base)), what
+        # against the oracle on a sample of the reads (the whole batch would take minutes of CPU)
+        sample = reads[:60]
+        ctx.upload_reads([r.seq for r in sample], [r.qual for r in sample])
+        got = ctx.count_resident(cfg)
+        want, _, _ = oracle_estep(refs, sample, O.Scores(O.Params.from_json(pj)), null, O.DPConfig())
+        assert_counts_close(got["counts"], want, "flush sample")
+    finally:
+        ctx.set_debug_flags(0)
+        ctx.set_params_json(None)

@@ -256,3 +256,30 @@ def test_single_diagonal_rows_kernel_many_chunks_and_a_strand_boundary_inside_a_
         assert sum(o["result_checksum"] for o in one) & MASK == whole["result_checksum"]
     finally:
         c.close()
+
+def test_row_prefilter_index_and_item_list_variants_agree(ctx):
+    """The row prefilter's chunk index has 16-bit entries where the sequences are short enough and 32-bit ones otherwise
+    (QF_DEBUG_ROW_INDEX_32 forces the latter), and for the scheduler's triangle its item list is formed by a kernel instead of the
+    host (QF_DEBUG_HOST_ROW_ITEMS keeps the host's): every variant must settle the same pairs and return the same hits."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(411)
+    reads = overlapping_reads(rng, 6000, 90, 260)
+    seqs = reads + [r.revcomp() for r in reads]
+    ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    cfg = Q.DPConfig(kmer_threshold=14)
+    ctx.set_score_threshold(0.0)
+    cols = ["x", "y", "viterbi", "score", "x_start", "x_end", "y_start", "y_end", "n_runs"]
+    try:
+        ctx.set_debug_flags(512)                                   # QF_DEBUG_COUNT_SETTLED
+        base = ctx.overlap_rows(90, 0, 89, cfg)
+        settled = ctx.rows_settled()
+        assert settled > 0
+        for flags in (131072, 262144, 131072 | 262144):           # 32-bit entries; the host's item list; both
+            ctx.set_debug_flags(512 | flags)
+            got = ctx.overlap_rows(90, 0, 89, cfg)
+            assert ctx.rows_settled() == settled, flags
+            for k in ("n_pairs", "n_finite", "total_cells", "total_diagonals", "result_checksum"):
+                assert got[k] == base[k], (flags, k)
+            assert np.array_equal(got["hits"][cols], base["hits"][cols]) and np.array_equal(got["runs"], base["runs"])
+    finally:
+        ctx.set_debug_flags(0)
