@@ -55,4 +55,18 @@ __device__ __forceinline__ uint32_t shift_in_gt(uint32_t acc, double x, double y
   return acc;
 }
 
+// Traceback words are written once by a fill and read, sparsely, by the traceback kernel after it: a non-temporal store keeps them from
+// churning the L2 on their way out (QF_TB_NT: A/B)
+#ifndef QF_TB_NT
+#define QF_TB_NT 0
+#endif
+typedef uint32_t qf_u4v __attribute__((ext_vector_type(4), aligned(4)));   // (the words of a unit start on a 4-byte boundary)
+__device__ __forceinline__ void tb_store(uint32_t* p, uint32_t v) {
+  if (QF_TB_NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__device__ __forceinline__ void tb_store4(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {   // one 16-byte store
+  if (QF_TB_NT) __builtin_nontemporal_store(qf_u4v{a, b, c, d}, (qf_u4v*)p);
+  else *(qf_u4v*)p = qf_u4v{a, b, c, d};
+}
+
 }  // namespace qf

@@ -1681,12 +1681,12 @@ __global__ __launch_bounds__(256) void k_viterbi_fill(FillArgs a) {
           pubM = prevM; pubD = prevD;
         }
         if (WPL == 1) tile.v[s] = tbw0;
-        else if (colvalid) { tb[((uint64_t)t * G + l) * 2] = tbw0; tb[((uint64_t)t * G + l) * 2 + 1] = tbw1; }
+        else if (colvalid) { tb_store(&tb[((uint64_t)t * G + l) * 2], tbw0); tb_store(&tb[((uint64_t)t * G + l) * 2 + 1], tbw1); }
       }
       // steps t0+s4 .. +3 hold columns j0 .. j0+3 of this lane; stored when any of them is a real column
       if (WPL == 1) {
         const int j0 = t0 + s4 - l + 1;
-        if (active && j0 + 3 >= 1 && j0 <= yLen) *(U32x4*)(tb + tb_word_index(t0 + s4, l, G)) = tile;
+        if (active && j0 + 3 >= 1 && j0 <= yLen) tb_store4(tb + tb_word_index(t0 + s4, l, G), tile.v[0], tile.v[1], tile.v[2], tile.v[3]);
       }
     }
   }
@@ -1792,7 +1792,7 @@ __global__ __launch_bounds__(256) void k_viterbi_single(FillArgs a) {
     // four traceback words (one per eight columns); the unit's words are allocated in whole rounds
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8)
-      if (active && j0 + 8 * g8 <= yLen) tb[((j0 - 1) >> 3) + g8] = words4.v[g8];
+      if (active && j0 + 8 * g8 <= yLen) tb_store(&tb[((j0 - 1) >> 3) + g8], words4.v[g8]);
   }
   if (active) {
     a.units[uid].end_val = bestEnd;
@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(kVitLanes) void k_viterbi_rows(FillArgs a) {
       p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
       if (l == 63) { double* xo = s_x[wv][t % R]; xo[0] = p1M; xo[1] = p1I; xo[2] = p1D; }
       if (colvalid) {
-        tbw[woff + (unsigned long long)t * G + L] = tbword;
+        tb_store(&tbw[woff + (unsigned long long)t * G + L], tbword);
         if (L == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
       }
       // Ring slots are read K / K+1 steps after they are written.  The barrier orders LDS only (LDS operations complete in

@@ -388,8 +388,8 @@ void k_overlap_fill(OvArgs a) {
     wy = wyN; wyN = wyNN;
     wyNN = yword(j + 3);
     if (colvalid) {
-      tb[((uint64_t)t * G + l) * 2] = tbw0;
-      tb[((uint64_t)t * G + l) * 2 + 1] = tbw1;
+      tb_store(&tb[((uint64_t)t * G + l) * 2], tbw0);
+      tb_store(&tb[((uint64_t)t * G + l) * 2 + 1], tbw1);
     }
   }
   for (int o = 1; o < G; o <<= 1) {
@@ -997,8 +997,8 @@ __global__ __launch_bounds__(64) void k_overlap_rows(OvArgs a) {
       p2M = p1M; p2I = p1I; p2D = p1D;
       p1M = M[B - 1]; p1I = I[B - 1]; p1D = D[B - 1];
       if (colvalid) {
-        tbw[woff + ((unsigned long long)t * G + l) * 2] = tbw0;
-        tbw[woff + ((unsigned long long)t * G + l) * 2 + 1] = tbw1;
+        tb_store(&tbw[woff + ((unsigned long long)t * G + l) * 2], tbw0);
+        tb_store(&tbw[woff + ((unsigned long long)t * G + l) * 2 + 1], tbw1);
         if (l == G - 1) { bnext[j] = p1M; bnext[(yLen + 2) + j] = p1I; bnext[2 * (yLen + 2) + j] = p1D; }
       }
     }
