@@ -223,7 +223,7 @@ struct qf_ctx : Slot {
   struct PairRow { uint32_t x, y0, n, p0; };
   std::vector<PairRow> ov_rows;
   bool ov_use_rows = false;
-  DevBuf d_cstart, d_ccursor, d_centries, d_row_items, d_row_skip, d_slot_list;
+  DevBuf d_cstart, d_ccursor, d_centries, d_cbounds, d_row_items, d_row_skip, d_slot_list;
   std::vector<PairRow> row_items_rows;   // the runs / block / chunk size d_row_items was built for
   uint32_t row_items_lo = 0, row_items_hi = 0, row_items_n = 0;
   int row_items_cl = -1;
@@ -379,7 +379,7 @@ void qf_ctx_destroy(qf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->d_ematch, &c->d_eins, &c->d_trans, &c->d_nullq, &c->d_ref_seq, &c->d_ref_tok, &c->d_ref_off,
                     &c->d_ref_woff, &c->d_ref_packed, &c->d_bucket, &c->d_cursor, &c->d_pos, &c->d_seq, &c->d_qual,
-                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_qrange, &c->d_ematch_q, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_row_items, &c->d_row_skip, &c->d_slot_list, &c->d_row_sorted, &c->d_row_pieces,
+                    &c->d_roff, &c->d_tok, &c->d_ctx, &c->d_skmer, &c->d_nll, &c->d_qrange, &c->d_ematch_q, &c->d_cover, &c->d_lse, &c->d_lse_pack, &c->d_cstart, &c->d_ccursor, &c->d_centries, &c->d_cbounds, &c->d_row_items, &c->d_row_skip, &c->d_slot_list, &c->d_row_sorted, &c->d_row_pieces,
                     &c->d_mmic0, &c->d_mmic1, &c->d_xrowoff, &c->d_ycol0, &c->d_ycol1, &c->d_ygoff,
                     &c->d_counts, &c->d_order_in, &c->d_order_n_in,
                     &c->d_skip, &c->d_ctxc, &c->d_ins_sum, &c->d_ins_sum_c, &c->d_nll_c,
@@ -2049,6 +2049,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
           s.chunk_log2 = c->chunk_log2;
           s.chunk_estride = c->chunk_estride;
           s.chunk_pb = c->chunk_pb;
+          s.chunk_bounds = c->d_cbounds.as<uint2>();
           s.row_skip = c->d_row_skip.as<uint8_t>();
           if (c->row_lds && c->row_pieces_n) {
             s.row_sorted = c->row_tri ? nullptr : c->d_row_sorted.p;
@@ -2403,15 +2404,17 @@ static int overlap_run(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], u
       if (c->chunk_epoch != c->prep_epoch || c->chunk_k != cfg->kmer_len || c->chunk_log2 != cl || c->chunk_estride != estride || c->chunk_span != seed_row_entry_span(t) || c->chunk_pb != pb) {
         const uint32_t nb = 1u << (2 * cfg->kmer_len), n_chunks = (n_seqs + (1u << cl) - 1) >> cl;
         const size_t bytes = (size_t)n_chunks * (nb + 1) * 4;
-        const size_t ebytes = estride ? (size_t)n_chunks * estride * 4 : (c->read_total + 16) * 4;
+        // (16-bit entries: a chunk's buckets are padded to even length, at most one pad entry per bucket: chunk_base16)
+        const size_t ebytes = estride ? (size_t)n_chunks * estride * 4 : std::max<size_t>((c->read_total + 16) * 4, pb ? (c->read_total + (size_t)n_chunks * nb + 64) * 2 : 0);
         HIPCHK(c, c->d_cstart.reserve(bytes));
         HIPCHK(c, c->d_ccursor.reserve(bytes));
         HIPCHK(c, c->d_centries.reserve(ebytes));
+        if (pb) HIPCHK(c, c->d_cbounds.reserve((size_t)n_chunks * nb * sizeof(uint2)));
         HIPCHK(c, hipMemsetAsync(c->d_cstart.p, 0, bytes, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ccursor.p, 0, bytes, c->stream));
         if (estride) HIPCHK(c, hipMemsetAsync(c->d_centries.p, 0xFF, ebytes, c->stream));   // pad entries
         launch_chunk_index(c->d_tok.as<uint8_t>(), c->d_roff.as<uint64_t>(), n_seqs, c->read_maxlen, (uint32_t)cfg->kmer_len, nb, cl,
-                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), estride, seed_row_entry_span(t), pb, c->stream);
+                           c->d_cstart.as<uint32_t>(), c->d_ccursor.as<uint32_t>(), c->d_centries.as<uint32_t>(), estride, seed_row_entry_span(t), pb, c->d_cbounds.as<uint2>(), c->stream);
         HIPCHK(c, hipGetLastError());
         c->chunk_epoch = c->prep_epoch;
         c->chunk_k = cfg->kmer_len;

@@ -126,6 +126,11 @@ __host__ __device__ inline uint64_t row_ov_words(int dlo, int dhi, int xLen, int
   }
   return w;
 }
+// 16-bit chunk index (k_seed_rows<., true>): first element of chunk c's entries -- behind the sequences before it plus room for one
+// pad entry per bucket of the chunks before (buckets are padded to even length), on an even element (4-byte aligned)
+__host__ __device__ inline uint64_t chunk_base16(const uint64_t* off, uint32_t c, int cl, uint32_t nbuckets) {
+  return (off[(uint64_t)c << cl] + (uint64_t)c * nbuckets + 1) & ~1ull;
+}
 // traceback words a unit occupies
 // One-word classes (B <= 8) keep the words of eight consecutive steps of a fill lane together ([step/8][lane][step%8]): the
 // fill stores 16 bytes per lane every four steps (one half of the lane's 32-byte slot) and a traceback, which follows one

@@ -916,7 +916,8 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
   const int xLen = (int)(a.ref_off[it.x + 1] - xb), nkx = xLen - k + 1;
   const uint32_t* __restrict__ cs = a.chunk_start + (uint64_t)it.chunk * (a.nbuckets + 1);
   const uint32_t* __restrict__ ce = a.chunk_entries + (E16 ? 0 : a.read_off[(uint64_t)it.chunk << cl]);
-  const uint16_t* __restrict__ ce16 = (const uint16_t*)a.chunk_entries + (E16 ? a.read_off[(uint64_t)it.chunk << cl] : 0);
+  const uint16_t* __restrict__ ce16 = (const uint16_t*)a.chunk_entries + (E16 ? chunk_base16(a.read_off, it.chunk, cl, a.nbuckets) : 0);
+  const uint2* __restrict__ cb2 = E16 ? a.chunk_bounds + (uint64_t)it.chunk * a.nbuckets : nullptr;
   const uint32_t* __restrict__ xk = a.skmer + xb;
   const uint32_t y0 = it.chunk << cl, yylo = it.ylo - y0, yyhi = it.yhi - y0;
   const bool whole = yylo == 0 && yyhi == csize;            // the item takes every sequence of the chunk (all but a row's two end chunks)
@@ -941,21 +942,25 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
     for (int c = 0; c < kRowPos; ++c) km[c] = i0 + c * kSeedRowThreads < nkx ? xk[i0 + c * kSeedRowThreads] : 0u;
 #pragma unroll
     for (int c = 0; c < kRowPos; ++c) {
-      const W2a se = *(const W2a*)(cs + km[c]);            // the bucket's bounds as one 8-byte load
-      sq[c] = se.v[0];
-      eq[c] = i0 + c * kSeedRowThreads < nkx ? se.v[1] : sq[c];
+      if (E16) {                                           // (first entry: even, entries) as one 8-byte load
+        const uint2 se = cb2[km[c]];
+        sq[c] = se.x;
+        eq[c] = se.x + (i0 + c * kSeedRowThreads < nkx ? se.y : 0u);
+      } else {
+        const W2a se = *(const W2a*)(cs + km[c]);          // the bucket's bounds as one 8-byte load
+        sq[c] = se.v[0];
+        eq[c] = i0 + c * kSeedRowThreads < nkx ? se.v[1] : sq[c];
+      }
     }
     W4a v[kRowPos][kRowBatch];
-    auto odd16 = [&](int c) { return (uint32_t)(((uintptr_t)(ce16 + sq[c]) >> 1) & 1u); };   // the bucket's first 16-bit entry sits in the upper half of its dword
 #pragma unroll
     for (int c = 0; c < kRowPos; ++c)
 #pragma unroll
       for (int b = 0; b < kRowBatch; ++b) {
-        // (the entry array has 16 words of slack; a lane whose bucket ends earlier holds zeros it never counts; 16-bit entries are
-        // fetched from the even element at or below the bucket's first, so that the load is 4-byte aligned)
-        // (-1 for the first bucket of a chunk whose entries start at an odd element: the chunk before's last entry, never counted)
-        const int32_t first = (int32_t)(E16 ? sq[c] - odd16(c) : sq[c]);
-        if (first + kPerLoad * b < (int32_t)eq[c]) v[c][b] = E16 ? *(const W4a*)(ce16 + first + kPerLoad * b) : *(const W4a*)(ce + first + kPerLoad * b);
+        // (the entry array has 16 words of slack; a lane whose bucket ends earlier holds zeros it never counts; a 16-bit bucket
+        // starts on an even element of an even base, so its loads are 4-byte aligned)
+        const uint32_t first = sq[c];
+        if (first + kPerLoad * b < eq[c]) v[c][b] = E16 ? *(const W4a*)(ce16 + first + kPerLoad * b) : *(const W4a*)(ce + first + kPerLoad * b);
         else v[c][b] = W4a{{0u, 0u, 0u, 0u}};
       }
 #pragma unroll
@@ -990,15 +995,13 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
               : "vcc", "memory");
         }
       } else if (whole && E16) {
-        // The same for 16-bit entries, a dword = two entries at a time: entry e -> L = e + (e & himask); entry number q of the
-        // load (from the even entry at or below the bucket's first) is the bucket's entry q - (first & 1): counted while that is
-        // below the bucket's length (unsigned: the entry before the bucket wraps to a large number).
-        const uint32_t odd = odd16(c);
+        // The same for 16-bit entries, a dword = two entries at a time: entry e -> L = e + (e & himask); the increment is
+        // 1 + 0xFFFF x (bin parity) by one multiply-add.  Nine vector instructions per entry.
 #pragma unroll
         for (int b = 0; b < kRowBatch; ++b)
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
-            uint32_t e0, e1, t0, t1, a0, a1, q0, q1;
+            uint32_t e0, e1, t0, t1, a0, a1;
             unsigned long long sv;
             asm volatile(
                 "v_and_b32 %[e0], 0xffff, %[wd]\n v_lshrrev_b32 %[e1], 16, %[wd]\n"
@@ -1007,27 +1010,21 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
                 "v_lshrrev_b32 %[a0], %[shw], %[t0]\n v_lshrrev_b32 %[a1], %[shw], %[t1]\n"
                 "v_and_b32 %[a0], -4, %[a0]\n v_and_b32 %[a1], -4, %[a1]\n"
                 "v_bfe_u32 %[t0], %[t0], %[cb], 1\n v_bfe_u32 %[t1], %[t1], %[cb], 1\n"
-                "v_lshlrev_b32 %[t0], 4, %[t0]\n v_lshlrev_b32 %[t1], 4, %[t1]\n"
-                "v_lshlrev_b32_e64 %[t0], %[t0], 1\n v_lshlrev_b32_e64 %[t1], %[t1], 1\n"
-                "v_sub_u32 %[q0], %[k0], %[odd]\n v_sub_u32 %[q1], %[k1], %[odd]\n"
+                "v_mad_u32_u24 %[t0], %[t0], %[ffff], 1\n v_mad_u32_u24 %[t1], %[t1], %[ffff], 1\n"
                 "s_mov_b64 %[sv], exec\n"
-                "v_cmpx_lt_u32 vcc, %[q0], %[n]\n ds_add_u32 %[a0], %[t0]\n s_mov_b64 exec, %[sv]\n"
-                "v_cmpx_lt_u32 vcc, %[q1], %[n]\n ds_add_u32 %[a1], %[t1]\n s_mov_b64 exec, %[sv]\n"
-                : [e0] "=&v"(e0), [e1] "=&v"(e1), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "=&v"(a0), [a1] "=&v"(a1), [q0] "=&v"(q0), [q1] "=&v"(q1),
-                  [sv] "=&s"(sv)
-                : [wd] "v"(v[c][b].v[w]), [hm] "v"(himask), [ip] "v"(ip), [n] "v"(nrem), [odd] "v"(odd), [shw] "n"(CB - 1), [cb] "n"(CB),
+                "v_cmpx_lt_u32 vcc, %[k0], %[n]\n ds_add_u32 %[a0], %[t0]\n s_mov_b64 exec, %[sv]\n"
+                "v_cmpx_lt_u32 vcc, %[k1], %[n]\n ds_add_u32 %[a1], %[t1]\n s_mov_b64 exec, %[sv]\n"
+                : [e0] "=&v"(e0), [e1] "=&v"(e1), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "=&v"(a0), [a1] "=&v"(a1), [sv] "=&s"(sv)
+                : [wd] "v"(v[c][b].v[w]), [hm] "v"(himask), [ip] "v"(ip), [n] "v"(nrem), [ffff] "v"(0xFFFFu), [shw] "n"(CB - 1), [cb] "n"(CB),
                   [k0] "n"(8 * b + 2 * w), [k1] "n"(8 * b + 2 * w + 1)
                 : "vcc", "memory");
           }
       } else if (E16) {
-        const uint32_t odd = odd16(c);
 #pragma unroll
         for (int b = 0; b < kRowBatch; ++b)
 #pragma unroll
-          for (int w = 0; w < 8; ++w) {
-            const uint32_t q = (uint32_t)(8 * b + w) - odd;
-            if (q < nrem) count(i, (v[c][b].v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu);
-          }
+          for (int w = 0; w < 8; ++w)
+            if ((uint32_t)(8 * b + w) < nrem) count(i, (v[c][b].v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu);
       } else {
 #pragma unroll
         for (int b = 0; b < kRowBatch; ++b)
@@ -1036,7 +1033,7 @@ __global__ __launch_bounds__(kSeedRowThreads) void k_seed_rows(SeedArgs a, uint3
             if (sq[c] + 4 * b + w < eq[c]) count(i, v[c][b].v[w]);
       }
       // longer buckets: rare
-      if (E16) for (uint32_t q = sq[c] - odd16(c) + kPerLoad * kRowBatch; q < eq[c]; ++q) count(i, ce16[q]);
+      if (E16) for (uint32_t q = sq[c] + kPerLoad * kRowBatch; q < eq[c]; ++q) count(i, ce16[q]);
       else for (uint32_t q = sq[c] + kPerLoad * kRowBatch; q < eq[c]; ++q) count(i, ce[q]);
     }
   }
@@ -1289,10 +1286,19 @@ __global__ void k_chunk_kmer_scatter(const uint8_t* __restrict__ tok, const uint
   const uint64_t bi = (uint64_t)(x >> cl) * (nbuckets + 1) + km;
   const uint32_t slot = starts[bi] + atomicAdd(&cursor[bi], 1u);
   // a chunk's entries: behind those of the chunks before it, or (padded index) `estride` entries per chunk
-  const uint64_t cbase = estride ? (uint64_t)(x >> cl) * estride : off[(uint64_t)(x >> cl) << cl];
+  const uint64_t cbase = estride ? (uint64_t)(x >> cl) * estride : pb ? chunk_base16(off, x >> cl, cl, nbuckets) : off[(uint64_t)(x >> cl) << cl];
   // (k_seed_rows: sequence x wd + position, wd = the diagonals a sequence's counters span; k_seed_rows_lds re-packs (sequence, position) itself)
   if (pb) ((uint16_t*)entries)[cbase + slot] = (uint16_t)(((x & ((1u << cl) - 1)) << pb) | (uint32_t)(len - 1 - i));   // k_seed_rows<., true>
   else entries[cbase + slot] = wd ? (x & ((1u << cl) - 1)) * wd + (uint32_t)(len - 1 - i) : ((x & ((1u << cl) - 1)) << 26) | (uint32_t)(len - 1 - i);
+}
+
+// 16-bit index: a bucket's (first entry, entries) side by side, so that k_seed_rows fetches both with one 8-byte load (the cursor
+// array holds the counts once the scatter is done; buckets are padded to even length, so starts are even)
+__global__ void k_chunk_bounds(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ cursor, uint32_t nbuckets, uint2* __restrict__ bounds) {
+  const uint32_t km = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (km >= nbuckets) return;
+  const uint64_t bi = (uint64_t)c * (nbuckets + 1) + km;
+  bounds[(uint64_t)c * nbuckets + km] = make_uint2(starts[bi], cursor[bi]);
 }
 
 // Bands -> units: class, unit id, class-list slot, traceback offset, cell counts.  One thread per
@@ -2434,12 +2440,14 @@ void launch_ref_index(const uint8_t* tok, const uint64_t* off, uint32_t n_refs, 
 // estride = 0: a chunk's entries follow the chunks before it; > 0 (k_seed_rows_lds): buckets padded to even length (the pad
 // entry stays 0xFFFFFFFF: the caller fills the array with it first), `estride` entries per chunk
 void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
-                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, uint32_t wd, int pb, hipStream_t s) {
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, uint32_t wd, int pb, uint2* bounds, hipStream_t s) {
   const dim3 grid((uint32_t)((max_len + 255) / 256), n_seqs);
   const uint32_t n_chunks = (n_seqs + (1u << chunk_log2) - 1) >> chunk_log2;
   hipLaunchKernelGGL(k_chunk_kmer_count, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts);
-  hipLaunchKernelGGL(k_bucket_scan, dim3(n_chunks), dim3(1024), 0, s, starts, nbuckets, estride ? 2u : 1u);
+  const bool e16 = !estride && pb;
+  hipLaunchKernelGGL(k_bucket_scan, dim3(n_chunks), dim3(1024), 0, s, starts, nbuckets, estride || e16 ? 2u : 1u);
   hipLaunchKernelGGL(k_chunk_kmer_scatter, grid, dim3(256), 0, s, tok, off, k, nbuckets, chunk_log2, starts, cursor, entries, estride, estride ? 0u : wd, estride ? 0 : pb);
+  if (e16) hipLaunchKernelGGL(k_chunk_bounds, dim3((nbuckets + 255) / 256, n_chunks), dim3(256), 0, s, starts, cursor, nbuckets, bounds);
 }
 void launch_prep_reads(const PrepArgs& a, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;

@@ -90,7 +90,8 @@ struct SeedArgs {
   uint32_t n_row_items;
   const uint32_t* chunk_start; // [n_chunks][nbuckets + 1] bucket starts of each chunk of 2^chunk_log2 consecutive sequences
   const uint32_t* chunk_entries; // per chunk, from position read_off[first sequence of the chunk]: (sequence in chunk) x seed_row_entry_span + (len - 1 - j); with chunk_estride, from chunk x chunk_estride: (sequence in chunk) << 26 | (len - 1 - j)
-  int chunk_pb;                // > 0: 16-bit index entries, (sequence in chunk) << chunk_pb | (len - 1 - j) (k_seed_rows<., true>)
+  int chunk_pb;                // > 0: 16-bit index entries, (sequence in chunk) << chunk_pb | (len - 1 - j) (k_seed_rows<., true>), a chunk's from element chunk_base16() of chunk_entries
+  const uint2* chunk_bounds;   // 16-bit index: per chunk and bucket (first entry: even, entries)
   uint64_t chunk_estride;      // > 0: the padded index of k_seed_rows_lds (buckets of even length, pad entries 0xFFFFFFFF)
   int chunk_log2;
   uint8_t* row_skip;           // [n_pairs], zero-initialised: set for the pairs the prefilter settled
@@ -300,7 +301,7 @@ int sort_kmer_index(const uint8_t* tok, const uint64_t* d_off, const int* d_off3
 void launch_prep_overlap(const PrepArgs& a, uint32_t n, hipStream_t s);
 // k-mer index of chunks of 2^chunk_log2 consecutive sequences (row prefilter of the overlap seeding)
 void launch_chunk_index(const uint8_t* tok, const uint64_t* off, uint32_t n_seqs, uint64_t max_len, uint32_t k, uint32_t nbuckets,
-                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, uint32_t wd, int pb, hipStream_t s);
+                        int chunk_log2, uint32_t* starts, uint32_t* cursor, uint32_t* entries, uint64_t estride, uint32_t wd, int pb, uint2* bounds, hipStream_t s);
 uint32_t seed_row_entry_span(const struct SeedArgs& a);
 size_t seed_row_stride_bytes_e16(int pb, int cb);
 int seed_row_bits_of(const struct SeedArgs& a);
