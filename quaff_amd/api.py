@@ -301,6 +301,14 @@ class Context:
         self.L.qf_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         self._chk(self.L.qf_debug_set_flags(self.h, flags))
 
+    def fail_chunk_reserve(self, nth):
+        """Tests only (csrc/qf_internal.h): the nth per-chunk device reserve from now (0 = the next one, counted over the whole
+        process) fails once as if the device were out of memory: the chunk is split and retried.  -1 switches it off.  Returns
+        the countdown it replaces: negative once the failure has happened."""
+        self.L.qf_debug_fail_chunk_reserve.argtypes = [C.c_int]
+        self.L.qf_debug_fail_chunk_reserve.restype = C.c_int
+        return int(self.L.qf_debug_fail_chunk_reserve(int(nth)))
+
     def rows_settled(self):
         """Tests only (csrc/qf_internal.h): pairs the overlap seeding's row prefilter settled in the last overlap call
         (counted under debug flag 512)."""

@@ -273,6 +273,26 @@ struct qf_ctx : Slot {
     }                                                                                           \
   } while (0)
 
+// A per-chunk device buffer (unit tables, alignment records, run lists, sort keys ...).  When it cannot be had the chunk function
+// returns kSplitChunk: its wrapper waits for what the abandoned chunk still has in flight, releases the big buffers of the entry
+// points that are not running, and has the caller cut the chunk in two -- the way the traceback / Forward budget does -- unless it
+// is one read or pair already (QF_ERR_MEMORY).  qf_debug_fail_chunk_reserve(n): the n-th such reserve from now fails once (tests).
+constexpr int kSplitChunk = -4242;
+static std::atomic<int> g_fail_chunk_reserve{-1};
+static hipError_t chunk_reserve(DevBuf& buf, size_t bytes) {
+  if (g_fail_chunk_reserve.load() >= 0 && g_fail_chunk_reserve.fetch_sub(1) == 0) return hipErrorOutOfMemory;
+  const hipError_t e = buf.reserve(bytes);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e;
+}
+#define CHUNKRES(ctx, buf, bytes)                                      \
+  do {                                                                 \
+    if (chunk_reserve((buf), (bytes)) != hipSuccess) {                 \
+      (ctx)->err = "out of device memory (" #buf ")";                  \
+      return kSplitChunk;                                              \
+    }                                                                  \
+  } while (0)
+
 constexpr uint64_t kMaxPairsPerCall = 1ull << 28;   // unit tables are sized 4 x pairs + slack in 32 bits
 constexpr size_t kLseHermiteOffset = 100002;  // doubles: the exact table (100001) padded to even, then the quadratic pieces
 
@@ -805,8 +825,8 @@ static int reserve_seed_workspace(Slot* c, SeedArgs& sa, bool mem, uint64_t n_pa
 static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_t max_units, bool pair_order_cls0 = false,
                             bool slotted_cls0 = false) {
   if (!c->ragged_reads && !pair_order_cls0) return QF_OK;
-  HIPCHK(S, S->d_sort_k.reserve((size_t)max_units * 4));
-  HIPCHK(S, S->d_sort_v.reserve((size_t)max_units * 4));
+  CHUNKRES(S, S->d_sort_k, (size_t)max_units * 4);
+  CHUNKRES(S, S->d_sort_v, (size_t)max_units * 4);
   for (int cls = 0; cls < kNumClasses; ++cls) {
     // (overlap sorts every list: bands by the columns they cross, the single-diagonal list into pair order)
     if (cls == kRowClass || bc.cls_count[cls] <= 64 || (cls == 0 && slotted_cls0)) continue;
@@ -819,19 +839,19 @@ static int sort_class_lists(qf_ctx* c, Slot* S, const BatchCounters& bc, uint32_
 }
 
 static int reserve_pair_buffers(Slot* c, uint64_t n_pairs, uint32_t max_units) {
-  HIPCHK(c, c->d_bc.reserve(sizeof(BatchCounters)));
-  HIPCHK(c, c->d_cls_key.reserve((size_t)kNumClasses * max_units * 4));
-  HIPCHK(c, c->d_units.reserve((size_t)max_units * sizeof(Unit)));
-  HIPCHK(c, c->d_cls_list.reserve((size_t)kNumClasses * max_units * 4));
-  HIPCHK(c, c->d_pair_head.reserve(n_pairs * 4));
-  HIPCHK(c, c->d_pair_bands.reserve(n_pairs * kMaxBandsPerPair * sizeof(int2)));
-  HIPCHK(c, c->d_pair_nbands.reserve(n_pairs * 4));
-  HIPCHK(c, c->d_ovf.reserve((size_t)max_units * sizeof(int4)));
+  CHUNKRES(c, c->d_bc, sizeof(BatchCounters));
+  CHUNKRES(c, c->d_cls_key, (size_t)kNumClasses * max_units * 4);
+  CHUNKRES(c, c->d_units, (size_t)max_units * sizeof(Unit));
+  CHUNKRES(c, c->d_cls_list, (size_t)kNumClasses * max_units * 4);
+  CHUNKRES(c, c->d_pair_head, n_pairs * 4);
+  CHUNKRES(c, c->d_pair_bands, n_pairs * kMaxBandsPerPair * sizeof(int2));
+  CHUNKRES(c, c->d_pair_nbands, n_pairs * 4);
+  CHUNKRES(c, c->d_ovf, (size_t)max_units * sizeof(int4));
   HIPCHK(c, hipMemsetAsync(c->d_pair_nbands.p, 0, n_pairs * 4, c->stream));
-  HIPCHK(c, c->d_pair_ndiag.reserve(n_pairs * 4));
-  HIPCHK(c, c->d_pair_cells.reserve(n_pairs * 8));
-  HIPCHK(c, c->d_pair_score.reserve(n_pairs * 8));
-  HIPCHK(c, c->d_pair_end_unit.reserve(n_pairs * 4));
+  CHUNKRES(c, c->d_pair_ndiag, n_pairs * 4);
+  CHUNKRES(c, c->d_pair_cells, n_pairs * 8);
+  CHUNKRES(c, c->d_pair_score, n_pairs * 8);
+  CHUNKRES(c, c->d_pair_end_unit, n_pairs * 4);
   HIPCHK(c, hipMemsetAsync(c->d_pair_head.p, 0xFF, n_pairs * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_pair_ndiag.p, 0, n_pairs * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_pair_cells.p, 0, n_pairs * 8, c->stream));
@@ -869,7 +889,7 @@ static int seed_pairs(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t n_pa
 // Reads [lo, hi) of the resident set against every reference.  Results go to the context's host arrays at the chunk's
 // offsets and are accumulated into *out.  If the chunk's traceback would exceed the memory budget nothing is filled and
 // *too_big is set (the caller splits the range).
-static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
+static int align_chunk_impl(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
                        uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool two_in_flight, bool* too_big,
                        uint64_t* need_bytes, uint32_t* row_granule) {
   *too_big = false;
@@ -1001,12 +1021,12 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   const bool dense = !(flags & QF_ALIGN_ALL) && !(flags & QF_ALIGN_NO_TRACEBACK);
   if (!(flags & QF_ALIGN_NO_TRACEBACK)) {
     const size_t max_recs = fin.all ? n_pairs : n_reads;
-    HIPCHK(S, S->d_recs.reserve(max_recs * sizeof(AlignRec)));
+    CHUNKRES(S, S->d_recs, max_recs * sizeof(AlignRec));
     fin.recs = S->d_recs.as<AlignRec>();
     fin.dense = !fin.all;
     fin.read_base = lo;
     if (fin.dense) {
-      HIPCHK(S, S->d_align_out.reserve((size_t)n_reads * sizeof(AlignOut)));
+      CHUNKRES(S, S->d_align_out, (size_t)n_reads * sizeof(AlignOut));
       fin.out_align = S->d_align_out.as<AlignOut>();
     }
     launch_select(fin, S->stream);
@@ -1015,8 +1035,8 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
     if (token.owns_lock()) token.unlock();  // the fill has drained
     n_recs = fin.dense ? n_reads : bc.n_align;
     n_valid = bc.n_align;
-    HIPCHK(S, S->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
-    HIPCHK(S, S->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
+    CHUNKRES(S, S->d_runs_tmp, (size_t)bc.n_runs * 4 + 64);
+    CHUNKRES(S, S->d_runs_out, (size_t)bc.n_runs * 4 + 64);
     fin.n_recs = n_recs;
     fin.runs_tmp = S->d_runs_tmp.as<uint32_t>();
     fin.runs_out = S->d_runs_out.as<uint32_t>();
@@ -1070,6 +1090,24 @@ static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t fla
   return QF_OK;
 }
 
+
+// (see CHUNKRES)
+static int split_instead(qf_ctx* c, Slot* S, int rc, bool single, bool* too_big, std::initializer_list<DevBuf*> idle) {
+  if (rc != kSplitChunk) return rc;
+  (void)hipDeviceSynchronize();          // what the abandoned chunk still has in flight
+  for (DevBuf* b : idle) b->release();   // the big buffers of the entry points that are not running
+  if (single) return fail(S, QF_ERR_MEMORY, S->err + ": one read / pair does not fit");
+  *too_big = true;
+  (void)c;
+  return QF_OK;
+}
+static int align_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, uint32_t flags, uint32_t lo, uint32_t hi,
+                       uint64_t budget, qf_align_result* out, std::mutex& out_mu, bool two_in_flight, bool* too_big,
+                       uint64_t* need_bytes, uint32_t* row_granule) {
+  const int rc = align_chunk_impl(c, S, cfg, flags, lo, hi, budget, out, out_mu, two_in_flight, too_big, need_bytes, row_granule);
+  if (rc == kSplitChunk) { *need_bytes = 0; *row_granule = 0; }
+  return split_instead(c, S, rc, hi - lo <= 1, too_big, {&c->d_fw, &c->second.d_fw});
+}
 
 int qf_align_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, qf_align_result* out) {
   if (int rc = check_cfg(c, cfg)) return rc;
@@ -1275,6 +1313,7 @@ uint32_t qf_debug_pack_lse_table(uint8_t* out, uint32_t cap) {
 }
 uint64_t qf_debug_rows_settled(const qf_ctx* c) { return c ? c->rows_settled : 0; }
 double qf_debug_alloc_ms(void) { return (double)g_alloc_us.load() * 1e-3; }
+int qf_debug_fail_chunk_reserve(int nth) { return g_fail_chunk_reserve.exchange(nth); }
 uint32_t qf_debug_lse_pack_bytes(qf_ctx* c) {
   if (!c || hipSetDevice(c->device) != hipSuccess || ensure_lse(c) != QF_OK) return 0;
   return c->lse_pack_bytes;
@@ -1469,7 +1508,7 @@ static int launch_classes_concurrently(Slot* c, const BatchCounters& bc, bool se
 
 // Forward-Backward over reads [lo, hi) of the resident set; counts accumulate in d_counts, per-read / per-pair results go to
 // the host arrays at the chunk's offsets.  Sets *too_big (and does nothing) when the Forward matrices exceed the budget.
-static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
+static int count_chunk_impl(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
                        int slots_in_flight, qf_count_result* out, std::mutex& out_mu, bool* too_big) {
   *too_big = false;
   const uint32_t n_reads = hi - lo, n_refs = c->n_refs;
@@ -1513,11 +1552,11 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
     return QF_OK;
   }
   if (int rc = sort_class_lists(c, S, bc, max_units)) return rc;
-  HIPCHK(S, S->d_weight.reserve((size_t)n_pairs * 8));
-  HIPCHK(S, S->d_fwd_out.reserve((size_t)n_pairs * 8));
-  HIPCHK(S, S->d_order_out.reserve((size_t)n_pairs * 4));
-  HIPCHK(S, S->d_order_n_out.reserve((size_t)n_reads * 4));
-  HIPCHK(S, S->d_rll.reserve((size_t)n_reads * 8));
+  CHUNKRES(S, S->d_weight, (size_t)n_pairs * 8);
+  CHUNKRES(S, S->d_fwd_out, (size_t)n_pairs * 8);
+  CHUNKRES(S, S->d_order_out, (size_t)n_pairs * 4);
+  CHUNKRES(S, S->d_order_n_out, (size_t)n_reads * 4);
+  CHUNKRES(S, S->d_rll, (size_t)n_reads * 8);
   const Scores& sc = c->scores;
   FbArgs fa{};
   fa.n_refs = n_refs;
@@ -1663,6 +1702,12 @@ static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_nul
   out->n_fill_classes = kNumClasses;
   (void)csize;
   return QF_OK;
+}
+
+static int count_chunk(qf_ctx* c, Slot* S, const qf_dp_config* cfg, bool use_null, bool have_sort, uint32_t lo, uint32_t hi,
+                       int slots_in_flight, qf_count_result* out, std::mutex& out_mu, bool* too_big) {
+  const int rc = count_chunk_impl(c, S, cfg, use_null, have_sort, lo, hi, slots_in_flight, out, out_mu, too_big);
+  return split_instead(c, S, rc, hi - lo <= 1, too_big, {&c->d_tb, &c->second.d_tb});
 }
 
 int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const uint32_t* sort_in,
@@ -1883,6 +1928,8 @@ int qf_count_resident(qf_ctx* c, const qf_dp_config* cfg, uint32_t flags, const 
 // Pairs [lo, hi) of the uploaded pair list.  Results go to the host arrays at the chunk's offsets; *too_big (nothing done)
 // when the chunk's traceback exceeds the memory budget.
 static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t lo, uint32_t hi,
+                         qf_overlap_result* out, bool* too_big);
+static int overlap_chunk_impl(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t lo, uint32_t hi,
                          qf_overlap_result* out, bool* too_big) {
   *too_big = false;
   const uint32_t n_pairs = hi - lo;
@@ -1922,7 +1969,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       // ... and with the plain prefilter the list is formed by a kernel (k_row_items_tri), not built and copied by the host
       const uint32_t X0 = c->ov_rows[0].x, R = (uint32_t)c->ov_rows.size();
       const uint32_t n = launch_row_items_tri(X0, R, c->n_reads, cl, nullptr, 0, c->stream);
-      HIPCHK(c, c->d_row_items.reserve((size_t)n * sizeof(RowItem)));
+      CHUNKRES(c, c->d_row_items, (size_t)n * sizeof(RowItem));
       c->row_items_n = launch_row_items_tri(X0, R, c->n_reads, cl, c->d_row_items.as<RowItem>(), n, c->stream);
       HIPCHK(c, hipGetLastError());
       c->row_items_epoch = 0;   // (d_row_items no longer holds a cached host-built list)
@@ -1939,7 +1986,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       c->row_tri_x0 = X0;
       c->row_items_n = 1;   // (nothing of the plain list is used)
       if (!pieces.empty()) {
-        HIPCHK(c, c->d_row_pieces.reserve(pieces.size() * sizeof(uint4)));
+        CHUNKRES(c, c->d_row_pieces, pieces.size() * sizeof(uint4));
         HIPCHK(c, hipMemcpyAsync(c->d_row_pieces.p, pieces.data(), pieces.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // stack-lifetime host buffer
       }
@@ -1980,8 +2027,8 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
         c->row_pieces_n = (uint32_t)pieces.size();
         c->row_tri = false;
         if (!sl.empty()) {
-          HIPCHK(c, c->d_row_sorted.reserve(sl.size() * sizeof(RowItemL)));
-          HIPCHK(c, c->d_row_pieces.reserve(pieces.size() * sizeof(uint4)));
+          CHUNKRES(c, c->d_row_sorted, sl.size() * sizeof(RowItemL));
+          CHUNKRES(c, c->d_row_pieces, pieces.size() * sizeof(uint4));
           HIPCHK(c, hipMemcpyAsync(c->d_row_sorted.p, sl.data(), sl.size() * sizeof(RowItemL), hipMemcpyHostToDevice, c->stream));
           HIPCHK(c, hipMemcpyAsync(c->d_row_pieces.p, pieces.data(), pieces.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));   // stack-lifetime host buffers
@@ -1997,7 +2044,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       }
       c->row_items_n = (uint32_t)items.size();
       if (!items.empty()) {
-        HIPCHK(c, c->d_row_items.reserve(items.size() * sizeof(RowItem)));
+        CHUNKRES(c, c->d_row_items, items.size() * sizeof(RowItem));
         HIPCHK(c, hipMemcpyAsync(c->d_row_items.p, items.data(), items.size() * sizeof(RowItem), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // `items` is a stack-lifetime host buffer
       }
@@ -2005,7 +2052,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
       c->row_items_lo = lo; c->row_items_hi = hi; c->row_items_cl = cl; c->row_items_lds = c->row_lds; c->row_items_epoch = c->prep_epoch;
     }
     n_row_items = c->row_items_n;
-    if (n_row_items) HIPCHK(c, c->d_row_skip.reserve(n_pairs));
+    if (n_row_items) CHUNKRES(c, c->d_row_skip, n_pairs);
   }
   // Slotted single-diagonal list: x rows x0, x0 + 1, ... (the scheduler's order), at most one single-diagonal band per pair
   // (bands are at least 2 wide otherwise) and the staging kernel applies.
@@ -2027,7 +2074,7 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     if (ok && !first && (uint64_t)(xb - xa + 1) * slot_ychunks * 256 <= (1ull << 28)) {
       slot_rows = xb - xa + 1;
       slot_x0 = xa;
-      HIPCHK(c, c->d_slot_list.reserve((size_t)slot_rows * slot_ychunks * 256 * 4));
+      CHUNKRES(c, c->d_slot_list, (size_t)slot_rows * slot_ychunks * 256 * 4);
     }
   }
   SeedArgs sa;
@@ -2100,9 +2147,9 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
     return QF_OK;
   }
   if (int rc = sort_class_lists(c, c, bc, max_units, true, slot_rows != 0)) return rc;
-  HIPCHK(c, c->d_pair_result.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_pair_ij.reserve((size_t)n_pairs * 8));
-  HIPCHK(c, c->d_recs.reserve((size_t)n_pairs * sizeof(AlignRec)));
+  CHUNKRES(c, c->d_pair_result, (size_t)n_pairs * 8);
+  CHUNKRES(c, c->d_pair_ij, (size_t)n_pairs * 8);
+  CHUNKRES(c, c->d_recs, (size_t)n_pairs * sizeof(AlignRec));
   OvArgs oa{};
   oa.n_pairs = n_pairs;
   oa.units = c->d_units.as<Unit>();
@@ -2169,8 +2216,8 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   const BatchCounters seed_bc = bc;
   if (int rc = read_counters(c, bc)) return rc;
   const uint32_t n_recs = bc.n_align;
-  HIPCHK(c, c->d_runs_tmp.reserve((size_t)bc.n_runs * 4 + 64));
-  HIPCHK(c, c->d_runs_out.reserve((size_t)bc.n_runs * 4 + 64));
+  CHUNKRES(c, c->d_runs_tmp, (size_t)bc.n_runs * 4 + 64);
+  CHUNKRES(c, c->d_runs_out, (size_t)bc.n_runs * 4 + 64);
   oa.n_recs = n_recs;
   oa.runs_tmp = c->d_runs_tmp.as<uint32_t>();
   oa.runs_out = c->d_runs_out.as<uint32_t>();
@@ -2215,6 +2262,11 @@ static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2],
   }
   out->n_fill_classes = kNumClasses;
   return QF_OK;
+}
+static int overlap_chunk(qf_ctx* c, const qf_dp_config* cfg, const bool need[2], uint32_t lo, uint32_t hi,
+                         qf_overlap_result* out, bool* too_big) {
+  const int rc = overlap_chunk_impl(c, cfg, need, lo, hi, out, too_big);
+  return split_instead(c, c, rc, hi - lo <= 1, too_big, {&c->d_fw, &c->second.d_fw, &c->second.d_tb});
 }
 
 // The resident sequences' derived arrays for the overlap path: tokens / context words / null log-likelihoods (prep_reads), the
@@ -2968,7 +3020,7 @@ int64_t qf_envelope(qf_ctx* c, const qf_dp_config* cfg, uint32_t read, uint32_t 
   if (sparse) if (int rc = ensure_ref_index(c, cfg->kmer_len)) return rc;
   const uint64_t n_pairs = (uint64_t)c->n_reads * c->n_refs;
   const uint32_t max_units = 4096;
-  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc;
+  if (int rc = reserve_pair_buffers(c, n_pairs, max_units)) return rc == kSplitChunk ? QF_ERR_MEMORY : rc;
   if (int rc = prep_reads(c, sparse ? cfg->kmer_len : 0)) return rc;
   const int xLen = (int)(c->ref_off[ref + 1] - c->ref_off[ref]), yLen = (int)(c->read_off[read + 1] - c->read_off[read]);
   const int nd = xLen + yLen - 1;

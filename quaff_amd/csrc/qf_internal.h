@@ -43,6 +43,7 @@ uint32_t qf_debug_pack_lse_table(uint8_t *out, uint32_t cap);
 uint32_t qf_debug_lse_pack_bytes(qf_ctx *ctx);
 /* Pairs of the last qf_overlap_resident call that the seeding's row prefilter settled (given their single forced diagonal without
  * the per-pair kernel); counted only under QF_DEBUG_COUNT_SETTLED. */
+int qf_debug_fail_chunk_reserve(int nth);    /* the nth per-chunk device reserve from now (0 = the next) fails once, as if out of memory; -1 = off; returns the countdown it replaces (< 0: the failure happened) -- tests of the split-and-retry path */
 double qf_debug_alloc_ms(void);   /* milliseconds spent growing device buffers (hipFree + hipMalloc) in this process */
 uint64_t qf_debug_rows_settled(const qf_ctx *ctx);
 

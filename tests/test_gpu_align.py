@@ -546,3 +546,64 @@ def test_many_references_of_different_lengths(ctx):
     res = check_against_oracle(ctx, refs, reads, dict(), sc, null)
     assert len({a["ref"] for a in res["alignments"]}) >= 6
     check_against_oracle(ctx, refs, reads[:12], dict(kmer_threshold=8, band_size=20), sc, null, print_all=True)
+
+
+def test_secondary_buffers_that_do_not_fit_split_the_chunk(ctx):
+    """Every per-chunk device buffer besides the traceback / Forward storage (unit tables, sort keys, alignment records, run lists
+    ...) goes through the same release-split-retry path as the big one: a reserve that fails makes the chunk's caller cut it in two
+    (qf_debug_fail_chunk_reserve injects the failure).  Results must not change -- for align, count and overlap, with the n-th
+    reserve failing for a range of n, also under a memory budget that forces splits of its own and with three contexts at work."""
+    import quaff_amd as Q
+    from quaff_amd import api
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(606)
+    ref = rand_seq(rng, 3000)
+    refs = both_strands(ref)
+    reads = make_reads(rng, ref, 400, 260)
+    seqs, quals = [r.seq for r in reads], [r.qual for r in reads]
+    others = [Q.Context(0), Q.Context(0)]
+    ctxs = [ctx] + others
+    try:
+        for c in ctxs:
+            c.set_params_json(None)
+            c.set_null_json(NULL_JSON)
+            c.set_refs([x.seq for x in refs])
+            c.upload_reads(seqs, quals)
+        cfg = Q.DPConfig()
+
+        def align_key(res):
+            return [(int(a["read"]), int(a["ref"]), float(a["viterbi"]), float(a["score"]), int(a["xStart"]), a["cigar"]) for a in res["alignments"]]
+
+        base_al = ctx.align_resident(cfg)
+        base_ct = ctx.count_resident(cfg)
+        words = lambda r: np.concatenate([r["counts_exact"], r["loglike_exact"].reshape(1, 2)])
+        fired = 0
+        for nth in (0, 1, 3, 7, 12, 15, 17, 20):
+            ctx.fail_chunk_reserve(nth)
+            got = ctx.align_resident(cfg)
+            fired += ctx.fail_chunk_reserve(-1) < 0
+            assert align_key(got) == align_key(base_al), nth
+            assert np.array_equal(got["viterbi"], base_al["viterbi"]), nth
+        assert fired >= 6, fired                          # (the late ones too: alignment records, run lists)
+        fired = 0
+        for nth in (0, 2, 5, 9, 13, 16, 19):
+            ctx.fail_chunk_reserve(nth)
+            got = ctx.count_resident(cfg)
+            fired += ctx.fail_chunk_reserve(-1) < 0
+            assert np.array_equal(words(got), words(base_ct)), nth
+        assert fired >= 5, fired
+        # three contexts at once, a budget that forces splits of the big buffer too, failures injected while they run
+        for c in ctxs:
+            c.set_memory_budget(8 << 20)
+        ctx.fail_chunk_reserve(5)
+        with ThreadPoolExecutor(3) as ex:
+            res = list(ex.map(lambda c: (c.align_resident(cfg), c.count_resident(cfg)), ctxs))
+        assert ctx.fail_chunk_reserve(-1) < 0
+        for al, ct in res:
+            assert align_key(al) == align_key(base_al) and np.array_equal(words(ct), words(base_ct))
+    finally:
+        ctx.fail_chunk_reserve(-1)
+        for c in ctxs:
+            c.set_memory_budget(0)
+        for c in others:
+            c.close()

@@ -283,3 +283,29 @@ def test_row_prefilter_index_and_item_list_variants_agree(ctx):
             assert np.array_equal(got["hits"][cols], base["hits"][cols]) and np.array_equal(got["runs"], base["runs"])
     finally:
         ctx.set_debug_flags(0)
+
+
+def test_rows_survive_a_secondary_buffer_that_does_not_fit(ctx):
+    """The overlap path's per-chunk buffers (unit tables, slot list, item list, alignment records, run lists) split the chunk when
+    they cannot be had, like the traceback budget does (tests/test_gpu_align.py has the align / count side): same hits."""
+    import quaff_amd as Q
+    rng = np.random.default_rng(517)
+    reads = overlapping_reads(rng, 4000, 40, 250)
+    seqs = reads + [r.revcomp() for r in reads]
+    ctx.upload_reads([s.seq for s in seqs], [s.qual for s in seqs])
+    cfg = Q.DPConfig(kmer_threshold=14)
+    ctx.set_score_threshold(0.0)
+    cols = ["x", "y", "viterbi", "score", "x_start", "x_end", "y_start", "y_end", "n_runs"]
+    base = ctx.overlap_rows(40, 0, 39, cfg)
+    fired = 0
+    try:
+        for nth in (0, 2, 6, 11, 14, 16, 18, 21, 24):
+            ctx.fail_chunk_reserve(nth)
+            got = ctx.overlap_rows(40, 0, 39, cfg)
+            fired += ctx.fail_chunk_reserve(-1) < 0
+            for k in ("n_pairs", "n_finite", "total_cells", "total_diagonals", "result_checksum"):
+                assert got[k] == base[k], (nth, k)
+            assert np.array_equal(got["hits"][cols], base["hits"][cols]) and np.array_equal(got["runs"], base["runs"]), nth
+        assert fired >= 6, fired
+    finally:
+        ctx.fail_chunk_reserve(-1)
